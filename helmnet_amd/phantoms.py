@@ -1,0 +1,66 @@
+"""Synthetic sound-speed (SoS) maps for tests and benchmarks (pure numpy, host side).
+
+The paper's test set is a Google-Drive download that is not available offline,
+so the benchmark inputs are regenerated from the *distribution* the reference
+draws its training/test maps from: background 1.0 plus one closed harmonic
+ring ("skull") of value 1.5..2.0 and thickness 2..9 px
+(reference helmnet/dataloaders.py:115-156, ``EllipsesDataset._make_ellipsoid``;
+that code rasterises with cv2.polylines, here the curve is densely sampled and
+stamped with a disc of the same thickness -- cv2 is not needed).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def ring_sos(n: int, rng: np.random.Generator) -> np.ndarray:
+    """One [n, n] float32 SoS map: background 1.0 + a random harmonic ring."""
+    avg = np.array([1.0, 0.0, 0.0, 0.0])
+    std = np.array([0.1, 0.05, 0.025, 0.01])
+    a_x = avg + rng.standard_normal(4) * std
+    a_y = avg + rng.standard_normal(4) * std
+    ph_x = rng.standard_normal(4) * (np.pi / 16)
+    ph_y = rng.standard_normal(4) * (np.pi / 16)
+    t = np.linspace(0.0, 2 * np.pi, num=max(360, 8 * n), endpoint=True)
+    x = sum(np.sin(t * (i + 1) + ph_x[i]) * a_x[i] for i in range(4))
+    y = sum(np.cos(t * (i + 1) + ph_y[i]) * a_y[i] for i in range(4))
+    x = (x + 2) / 4 * n  # column coordinate (cv2 point order is (x, y))
+    y = (y + 2) / 4 * n  # row coordinate
+    thickness = int(2 + rng.random() * 8)
+    boost = 0.5 + rng.random() * 0.5
+    img = np.zeros((n, n), np.float32)
+    r = thickness / 2.0
+    k = int(np.ceil(r))
+    cx, cy = np.rint(x).astype(np.int64), np.rint(y).astype(np.int64)
+    for dy in range(-k, k + 1):
+        for dx in range(-k, k + 1):
+            if dx * dx + dy * dy <= r * r + 0.25:
+                yy, xx = cy + dy, cx + dx
+                ok = (yy >= 0) & (yy < n) & (xx >= 0) & (xx < n)
+                img[yy[ok], xx[ok]] = 1.0
+    return (1.0 + img * boost).astype(np.float32)
+
+
+def ring_sos_batch(n: int, batch: int, seed: int = 0) -> np.ndarray:
+    """[batch, 1, n, n] float32 ring phantoms (BASELINE.json config 2 inputs)."""
+    rng = np.random.default_rng(seed)
+    return np.stack([ring_sos(n, rng) for _ in range(batch)])[:, None]
+
+
+def readme_sos(n: int = 256) -> np.ndarray:
+    """[1, 1, 256, 256] map of the reference README / test.py:17-18 example:
+    ones with a rectangle whose speed ramps linearly from 2 down to 1."""
+    assert n == 256
+    sos = np.ones((n, n), np.float32)
+    sos[100:170, 30:240] = np.tile(np.linspace(2, 1, 210), (70, 1)).astype(np.float32)
+    return sos[None, None]
+
+
+def smooth_random_sos(n: int, batch: int, seed: int = 1) -> np.ndarray:
+    """[batch, 1, n, n]: 1 + U(0,1) blurred with an 8x8 box (values stay in [1, 2]);
+    BASELINE.json config 3 inputs."""
+    rng = np.random.default_rng(seed)
+    u = rng.random((batch, n + 7, n + 7), dtype=np.float32)
+    c = np.cumsum(np.cumsum(np.pad(u, ((0, 0), (1, 0), (1, 0))), axis=1), axis=2)
+    box = (c[:, 8:, 8:] - c[:, :-8, 8:] - c[:, 8:, :-8] + c[:, :-8, :-8]) / 64.0
+    return (1.0 + box[:, None, :n, :n]).astype(np.float32)

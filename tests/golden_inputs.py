@@ -1,0 +1,30 @@
+"""Deterministic inputs shared by tests/golden/make_golden.py and the parity tests.
+
+``numpy.random.default_rng`` (PCG64) streams are stable across numpy releases,
+so the inputs of the teacher-forced golden cases are re-created here from
+their seeds instead of being committed.
+"""
+import numpy as np
+
+from helmnet_amd.phantoms import readme_sos, ring_sos_batch  # noqa: F401 (re-exported)
+
+
+def state_len(n: int, depth: int = 4) -> int:
+    return sum((n // 2 ** d) ** 2 for d in range(depth))
+
+
+def teacher_inputs(n: int, b: int, seed: int):
+    """White-noise wavefield / residual / hidden state + random SoS in [1, 2].
+
+    White noise excites every spatial frequency, so it is the harshest input
+    for the spectral operator; magnitudes are those the solver sees
+    (|wf| ~ 1, 1e3*|res| ~ 5, |state| ~ 1).
+    """
+    rng = np.random.default_rng(seed)
+    f32 = np.float32
+    return {
+        "wf": (0.5 * rng.standard_normal((b, 2, n, n))).astype(f32),
+        "res": (5e-3 * rng.standard_normal((b, 2, n, n))).astype(f32),
+        "states": (0.5 * rng.standard_normal((b, 2, state_len(n)))).astype(f32),
+        "sos": (1.0 + rng.random((b, 1, n, n))).astype(f32),
+    }
