@@ -1,0 +1,81 @@
+"""ctypes binding of libhelmnet_hip.so (C ABI: include/helmnet_hip.h).
+
+There is deliberately NO fallback: if the shared object is missing or cannot be loaded the
+import of the product path raises, and every compute entry point of the package goes through
+this module.  ``import torch`` must come first so that the HIP runtime already resident in the
+process (torch's ``libamdhip64.so.7``) is the one the library binds to -- streams and device
+pointers are then shared with PyTorch.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must be imported before the library is loaded, see above)
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhelmnet_hip.so")
+_lib = None
+
+HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2}
+
+# name -> (restype, argtypes); every symbol include/helmnet_hip.h declares
+SYMBOLS = {
+    "hn_abi_version": (c_int, []),
+    "hn_create": (c_int, [POINTER(c_void_p), c_int]),
+    "hn_destroy": (None, [c_void_p]),
+    "hn_last_error": (c_char_p, [c_void_p]),
+    "hn_weight_count": (c_size_t, [c_int, c_int, c_int]),
+    "hn_load_weights": (c_int, [c_void_p, POINTER(c_float), c_size_t, c_int, c_int, c_int, c_int]),
+    "hn_set_domain": (c_int, [c_void_p, c_int, c_int, c_float, c_float]),
+    "hn_get_sigmas": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "hn_state_len": (c_int64, [c_void_p]),
+    "hn_reserve": (c_int, [c_void_p, c_int]),
+    "hn_laplacian": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "hn_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "hn_rmse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "hn_unet": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "hn_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+class HelmnetHipError(RuntimeError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise HelmnetHipError(
+            f"{_LIB_PATH} is missing: build it with `python -m helmnet_amd.build` "
+            "(hipcc --offload-arch=gfx950).  helmnet_amd has no CPU / PyTorch fallback."
+        )
+    lib = ctypes.CDLL(_LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hn_abi_version() != 1:
+        raise HelmnetHipError(f"ABI version mismatch: library reports {lib.hn_abi_version()}, binding expects 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, ctx=None, what: str = ""):
+    if rc == 0:
+        return
+    msg = load().hn_last_error(ctx)
+    text = msg.decode() if msg else "unknown error"
+    if rc == -3:
+        raise NotImplementedError(f"{what}: {text}")
+    if rc == -1:
+        raise ValueError(f"{what}: {text}")
+    raise HelmnetHipError(f"{what} failed (status {rc}): {text}")

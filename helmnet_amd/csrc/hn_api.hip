@@ -1,0 +1,314 @@
+// C ABI of libhelmnet_hip.so (see include/helmnet_hip.h): context, weight re-packing, workspace,
+// and the fused solver loop.  gfx950 only.
+#include <cmath>
+#include <cstring>
+
+#include "hn_internal.h"
+
+namespace hn {
+
+static thread_local std::string g_err;
+
+void set_global_error(const char* msg) { g_err = msg; }
+
+int fail(hn_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_err = buf;
+    return code;
+}
+
+namespace {
+
+constexpr size_t dc_count(int cin, int cm, int co) { return (size_t)cm * cin * 9 + cm + 1 + (size_t)co * cm * 9 + co; }
+constexpr size_t k8_count() { return (size_t)kFeat * kFeat * 64 + kFeat; }
+
+// [cout][cin][kh][kw] -> [cin][kh][kw][cout]
+void repack_oihw(const float* src, float* dst, int co, int ci, int kk) {
+    for (int o = 0; o < co; ++o)
+        for (int i = 0; i < ci; ++i)
+            for (int t = 0; t < kk; ++t) dst[((size_t)i * kk + t) * co + o] = src[((size_t)o * ci + i) * kk + t];
+}
+// ConvTranspose2d weight [cin][cout][kh][kw] -> [cin][kh][kw][cout]
+void repack_iohw(const float* src, float* dst, int ci, int co, int kk) {
+    for (int i = 0; i < ci; ++i)
+        for (int o = 0; o < co; ++o)
+            for (int t = 0; t < kk; ++t) dst[((size_t)i * kk + t) * co + o] = src[((size_t)i * co + o) * kk + t];
+}
+
+struct Packer {
+    const float* src;
+    std::vector<float>& dst;
+    float* dev;
+    size_t pos = 0;
+    DcW dc(int cin, int cm, int co) {
+        DcW w;
+        repack_oihw(src + pos, dst.data() + pos, cm, cin, 9);
+        w.w1 = dev + pos; pos += (size_t)cm * cin * 9;
+        std::memcpy(dst.data() + pos, src + pos, sizeof(float) * cm);
+        w.b1 = dev + pos; pos += cm;
+        dst[pos] = src[pos];
+        w.slope = dev + pos; pos += 1;
+        repack_oihw(src + pos, dst.data() + pos, co, cm, 9);
+        w.w2 = dev + pos; pos += (size_t)co * cm * 9;
+        std::memcpy(dst.data() + pos, src + pos, sizeof(float) * co);
+        w.b2 = dev + pos; pos += co;
+        return w;
+    }
+    K8W k8(bool transposed) {
+        K8W w;
+        if (transposed) repack_iohw(src + pos, dst.data() + pos, kFeat, kFeat, 64);
+        else repack_oihw(src + pos, dst.data() + pos, kFeat, kFeat, 64);
+        w.w = dev + pos; pos += (size_t)kFeat * kFeat * 64;
+        std::memcpy(dst.data() + pos, src + pos, sizeof(float) * kFeat);
+        w.b = dev + pos; pos += kFeat;
+        return w;
+    }
+};
+
+void free_workspace(hn_ctx* c) {
+    for (int d = 0; d <= kMaxDepth; ++d) {
+        hipFree(c->buf_a[d]); c->buf_a[d] = nullptr;
+        hipFree(c->buf_y[d]); c->buf_y[d] = nullptr;
+        if (d < kMaxDepth) { hipFree(c->buf_o[d]); c->buf_o[d] = nullptr; }
+    }
+    hipFree(c->st_tmp); c->st_tmp = nullptr;
+    c->cap_batch = 0;
+}
+
+int check_ready(hn_ctx* ctx, int batch) {
+    if (!ctx) return HN_ERR_ARG;
+    if (!ctx->have_weights) return fail(ctx, HN_ERR_STATE, "hn_load_weights has not been called");
+    if (ctx->tab.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
+    if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
+    if (ctx->tab.n % (1 << ctx->depth) != 0)
+        return fail(ctx, HN_ERR_ARG, "domain size %d is not divisible by 2^depth = %d", ctx->tab.n, 1 << ctx->depth);
+    return HN_OK;
+}
+
+__global__ void k_sumsq(const float* __restrict__ x, float* __restrict__ out, long per_sample) {
+    const int b = blockIdx.y;
+    const float* p = x + (long)b * per_sample;
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (long)gridDim.x * blockDim.x) s += p[i] * p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&out[b], s);
+}
+__global__ void k_rmse_finalize(float* __restrict__ v, int count, float inv_n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) v[i] = sqrtf(v[i] * inv_n);
+}
+
+}  // namespace
+}  // namespace hn
+
+using namespace hn;
+
+extern "C" {
+
+int hn_abi_version(void) { return HN_ABI_VERSION; }
+
+const char* hn_last_error(const hn_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int hn_create(hn_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, HN_ERR_ARG, "hn_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return fail(nullptr, HN_ERR_HIP, "hn_create: no HIP device available (%s)", hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) return fail(nullptr, HN_ERR_ARG, "hn_create: device %d of %d", device_id, count);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+        return fail(nullptr, HN_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, HN_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(nullptr, HN_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    hn_ctx* c = new (std::nothrow) hn_ctx();
+    if (!c) return fail(nullptr, HN_ERR_NOMEM, "out of host memory");
+    c->device = device_id;
+    *out = c;
+    return HN_OK;
+}
+
+void hn_destroy(hn_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    free_workspace(ctx);
+    spec_free(ctx->tab);
+    hipFree(ctx->wdev);
+    delete ctx;
+}
+
+size_t hn_weight_count(int features, int depth, int state_ch) {
+    if (features != kFeat || state_ch != kState || depth < 1 || depth > kMaxDepth) return 0;
+    size_t n = dc_count(kInCh, kFeat, kFeat);
+    n += (size_t)depth * (dc_count(kFeat + kState, kFeat, kFeat) + k8_count() + dc_count(kFeat + kState, kState, kState));
+    n += (size_t)depth * dc_count(2 * kFeat, kFeat, kFeat) + dc_count(kFeat, kFeat, kFeat);
+    n += (size_t)depth * k8_count();
+    n += (size_t)2 * kFeat + 2;
+    return n;
+}
+
+int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int features, int depth, int state_ch, int act_kind) {
+    if (!ctx || !blob) return fail(ctx, HN_ERR_ARG, "hn_load_weights: NULL argument");
+    if (features != kFeat || state_ch != kState)
+        return fail(ctx, HN_ERR_UNSUPPORTED, "only features=8, state_channels=2 are implemented (got %d, %d)", features, state_ch);
+    if (depth < 1 || depth > kMaxDepth) return fail(ctx, HN_ERR_UNSUPPORTED, "depth %d outside [1, %d]", depth, kMaxDepth);
+    if (act_kind != HN_ACT_PRELU && act_kind != HN_ACT_RELU && act_kind != HN_ACT_LEAKYRELU)
+        return fail(ctx, HN_ERR_UNSUPPORTED, "activation kind %d is not implemented (prelu / relu / leakyrelu only)", act_kind);
+    const size_t want = hn_weight_count(features, depth, state_ch);
+    if (n_floats != want) return fail(ctx, HN_ERR_ARG, "weight blob has %zu floats, expected %zu", n_floats, want);
+    HN_HIP(ctx, hipSetDevice(ctx->device));
+    hipFree(ctx->wdev);
+    ctx->wdev = nullptr;
+    HN_HIP(ctx, hipMalloc((void**)&ctx->wdev, want * sizeof(float)));
+    std::vector<float> packed(want);
+    Packer p{blob, packed, ctx->wdev};
+    ctx->inc = p.dc(kInCh, kFeat, kFeat);
+    for (int d = 0; d < depth; ++d) {
+        ctx->sig[d] = p.dc(kFeat + kState, kFeat, kFeat);
+        ctx->down[d] = p.k8(false);
+        ctx->st[d] = p.dc(kFeat + kState, kState, kState);
+    }
+    for (int d = 0; d <= depth; ++d) ctx->dec[d] = p.dc(d < depth ? 2 * kFeat : kFeat, kFeat, kFeat);
+    for (int d = 0; d < depth; ++d) ctx->up[d] = p.k8(true);
+    repack_oihw(blob + p.pos, packed.data() + p.pos, 2, kFeat, 1);  // outc [2][8] -> [8][2]
+    ctx->outc_w = ctx->wdev + p.pos; p.pos += 2 * kFeat;
+    packed[p.pos] = blob[p.pos]; packed[p.pos + 1] = blob[p.pos + 1];
+    ctx->outc_b = ctx->wdev + p.pos; p.pos += 2;
+    if (p.pos != want) return fail(ctx, HN_ERR_ARG, "internal: packed %zu of %zu floats", p.pos, want);
+    HN_HIP(ctx, hipMemcpy(ctx->wdev, packed.data(), want * sizeof(float), hipMemcpyHostToDevice));
+    if (ctx->have_weights && ctx->depth != depth) free_workspace(ctx);
+    ctx->depth = depth;
+    ctx->have_weights = true;
+    if (ctx->tab.n) {  // state layout depends on depth
+        ctx->state_len = 0;
+        for (int d = 0; d < depth; ++d) { ctx->state_off[d] = ctx->state_len; ctx->state_len += (int64_t)(ctx->tab.n >> d) * (ctx->tab.n >> d); }
+    }
+    return HN_OK;
+}
+
+int hn_set_domain(hn_ctx* ctx, int n, int pml, float sigma_max, float k) {
+    if (!ctx) return HN_ERR_ARG;
+    HN_HIP(ctx, hipSetDevice(ctx->device));
+    if (n % 16 != 0) return fail(ctx, HN_ERR_ARG, "domain size %d must be divisible by 16", n);
+    if (!(k > 0.f) || !(sigma_max >= 0.f)) return fail(ctx, HN_ERR_ARG, "k must be > 0 and sigma_max >= 0");
+    if (n != ctx->tab.n) free_workspace(ctx);
+    int rc = spec_build(ctx, n, pml, (double)sigma_max, (double)k);
+    if (rc != HN_OK) return rc;
+    const int depth = ctx->have_weights ? ctx->depth : 4;
+    ctx->state_len = 0;
+    for (int d = 0; d < depth; ++d) { ctx->state_off[d] = ctx->state_len; ctx->state_len += (int64_t)(n >> d) * (n >> d); }
+    return HN_OK;
+}
+
+int hn_get_sigmas(hn_ctx* ctx, float* out, void* stream) {
+    if (!ctx || !out) return fail(ctx, HN_ERR_ARG, "hn_get_sigmas: NULL argument");
+    if (ctx->tab.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
+    HN_HIP(ctx, hipMemcpyAsync(out, ctx->tab.sigmas, sizeof(float) * 2 * ctx->tab.n * ctx->tab.n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return HN_OK;
+}
+
+int64_t hn_state_len(const hn_ctx* ctx) { return ctx ? ctx->state_len : 0; }
+
+int hn_reserve(hn_ctx* ctx, int max_batch) {
+    int rc = check_ready(ctx, max_batch);
+    if (rc != HN_OK) return rc;
+    if (max_batch <= ctx->cap_batch) return HN_OK;
+    HN_HIP(ctx, hipSetDevice(ctx->device));
+    HN_HIP(ctx, hipDeviceSynchronize());  // nothing may still be using the old workspace
+    free_workspace(ctx);
+    const int n = ctx->tab.n, depth = ctx->depth;
+    for (int d = 0; d <= depth; ++d) {
+        const size_t bytes = sizeof(float) * (size_t)max_batch * kFeat * (n >> d) * (n >> d);
+        HN_HIP(ctx, hipMalloc((void**)&ctx->buf_a[d], bytes));
+        if (d < depth) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_o[d], bytes));
+        if (d > 0) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_y[d], bytes));
+    }
+    HN_HIP(ctx, hipMalloc((void**)&ctx->st_tmp, sizeof(float) * (size_t)max_batch * kState * ctx->state_len));
+    ctx->cap_batch = max_batch;
+    return HN_OK;
+}
+
+int hn_laplacian(hn_ctx* ctx, const float* wf, float* out, int batch, void* stream) {
+    if (!ctx || !wf || !out) return fail(ctx, HN_ERR_ARG, "hn_laplacian: NULL argument");
+    if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
+    return spec_apply(ctx, wf, out, nullptr, nullptr, 1, batch, nullptr, (hipStream_t)stream);
+}
+
+int hn_residual(hn_ctx* ctx, const float* wf, const float* k_sq, const float* src, int src_batch, float* res, int batch, void* stream) {
+    if (!ctx || !wf || !k_sq || !src || !res) return fail(ctx, HN_ERR_ARG, "hn_residual: NULL argument");
+    if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
+    if (src_batch != 1 && src_batch != batch)
+        return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
+    return spec_apply(ctx, wf, res, k_sq, src, src_batch, batch, nullptr, (hipStream_t)stream);
+}
+
+int hn_rmse(hn_ctx* ctx, const float* res, float* rmse, int batch, void* stream) {
+    if (!ctx || !res || !rmse) return fail(ctx, HN_ERR_ARG, "hn_rmse: NULL argument");
+    if (ctx->tab.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
+    if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
+    hipStream_t s = (hipStream_t)stream;
+    const long per = 2L * ctx->tab.n * ctx->tab.n;
+    HN_HIP(ctx, hipMemsetAsync(rmse, 0, sizeof(float) * batch, s));
+    hipLaunchKernelGGL(k_sumsq, dim3(32, batch), dim3(256), 0, s, res, rmse, per);
+    hipLaunchKernelGGL(k_rmse_finalize, dim3((batch + 255) / 256), dim3(256), 0, s, rmse, batch, 1.0f / (float)per);
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states_out, float* d_out, int batch, void* stream) {
+    if (!ctx || !in6 || !states_in || !states_out || !d_out) return fail(ctx, HN_ERR_ARG, "hn_unet: NULL argument");
+    if (states_in == states_out) return fail(ctx, HN_ERR_ARG, "hn_unet: states_in must not alias states_out");
+    int rc = check_ready(ctx, batch);
+    if (rc != HN_OK) return rc;
+    if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
+    const long plane = (long)ctx->tab.n * ctx->tab.n;
+    const Src wf{in6, kInCh * plane, plane, 1.f};
+    const Src res{in6 + 2 * plane, kInCh * plane, plane, 1.f};
+    const Src sig{in6 + 4 * plane, kInCh * plane, plane, 1.f};
+    return unet_forward(ctx, wf, res, sig, states_in, states_out, d_out, nullptr, batch, (hipStream_t)stream);
+}
+
+int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq, const float* src, int src_batch, int batch,
+            int n_iter, float* res_hist, float* wf_hist, float* st_hist, float* rmse_hist, void* stream) {
+    if (!ctx || !wf || !res || !states || !k_sq || !src) return fail(ctx, HN_ERR_ARG, "hn_step: NULL argument");
+    if (n_iter < 0) return fail(ctx, HN_ERR_ARG, "n_iter must be >= 0");
+    if (src_batch != 1 && src_batch != batch)
+        return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
+    int rc = check_ready(ctx, batch);
+    if (rc != HN_OK) return rc;
+    if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const long plane = (long)ctx->tab.n * ctx->tab.n;
+    const size_t field_bytes = sizeof(float) * (size_t)batch * 2 * plane;
+    const size_t state_bytes = sizeof(float) * (size_t)batch * kState * ctx->state_len;
+    const Src s_wf{wf, 2 * plane, plane, 1.f};
+    const Src s_res{res, 2 * plane, plane, 1e3f};               // 1e3 * residual (hybridnet.py:566)
+    const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};            // sigmas.repeat(B) without the copy
+    if (rmse_hist && n_iter > 0) HN_HIP(ctx, hipMemsetAsync(rmse_hist, 0, sizeof(float) * (size_t)n_iter * batch, s));
+    for (int it = 0; it < n_iter; ++it) {
+        float* st_in = (it & 1) ? ctx->st_tmp : states;
+        float* st_out = (it & 1) ? states : ctx->st_tmp;
+        if ((rc = unet_forward(ctx, s_wf, s_res, s_sig, st_in, st_out, nullptr, wf, batch, s)) != HN_OK) return rc;
+        if ((rc = spec_apply(ctx, wf, res, k_sq, src, src_batch, batch, rmse_hist ? rmse_hist + (size_t)it * batch : nullptr, s)) != HN_OK) return rc;
+        if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + (size_t)it * batch * 2 * plane, res, field_bytes, hipMemcpyDeviceToDevice, s));
+        if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf_hist + (size_t)it * batch * 2 * plane, wf, field_bytes, hipMemcpyDeviceToDevice, s));
+        if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + (size_t)it * batch * kState * ctx->state_len, st_out, state_bytes, hipMemcpyDeviceToDevice, s));
+    }
+    if (n_iter & 1) HN_HIP(ctx, hipMemcpyAsync(states, ctx->st_tmp, state_bytes, hipMemcpyDeviceToDevice, s));
+    if (rmse_hist && n_iter > 0) {
+        const int count = n_iter * batch;
+        hipLaunchKernelGGL(k_rmse_finalize, dim3((count + 255) / 256), dim3(256), 0, s, rmse_hist, count, 1.0f / (float)(2 * plane));
+        HN_HIP(ctx, hipGetLastError());
+    }
+    return HN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// Internal declarations shared by the translation units of libhelmnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "helmnet_hip.h"
+
+namespace hn {
+
+constexpr int kFeat = 8;    // feature channels of the shipped net (hparams.features)
+constexpr int kState = 2;   // hidden-state channels per level (hparams.state_channels)
+constexpr int kInCh = 6;    // [wf_re, wf_im, 1e3*res_re, 1e3*res_im, sigma_x, sigma_y]
+constexpr int kMaxDepth = 6;
+
+// A read-only planar tensor view: element (b, c, y, x) at p[b*sb + c*sc + y*W + x].
+struct Src {
+    const float* p;
+    long sb;      // sample stride (0 broadcasts over the batch)
+    long sc;      // channel stride
+    float scale;  // multiplied in while staging (the reference's 1e3 * residual)
+};
+struct Dst {
+    float* p;
+    long sb;
+    long sc;
+};
+
+// Weights of one DoubleConv, re-packed for scalar (SGPR) broadcast loads:
+//   w1 [cin][3][3][cmid], b1 [cmid], slope (1 float), w2 [cmid][3][3][cout], b2 [cout]
+struct DcW {
+    const float* w1;
+    const float* b1;
+    const float* slope;
+    const float* w2;
+    const float* b2;
+};
+// 8x8 stride-2 conv / transposed conv weights re-packed [cin][8][8][cout], bias [cout].
+struct K8W {
+    const float* w;
+    const float* b;
+};
+
+struct SpecTables {
+    int n = 0;
+    bool pow2 = false;
+    // pow2 path (all device pointers)
+    float2* tw = nullptr;      // exp(-2 pi i m / n), m in [0, n)
+    float* k1 = nullptr;       // fp32 wavenumber grid, Nyquist at -pi
+    float* k2 = nullptr;       // -(k1*k1) evaluated in fp32 like the reference
+    float2* a = nullptr;       // PML first-derivative coefficient  (-gamma' / gamma^3)
+    float2* b = nullptr;       // PML second-derivative coefficient (1 / gamma^2)
+    // dense fallback (n not a power of two): complex n x n operator, stored transposed
+    float2* dense_t = nullptr; // dense_t[m*n + j] = M[j][m]
+    float* sigmas = nullptr;   // [2, n, n]
+};
+
+}  // namespace hn
+
+struct hn_ctx {
+    int device = 0;
+    std::string err;
+    // network
+    bool have_weights = false;
+    int depth = 0;
+    float* wdev = nullptr;  // all re-packed weights
+    hn::DcW inc{}, sig[hn::kMaxDepth]{}, st[hn::kMaxDepth]{}, dec[hn::kMaxDepth + 1]{};
+    hn::K8W down[hn::kMaxDepth]{}, up[hn::kMaxDepth]{};
+    const float* outc_w = nullptr;  // [8][2]
+    const float* outc_b = nullptr;  // [2]
+    // domain
+    hn::SpecTables tab;
+    int64_t state_len = 0;
+    int64_t state_off[hn::kMaxDepth]{};
+    // workspace
+    int cap_batch = 0;
+    float* buf_a[hn::kMaxDepth + 1]{};  // x_d, later reused for the upsampled tensor u_d
+    float* buf_o[hn::kMaxDepth]{};      // out_d (skip connections)
+    float* buf_y[hn::kMaxDepth + 1]{};  // decoder outputs y_d
+    float* st_tmp = nullptr;            // second flat state buffer for hn_step ping-pong
+    float* sumsq = nullptr;             // [cap_iter * cap_batch] scratch for the RMSE history
+    size_t sumsq_cap = 0;
+};
+
+namespace hn {
+
+int fail(hn_ctx* ctx, int code, const char* fmt, ...);
+void set_global_error(const char* msg);
+
+#define HN_HIP(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return hn::fail((ctx), HN_ERR_HIP, "%s failed: %s (%s:%d)", #call,              \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                     \
+    } while (0)
+
+// ---- spectral (hn_spectral.hip) ----
+int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k);
+void spec_free(SpecTables& t);
+// out = L(wf) [+ ksq*wf - src]; `accum_sumsq` (nullable) receives sum over (c,h,w) of out^2 per sample.
+int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, int src_batch,
+               int batch, float* accum_sumsq, hipStream_t s);
+
+// ---- unet (hn_unet.hip) ----
+// One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the
+// wavefield is updated in place (wf += d / 1e3) by the last kernel; if d_out != nullptr d is stored.
+int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
+                 float* d_out, float* wf_update, int batch, hipStream_t s);
+
+}  // namespace hn

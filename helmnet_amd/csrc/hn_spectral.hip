@@ -1,0 +1,380 @@
+// Spectral Laplacian with PML + Helmholtz residual for gfx950.
+//
+// Reference semantics (helmnet/spectral.py:31-79, hybridnet.py:544-556):
+//     L(u) = ax * F^-1[ i kx F u ] + bx * F^-1[ -kx^2 F u ] + ay * F^-1[ i ky F u ] + by * F^-1[ -ky^2 F u ]
+//     r    = L(u) + k_sq * u - src
+// with F the 2-D c2c FFT.  kx and (ax, bx) vary only along W, ky and (ay, by) only along H
+// (spectral.py:130-139, 312, 329), so every term is a 1-D operator along one axis: the
+// 2-D transform pair of the reference cancels along the other axis.  Instead of five 2-D FFTs
+// (~60 plane passes of HBM traffic) this file runs two kernels:
+//     k_spec_cols : per column  1 forward + 2 inverse length-N FFTs held in LDS -> ay*dy + by*ddy
+//     k_spec_rows : per row     the same along W, adds the column part, k_sq*u - src, and the
+//                   per-sample sum of squares used for the residual RMSE (hybridnet.py:295-297)
+// Both keep the whole 1-D transform in LDS (Stockham radix-4, optional final radix-2), one
+// 64-lane wavefront per length-256 row.  Domains whose size is not a power of two (e.g. the
+// 96^2 training size) use a dense complex N x N operator instead (same maths as
+// matlab/spectral_gmres_solver.m:50-82 builds explicitly).
+#include <cmath>
+#include <complex>
+
+#include "hn_internal.h"
+
+namespace hn {
+namespace {
+
+struct SpecPtrs {
+    const float2* tw;
+    const float* k1;
+    const float* k2;
+    const float2* a;
+    const float2* b;
+};
+
+__device__ __forceinline__ float2 cmul(float2 x, float2 y) {
+    return make_float2(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x);
+}
+
+// In-LDS Stockham FFT of length N distributed over N/4 threads.  On entry thread j holds
+// x[j + t*N/4] in v[t]; on exit it holds X[j + t*N/4] (natural order).  Element idx of this
+// transform lives at buf[idx * STRIDE].  INV selects the conjugate (unnormalised) transform.
+template <int N, int STRIDE, bool INV>
+__device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, const float2* __restrict__ tw) {
+    constexpr int T = N / 4;
+#pragma unroll
+    for (int ns = 1; ns * 4 <= N; ns *= 4) {
+        const int k = j & (ns - 1);
+        if (ns > 1) {
+            const int idx = k * (N / (4 * ns));
+            float2 w1 = tw[idx], w2 = tw[2 * idx], w3 = tw[3 * idx];
+            if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            v[1] = cmul(v[1], w1);
+            v[2] = cmul(v[2], w2);
+            v[3] = cmul(v[3], w3);
+        }
+        const float2 a0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y);
+        const float2 a1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
+        const float2 a2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
+        const float2 a3 = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
+        // multiply a3 by -i (forward) or +i (inverse)
+        const float2 r3 = INV ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);
+        const int j0 = ((j - k) << 2) + k;
+        __syncthreads();  // everyone finished reading the previous stage
+        buf[(j0) * STRIDE] = make_float2(a0.x + a2.x, a0.y + a2.y);
+        buf[(j0 + ns) * STRIDE] = make_float2(a1.x + r3.x, a1.y + r3.y);
+        buf[(j0 + 2 * ns) * STRIDE] = make_float2(a0.x - a2.x, a0.y - a2.y);
+        buf[(j0 + 3 * ns) * STRIDE] = make_float2(a1.x - r3.x, a1.y - r3.y);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = buf[(j + t * T) * STRIDE];
+    }
+    // N = 2 * 4^m: one radix-2 stage; its operands are already in this thread's registers.
+    constexpr bool kOdd = (N == 32 || N == 128 || N == 512 || N == 2048);
+    if (kOdd) {
+        float2 wa = tw[j], wb = tw[j + T];
+        if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
+        const float2 p = cmul(v[2], wa), q = cmul(v[3], wb);
+        const float2 x0 = v[0], x1 = v[1];
+        v[0] = make_float2(x0.x + p.x, x0.y + p.y);
+        v[2] = make_float2(x0.x - p.x, x0.y - p.y);
+        v[1] = make_float2(x1.x + q.x, x1.y + q.y);
+        v[3] = make_float2(x1.x - q.x, x1.y - q.y);
+    }
+}
+
+// forward transform, two derivative multipliers, two inverse transforms, PML coefficients.
+// in: v[t] = u[j + t*T] along the axis;  out: acc[t] = (a*du + b*ddu)[j + t*T]
+template <int N, int STRIDE>
+__device__ __forceinline__ void axis_operator(float2 (&v)[4], float2 (&acc)[4], float2* buf, int j, const SpecPtrs& t) {
+    constexpr int T = N / 4;
+    fft_pass<N, STRIDE, false>(v, buf, j, t.tw);
+    float2 U[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        U[q] = v[q];
+        const float k = t.k1[j + q * T];
+        v[q] = make_float2(-U[q].y * k, U[q].x * k);  // (0, k) * U   (spectral.py:50, 281)
+    }
+    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc[q] = cmul(t.a[j + q * T], v[q]);
+        const float k2 = t.k2[j + q * T];
+        v[q] = make_float2(k2 * U[q].x, k2 * U[q].y);  // (-k^2, 0) * U (spectral.py:52, 283)
+    }
+    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
+    constexpr float inv_n = 1.0f / N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float2 d = cmul(t.b[j + q * T], v[q]);
+        acc[q] = make_float2((acc[q].x + d.x) * inv_n, (acc[q].y + d.y) * inv_n);
+    }
+}
+
+template <int N>
+struct RowCfg {
+    static constexpr int T = N / 4;
+    static constexpr int R0 = (256 / T) > 0 ? (256 / T) : 1;
+    static constexpr int R = R0 < N ? R0 : N;  // rows per block
+};
+
+// Column pass: out = ay*dy + by*ddy.  Block = C columns x N/4 butterfly threads; consecutive
+// threads own consecutive columns so each global access is a C*4-byte row segment.
+template <int N, int C>
+__global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict__ wf, float* __restrict__ out,
+                                                          SpecPtrs t) {
+    constexpr int T = N / 4;
+    __shared__ float2 buf[N * C];
+    const int c = threadIdx.x, j = threadIdx.y;
+    const int col = blockIdx.x * C + c;
+    const long plane = (long)N * N;
+    const float* pre = wf + (long)blockIdx.y * 2 * plane + col;
+    float2 v[4], acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long o = (long)(j + q * T) * N;
+        v[q] = make_float2(pre[o], pre[o + plane]);
+    }
+    axis_operator<N, C>(v, acc, buf + c, j, t);
+    float* po = out + (long)blockIdx.y * 2 * plane + col;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const long o = (long)(j + q * T) * N;
+        po[o] = acc[q].x;
+        po[o + plane] = acc[q].y;
+    }
+}
+
+// Row pass: out = [out +] ax*dx + bx*ddx [+ k_sq*u - src]; optional per-sample sum of squares.
+// FLAGS: 1 = add the partial result already in `out` (column pass), 2 = residual terms.
+template <int N>
+__global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
+    const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
+    const float* __restrict__ src, long src_sb, SpecPtrs t, int flags, float* __restrict__ sumsq) {
+    constexpr int T = RowCfg<N>::T, R = RowCfg<N>::R;
+    __shared__ float2 buf[N * R];
+    __shared__ float red[(T * R + 63) / 64];
+    const int j = threadIdx.x, ry = threadIdx.y;
+    const int row = blockIdx.x * R + ry, b = blockIdx.y;
+    const long plane = (long)N * N;
+    const long ro = (long)row * N;
+    const float* pre = wf + (long)b * 2 * plane + ro;
+    float2 u[4], v[4], acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        u[q] = make_float2(pre[j + q * T], pre[plane + j + q * T]);
+        v[q] = u[q];
+    }
+    axis_operator<N, 1>(v, acc, buf + ry * N, j, t);
+    float* po = out + (long)b * 2 * plane + ro;
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = j + q * T;
+        float re = acc[q].x, im = acc[q].y;
+        if (flags & 1) {
+            re += po[x];
+            im += po[plane + x];
+        }
+        if (flags & 2) {
+            const float kq = ksq[(long)b * plane + ro + x];
+            const float* ps = src + (long)b * src_sb + ro + x;
+            re = re + kq * u[q].x - ps[0];
+            im = im + kq * u[q].y - ps[plane];
+        }
+        po[x] = re;
+        po[plane + x] = im;
+        ss += re * re + im * im;
+    }
+    if (sumsq != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        const int tid = ry * T + j;
+        if ((tid & 63) == 0) red[tid >> 6] = ss;
+        __syncthreads();
+        if (tid == 0) {
+            float s = 0.f;
+            for (int w = 0; w < (T * R + 63) / 64; ++w) s += red[w];
+            atomicAdd(&sumsq[b], s);
+        }
+    }
+}
+
+// Dense fallback: one thread per pixel, both axes; mt[m*n + j] = M[j][m].
+__global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf, float* __restrict__ out,
+                                                    const float* __restrict__ ksq, const float* __restrict__ src,
+                                                    long src_sb, const float2* __restrict__ mt, int n, int flags,
+                                                    float* __restrict__ sumsq) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y, b = blockIdx.z;
+    const long plane = (long)n * n;
+    const float* pre = wf + (long)b * 2 * plane;
+    const float* pim = pre + plane;
+    float re = 0.f, im = 0.f;
+    if (x < n) {
+        for (int m = 0; m < n; ++m) {
+            const float2 mx = mt[(long)m * n + x];  // M[x][m]
+            const float2 my = mt[(long)m * n + y];  // M[y][m]
+            const float2 ux = make_float2(pre[(long)y * n + m], pim[(long)y * n + m]);
+            const float2 uy = make_float2(pre[(long)m * n + x], pim[(long)m * n + x]);
+            re += mx.x * ux.x - mx.y * ux.y + my.x * uy.x - my.y * uy.y;
+            im += mx.x * ux.y + mx.y * ux.x + my.x * uy.y + my.y * uy.x;
+        }
+        const long o = (long)y * n + x;
+        if (flags & 2) {
+            const float kq = ksq[(long)b * plane + o];
+            re = re + kq * pre[o] - src[(long)b * src_sb + o];
+            im = im + kq * pim[o] - src[(long)b * src_sb + plane + o];
+        }
+        out[(long)b * 2 * plane + o] = re;
+        out[(long)b * 2 * plane + plane + o] = im;
+    }
+    if (sumsq != nullptr) {
+        float ss = (x < n) ? re * re + im * im : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[b], ss);
+    }
+}
+
+template <int N>
+void launch_pow2(const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch,
+                 const SpecPtrs& p, bool resid, float* sumsq, hipStream_t s) {
+    constexpr int T = N / 4;
+    constexpr int C = (1024 / T) < 16 ? (1024 / T) : 16;
+    hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / C, batch), dim3(C, T), 0, s, wf, out, p);
+    constexpr int R = RowCfg<N>::R;
+    hipLaunchKernelGGL((k_spec_rows<N>), dim3(N / R, batch), dim3(T, R), 0, s, wf, out, ksq, src, src_sb, p,
+                       1 | (resid ? 2 : 0), sumsq);
+}
+
+template <typename T>
+int upload(hn_ctx* ctx, T** dst, const std::vector<T>& h) {
+    HN_HIP(ctx, hipMalloc((void**)dst, h.size() * sizeof(T)));
+    HN_HIP(ctx, hipMemcpy(*dst, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return HN_OK;
+}
+
+}  // namespace
+
+void spec_free(SpecTables& t) {
+    hipFree(t.tw); hipFree(t.k1); hipFree(t.k2); hipFree(t.a); hipFree(t.b); hipFree(t.dense_t); hipFree(t.sigmas);
+    t = SpecTables{};
+}
+
+// Host-side construction of every constant, float64 then cast -- the formulas of
+// spectral.py:126-127 (k grid), :298-363 (sigma, gamma, a = -gamma' / gamma^3, b = 1 / gamma^2).
+int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k) {
+    if (n < 16 || n > 2048) return fail(ctx, HN_ERR_ARG, "domain size %d outside [16, 2048]", n);
+    if (pml < 1 || 2 * pml > n) return fail(ctx, HN_ERR_ARG, "PML size %d does not fit domain %d", pml, n);
+    spec_free(ctx->tab);
+    SpecTables& t = ctx->tab;
+    t.n = n;
+    t.pow2 = (n & (n - 1)) == 0;
+    const double pi = 3.14159265358979323846;
+    // k grid: 2*pi*linspace(-0.5, 0.5, n, endpoint=False) rotated by n//2
+    std::vector<double> kd(n);
+    for (int i = 0; i < n; ++i) {
+        const int s = (i + n / 2) % n;
+        kd[i] = 2.0 * pi * (-0.5 + (double)s / n);
+    }
+    std::vector<float> k1(n), k2(n);
+    for (int i = 0; i < n; ++i) {
+        k1[i] = (float)kd[i];
+        k2[i] = -(k1[i] * k1[i]);  // fp32 square of the fp32 grid, as kx.pow(2) in the reference
+    }
+    std::vector<double> sigma(n, 0.0), sigp(n, 0.0);
+    for (int i = 0; i < pml; ++i) {
+        const double q = std::fabs(1.0 - (double)i / pml);
+        const double so = sigma_max * (q * q);
+        const double sp = -2.0 * sigma_max * (1.0 - (double)i / pml) / pml;
+        sigma[i] = so;
+        sigma[n - 1 - i] = so;
+        sigp[i] = sp;
+        sigp[n - 1 - i] = -sp;
+    }
+    std::vector<std::complex<double>> ca(n), cb(n);
+    std::vector<float2> fa(n), fb(n);
+    for (int i = 0; i < n; ++i) {
+        const std::complex<double> inv_gamma = 1.0 / (std::complex<double>(1.0, 0.0) + std::complex<double>(0.0, 1.0 / k) * sigma[i]);
+        const std::complex<double> gamma_prime = std::complex<double>(0.0, 1.0 / k) * sigp[i];
+        ca[i] = (-gamma_prime) * (inv_gamma * (inv_gamma * inv_gamma));
+        cb[i] = inv_gamma * inv_gamma;
+        fa[i] = make_float2((float)ca[i].real(), (float)ca[i].imag());
+        fb[i] = make_float2((float)cb[i].real(), (float)cb[i].imag());
+    }
+    std::vector<float> sig((size_t)2 * n * n);
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+            sig[(size_t)y * n + x] = (float)sigma[x];                  // sigma_x[i, j] = sigma[j]
+            sig[(size_t)n * n + (size_t)y * n + x] = (float)sigma[y];  // sigma_y[i, j] = sigma[i]
+        }
+    int rc;
+    if ((rc = upload(ctx, &t.sigmas, sig)) != HN_OK) return rc;
+    if (t.pow2) {
+        std::vector<float2> tw(n);
+        for (int m = 0; m < n; ++m) tw[m] = make_float2((float)std::cos(2.0 * pi * m / n), (float)-std::sin(2.0 * pi * m / n));
+        if ((rc = upload(ctx, &t.tw, tw)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.k1, k1)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.k2, k2)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.a, fa)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.b, fb)) != HN_OK) return rc;
+    } else {
+        // M[j][m] = (1/n) sum_p (a_j * i*k_p + b_j * k2_p) exp(2 pi i p (j - m) / n), k2_p = -(k_p^2)
+        std::vector<std::complex<double>> e(n);
+        for (int q = 0; q < n; ++q) e[q] = std::polar(1.0, 2.0 * pi * q / n);
+        // g1[d] = (1/n) sum_p i*k_p e[(p*d) mod n];  g2[d] = (1/n) sum_p k2_p e[(p*d) mod n], d = (j-m) mod n
+        std::vector<std::complex<double>> g1(n), g2(n);
+        for (int d = 0; d < n; ++d) {
+            std::complex<double> s1 = 0, s2 = 0;
+            for (int p = 0; p < n; ++p) {
+                const std::complex<double> w = e[(int)(((long)p * d) % n)];
+                s1 += std::complex<double>(0.0, (double)k1[p]) * w;
+                s2 += (double)k2[p] * w;
+            }
+            g1[d] = s1 / (double)n;
+            g2[d] = s2 / (double)n;
+        }
+        std::vector<float2> mt((size_t)n * n);
+        for (int j = 0; j < n; ++j)
+            for (int m = 0; m < n; ++m) {
+                const int d = ((j - m) % n + n) % n;
+                // use the fp32-rounded coefficients, as the reference multiplies by fp32 tables
+                const std::complex<double> aj((double)fa[j].x, (double)fa[j].y), bj((double)fb[j].x, (double)fb[j].y);
+                const std::complex<double> v = aj * g1[d] + bj * g2[d];
+                mt[(size_t)m * n + j] = make_float2((float)v.real(), (float)v.imag());
+            }
+        if ((rc = upload(ctx, &t.dense_t, mt)) != HN_OK) return rc;
+    }
+    return HN_OK;
+}
+
+int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, int src_batch,
+               int batch, float* accum_sumsq, hipStream_t s) {
+    const SpecTables& t = ctx->tab;
+    if (t.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
+    if (batch <= 0) return HN_OK;
+    const bool resid = ksq != nullptr;
+    const long plane = (long)t.n * t.n;
+    const long src_sb = (src_batch == 1) ? 0 : 2 * plane;
+    if (t.pow2) {
+        const SpecPtrs p{t.tw, t.k1, t.k2, t.a, t.b};
+        switch (t.n) {
+            case 16: launch_pow2<16>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 32: launch_pow2<32>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 64: launch_pow2<64>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 128: launch_pow2<128>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 256: launch_pow2<256>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 512: launch_pow2<512>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 1024: launch_pow2<1024>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 2048: launch_pow2<2048>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            default: return fail(ctx, HN_ERR_ARG, "unsupported power-of-two size %d", t.n);
+        }
+    } else {
+        hipLaunchKernelGGL(k_spec_dense, dim3((t.n + 255) / 256, t.n, batch), dim3(256), 0, s, wf, out, ksq, src,
+                           src_sb, t.dense_t, t.n, resid ? 2 : 0, accum_sumsq);
+    }
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+}  // namespace hn

@@ -1,0 +1,465 @@
+// HybridNet (stateful 4-level UNet, 8 feature channels) forward pass for gfx950.
+//
+// Reference: helmnet/architectures.py:439-465 (HybridNet.forward), :240-252 (EncoderBlock.forward),
+// :63-84 (DoubleConv = conv3x3 -> PReLU(one scalar slope) -> conv3x3), :209-211 (8x8 stride-2 down
+// conv, pad 3), :375-382 (8x8 stride-2 transposed conv, pad 3), :47-60 (1x1 out conv) and
+// hybridnet.py:564-570 (input concat [wf, 1e3*res, sigmas]; wf <- d/1e3 + wf).
+//
+// Design (fp32 exact, no library calls):
+//   * activations are planar fp32 [B, C, H, W]; channel concatenations are never materialised --
+//     a kernel reads its 2 or 3 sources in place (wf, 1e3*res and sigma for the input layer;
+//     signal + hidden state; upsampled + skip).
+//   * k_double_conv fuses conv3x3 -> PReLU -> conv3x3 (+ optionally the 1x1 out conv and the
+//     wavefield update) in one launch: the input tile with a 2-pixel halo is streamed through LDS
+//     two channels at a time (double buffered), the mid tensor with a 1-pixel halo stays in LDS.
+//   * every thread owns a 1x4 pixel strip and all output channels, so one LDS value feeds 24 FMAs;
+//     the weights are wave-uniform and arrive through scalar loads (SGPR operands of v_pk_fma_f32).
+//   * the 8x8 stride-2 conv and its transpose use the same scheme on 2 output pixels / one 2x4
+//     output patch per thread.
+#include "hn_internal.h"
+
+namespace hn {
+namespace {
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ------------------------------------------------------------------------------------------
+// Fused DoubleConv
+// ------------------------------------------------------------------------------------------
+template <int CA, int CB, int CC, int CM, int CO, int TW>
+struct DcCfg {
+    static constexpr int TH = 16;
+    static constexpr int CIN = CA + CB + CC;
+    static constexpr int IR = TH + 4;            // staged input rows   (halo 2)
+    static constexpr int PI = TW + 4;            // staged input pitch  (halo 2), multiple of 4
+    static constexpr int MR = TH + 2;            // mid rows            (halo 1)
+    static constexpr int S1 = cdiv(TW + 2, 4);   // conv1 strips per mid row
+    static constexpr int PM = S1 * 4;            // mid pitch
+    static constexpr int S2 = TW / 4;            // conv2 strips per output row
+    static constexpr int NT = cdiv(S1 * MR, 64) * 64;
+    static constexpr int PLANE = IR * PI;        // floats per staged channel
+    static constexpr int NL = cdiv(PLANE, NT);   // staged positions per thread (x2 channels)
+    static_assert(CA % 2 == 0 && CB % 2 == 0 && CC % 2 == 0, "sources are staged two channels at a time");
+};
+
+struct DcEpi {
+    // EPI == 1 only: 1x1 out conv (architectures.py:57) and wavefield update (hybridnet.py:570)
+    const float* ow;  // [8][2]
+    const float* ob;  // [2]
+    float* d_out;     // [B,2,H,W] or nullptr
+    float* wf;        // [B,2,H,W] updated in place, or nullptr
+};
+
+// 3x3 taps of one input channel for a 1x4 strip: acc[p][m] += w[dy][dx][m] * row[dy][p + dx]
+template <int CMID, int PITCH>
+__device__ __forceinline__ void conv3x3_channel(const float* __restrict__ t, const float* __restrict__ w,
+                                                float (&acc)[4][CMID]) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const float4 lo = *reinterpret_cast<const float4*>(t + dy * PITCH);
+        const float2 hi = *reinterpret_cast<const float2*>(t + dy * PITCH + 4);
+        const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+#pragma unroll
+                for (int m = 0; m < CMID; ++m) acc[p][m] = fmaf(w[(dy * 3 + dx) * CMID + m], v[p + dx], acc[p][m]);
+    }
+}
+
+template <int CA, int CB, int CC, int CM, int CO, int TW, int EPI>
+__global__ __launch_bounds__((DcCfg<CA, CB, CC, CM, CO, TW>::NT)) void k_double_conv(
+    Src sa, Src sb, Src sc, Dst out, DcW w, DcEpi epi, int H, int W) {
+    using C = DcCfg<CA, CB, CC, CM, CO, TW>;
+    // +8: the last (partly unused) strip of a row reads up to 2 floats past the staged tile
+    __shared__ __attribute__((aligned(16))) float s_in[4 * C::PLANE + 8];
+    __shared__ __attribute__((aligned(16))) float s_mid[CM * C::MR * C::PM + 8];
+
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * C::TH;
+
+    // --- per-thread staging positions (identical for every channel pair) ---
+    int goff[C::NL];  // y*W + x, or -1 outside the image / the tile
+    int loff[C::NL];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * C::NT;
+        const int ir = e / C::PI, ic = e - ir * C::PI;
+        const int y = y0 - 2 + ir, x = x0 - 2 + ic;
+        const bool ok = (e < C::PLANE) && y >= 0 && y < H && x >= 0 && x < W;
+        goff[i] = ok ? y * W + x : -1;
+        loff[i] = (e < C::PLANE) ? e : -1;
+    }
+    auto chunk_src = [&](int g, const float*& p0, long& cs, float& scale) {
+        // channel pair g of the implicit concatenation [A, B, C]
+        int c = 2 * g;
+        if (c < CA) { p0 = sa.p + (long)b * sa.sb + (long)c * sa.sc; cs = sa.sc; scale = sa.scale; return; }
+        c -= CA;
+        if (CB > 0 && c < CB) { p0 = sb.p + (long)b * sb.sb + (long)c * sb.sc; cs = sb.sc; scale = sb.scale; return; }
+        c -= CB;
+        p0 = sc.p + (long)b * sc.sb + (long)c * sc.sc; cs = sc.sc; scale = sc.scale;
+    };
+    float stage[C::NL][2];
+    auto fetch = [&](int g) {
+        const float* p0; long cs; float scale;
+        chunk_src(g, p0, cs, scale);
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            const bool ok = goff[i] >= 0;
+            stage[i][0] = ok ? p0[goff[i]] * scale : 0.f;
+            stage[i][1] = ok ? p0[cs + goff[i]] * scale : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i)
+            if (loff[i] >= 0) {
+                s_in[buf * 2 * C::PLANE + loff[i]] = stage[i][0];
+                s_in[buf * 2 * C::PLANE + C::PLANE + loff[i]] = stage[i][1];
+            }
+    };
+
+    // --- conv1 over the (TH+2) x (TW+2) mid region ---
+    const int mr = tid / C::S1, s1 = tid - mr * C::S1;
+    const bool act1 = mr < C::MR;
+    float acc1[4][CM];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int m = 0; m < CM; ++m) acc1[p][m] = 0.f;
+
+    constexpr int NG = C::CIN / 2;
+    fetch(0);
+#pragma unroll 1
+    for (int g = 0; g < NG; ++g) {
+        const int buf = g & 1;
+        commit(buf);
+        __syncthreads();
+        if (g + 1 < NG) fetch(g + 1);
+        if (act1) {
+            const float* t = &s_in[buf * 2 * C::PLANE + mr * C::PI + 4 * s1];
+            const float* wg = w.w1 + (long)g * 2 * 9 * CM;
+            conv3x3_channel<CM, C::PI>(t, wg, acc1);
+            conv3x3_channel<CM, C::PI>(t + C::PLANE, wg + 9 * CM, acc1);
+        }
+    }
+    if (act1) {
+        const float slope = w.slope[0];
+        const int y = y0 - 1 + mr;
+        const bool yin = y >= 0 && y < H;
+#pragma unroll
+        for (int m = 0; m < CM; ++m) {
+            const float bias = w.b1[m];
+            float4 o;
+            float* op = reinterpret_cast<float*>(&o);
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int x = x0 - 1 + 4 * s1 + p;
+                float v = acc1[p][m] + bias;
+                v = v > 0.f ? v : slope * v;  // PReLU, one scalar slope (architectures.py:32-33)
+                // conv2 zero-pads the MID tensor: positions outside the image are zero, not conv1 values
+                op[p] = (yin && x >= 0 && x < W) ? v : 0.f;
+            }
+            *reinterpret_cast<float4*>(&s_mid[(m * C::MR + mr) * C::PM + 4 * s1]) = o;
+        }
+    }
+    __syncthreads();
+
+    // --- conv2 over the TH x TW output tile ---
+    const int oy = tid / C::S2, s2 = tid - oy * C::S2;
+    if (oy >= C::TH) return;
+    float acc2[4][CO];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int m = 0; m < CO; ++m) acc2[p][m] = 0.f;
+#pragma unroll 2
+    for (int cm = 0; cm < CM; ++cm)
+        conv3x3_channel<CO, C::PM>(&s_mid[(cm * C::MR + oy) * C::PM + 4 * s2], w.w2 + cm * 9 * CO, acc2);
+
+    const int y = y0 + oy, x = x0 + 4 * s2;
+    if (y >= H || x >= W) return;
+    const bool vec = ((W & 3) == 0);
+    if (EPI == 0) {
+#pragma unroll
+        for (int m = 0; m < CO; ++m) {
+            const float bias = w.b2[m];
+            float* po = out.p + (long)b * out.sb + (long)m * out.sc + (long)y * W + x;
+            if (vec) {
+                *reinterpret_cast<float4*>(po) =
+                    make_float4(acc2[0][m] + bias, acc2[1][m] + bias, acc2[2][m] + bias, acc2[3][m] + bias);
+            } else {
+#pragma unroll
+                for (int p = 0; p < 4; ++p)
+                    if (x + p < W) po[p] = acc2[p][m] + bias;
+            }
+        }
+    } else {
+        // 1x1 out conv 8 -> 2, then wf <- d / 1e3 + wf
+        const long plane = (long)H * W;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            float d[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                float s = epi.ob[c2];
+#pragma unroll
+                for (int m = 0; m < CO; ++m) s = fmaf(epi.ow[m * 2 + c2], acc2[p][m] + w.b2[m], s);
+                d[p] = s;
+            }
+            const long o = ((long)b * 2 + c2) * plane + (long)y * W + x;
+#pragma unroll
+            for (int p = 0; p < 4; ++p)
+                if (x + p < W) {
+                    if (epi.d_out) epi.d_out[o + p] = d[p];
+                    if (epi.wf) epi.wf[o + p] = d[p] / 1e3f + epi.wf[o + p];
+                }
+        }
+    }
+}
+
+template <int CA, int CB, int CC, int CM, int CO, int TW, int EPI>
+void launch_dc_tw(Src a, Src b, Src c, Dst out, const DcW& w, const DcEpi& e, int H, int W, int batch, hipStream_t s) {
+    using C = DcCfg<CA, CB, CC, CM, CO, TW>;
+    dim3 grid(cdiv(W, TW), cdiv(H, C::TH), batch);
+    hipLaunchKernelGGL((k_double_conv<CA, CB, CC, CM, CO, TW, EPI>), grid, dim3(C::NT), 0, s, a, b, c, out, w, e, H, W);
+}
+template <int CA, int CB, int CC, int CM, int CO, int EPI>
+void launch_dc(Src a, Src b, Src c, Dst out, const DcW& w, const DcEpi& e, int H, int W, int batch, hipStream_t s) {
+    if (W > 32) launch_dc_tw<CA, CB, CC, CM, CO, 64, EPI>(a, b, c, out, w, e, H, W, batch, s);
+    else if (W > 16) launch_dc_tw<CA, CB, CC, CM, CO, 32, EPI>(a, b, c, out, w, e, H, W, batch, s);
+    else launch_dc_tw<CA, CB, CC, CM, CO, 16, EPI>(a, b, c, out, w, e, H, W, batch, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// 8x8 stride-2 convolution, pad 3 (EncoderBlock.down, architectures.py:209-211)
+//   out[co][Y][X] = b[co] + sum_ci sum_ky sum_kx w[co][ci][ky][kx] * in[ci][2Y + ky - 3][2X + kx - 3]
+// Tile: 16 x 32 outputs; thread = 2 adjacent outputs x 8 channels; input staged 2 channels at a time.
+// ------------------------------------------------------------------------------------------
+struct DownCfg {
+    static constexpr int TH = 16, TW = 32;
+    static constexpr int IR = 2 * TH + 6;  // 38
+    static constexpr int PI = 2 * TW + 8;  // 72 (70 used)
+    static constexpr int PLANE = IR * PI;
+    static constexpr int NT = 256;
+    static constexpr int NL = cdiv(PLANE, NT);
+};
+
+__global__ __launch_bounds__(DownCfg::NT) void k_down8x8(Src in, Dst out, K8W w, int Hin, int Win) {
+    using C = DownCfg;
+    __shared__ __attribute__((aligned(16))) float s_in[2][2 * C::PLANE];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const int Hout = Hin / 2, Wout = Win / 2;
+    int goff[C::NL], loff[C::NL];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * C::NT;
+        const int ir = e / C::PI, ic = e - ir * C::PI;
+        const int y = 2 * Y0 - 3 + ir, x = 2 * X0 - 3 + ic;
+        const bool ok = (e < C::PLANE) && y >= 0 && y < Hin && x >= 0 && x < Win;
+        goff[i] = ok ? y * Win + x : -1;
+        loff[i] = (e < C::PLANE) ? e : -1;
+    }
+    float stage[C::NL][2];
+    auto fetch = [&](int g) {
+        const float* p0 = in.p + (long)b * in.sb + (long)(2 * g) * in.sc;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            const bool ok = goff[i] >= 0;
+            stage[i][0] = ok ? p0[goff[i]] : 0.f;
+            stage[i][1] = ok ? p0[in.sc + goff[i]] : 0.f;
+        }
+    };
+    const int oy = tid >> 4, sx = tid & 15;  // outputs (Y0+oy, X0 + 2*sx + {0,1})
+    float acc[2][kFeat];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int m = 0; m < kFeat; ++m) acc[p][m] = 0.f;
+    fetch(0);
+#pragma unroll 1
+    for (int g = 0; g < kFeat / 2; ++g) {
+        const int buf = g & 1;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i)
+            if (loff[i] >= 0) {
+                s_in[buf][loff[i]] = stage[i][0];
+                s_in[buf][C::PLANE + loff[i]] = stage[i][1];
+            }
+        __syncthreads();
+        if (g + 1 < kFeat / 2) fetch(g + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float* wc = w.w + (long)(2 * g + c) * 64 * kFeat;
+#pragma unroll 2
+            for (int ky = 0; ky < 8; ++ky) {
+                const float* t = &s_in[buf][c * C::PLANE + (2 * oy + ky) * C::PI + 4 * sx];
+                const float4 q0 = *reinterpret_cast<const float4*>(t);
+                const float4 q1 = *reinterpret_cast<const float4*>(t + 4);
+                const float2 q2 = *reinterpret_cast<const float2*>(t + 8);
+                const float v[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+#pragma unroll
+                for (int kx = 0; kx < 8; ++kx)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int m = 0; m < kFeat; ++m)
+                            acc[p][m] = fmaf(wc[(ky * 8 + kx) * kFeat + m], v[2 * p + kx], acc[p][m]);
+            }
+        }
+    }
+    const int Y = Y0 + oy, X = X0 + 2 * sx;
+    if (Y >= Hout || X >= Wout) return;
+#pragma unroll
+    for (int m = 0; m < kFeat; ++m) {
+        float* po = out.p + (long)b * out.sb + (long)m * out.sc + (long)Y * Wout + X;
+        const float bias = w.b[m];
+        po[0] = acc[0][m] + bias;
+        if (X + 1 < Wout) po[1] = acc[1][m] + bias;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 8x8 stride-2 transposed convolution, pad 3 (HybridNet.up, architectures.py:375-382)
+//   out[co][y][x] = b[co] + sum_ci sum_{iy,ky: y = 2 iy - 3 + ky} sum_{ix,kx} w[ci][co][ky][kx] * in[ci][iy][ix]
+// For y = 2Y + py the four contributing input rows are iy = Y - 2 + py + a (a = 0..3) with
+// ky = 7 - py - 2a; the same along x.  Thread = output patch rows {2Y, 2Y+1} x cols 4s..4s+3.
+// Tile: 16 x 32 input positions -> 32 x 64 outputs; all 8 input channels staged at once.
+// ------------------------------------------------------------------------------------------
+struct UpCfg {
+    static constexpr int TH = 16, TW = 32;  // in input coordinates
+    static constexpr int IR = TH + 4;       // rows Y0-2 .. Y0+TH+1
+    static constexpr int PI = TW + 4;       // cols X0-2 .. X0+TW+1
+    static constexpr int PLANE = IR * PI;
+    static constexpr int NT = 256;
+};
+
+__global__ __launch_bounds__(UpCfg::NT) void k_up8x8(Src in, Dst out, K8W w, int Hin, int Win) {
+    using C = UpCfg;
+    __shared__ __attribute__((aligned(16))) float s_in[kFeat * C::PLANE];
+    const int tid = threadIdx.x, b = blockIdx.z;
+    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const int Hout = 2 * Hin, Wout = 2 * Win;
+    for (int e = tid; e < C::PLANE; e += C::NT) {
+        const int ir = e / C::PI, ic = e - ir * C::PI;
+        const int y = Y0 - 2 + ir, x = X0 - 2 + ic;
+        const bool ok = y >= 0 && y < Hin && x >= 0 && x < Win;
+        const float* p0 = in.p + (long)b * in.sb + (long)y * Win + x;
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c) s_in[c * C::PLANE + e] = ok ? p0[(long)c * in.sc] : 0.f;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, sx = tid & 15;  // input row Y0+ty, input cols X0 + 2*sx + {0,1}
+    float acc[2][4][kFeat];                  // [py][output col 4*sx + q][co]
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < kFeat; ++m) acc[py][q][m] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < kFeat; ++c) {
+        const float* wc = w.w + (long)c * 64 * kFeat;
+        // staged rows ty .. ty+4 (input rows Y-2 .. Y+2), cols 2*sx .. 2*sx+5 (input cols X-2 .. X+3)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const float* t = &s_in[c * C::PLANE + (ty + r) * C::PI + 2 * sx];
+            const float2 q0 = *reinterpret_cast<const float2*>(t);
+            const float2 q1 = *reinterpret_cast<const float2*>(t + 2);
+            const float2 q2 = *reinterpret_cast<const float2*>(t + 4);
+            const float v[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int a = r - py;  // input row Y - 2 + py + a
+                if (a < 0 || a > 3) continue;
+                const int ky = 7 - py - 2 * a;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    // output col x = 2*(2*sx) + q = 2*Xq + px with Xq = 2*sx + (q >> 1), px = q & 1
+                    const int px = q & 1, xo = q >> 1;
+#pragma unroll
+                    for (int bb = 0; bb < 4; ++bb) {
+                        const int kx = 7 - px - 2 * bb;  // input col Xq - 2 + px + bb -> staged col xo + px + bb
+#pragma unroll
+                        for (int m = 0; m < kFeat; ++m)
+                            acc[py][q][m] = fmaf(wc[(ky * 8 + kx) * kFeat + m], v[xo + px + bb], acc[py][q][m]);
+                    }
+                }
+            }
+        }
+    }
+    const int Y = Y0 + ty, X = X0 + 2 * sx;
+    if (Y >= Hin || X >= Win) return;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int m = 0; m < kFeat; ++m) {
+            const float bias = w.b[m];
+            float* po = out.p + (long)b * out.sb + (long)m * out.sc + (long)(2 * Y + py) * Wout + 2 * X;
+            if (2 * X + 3 < Wout && (Wout & 3) == 0) {
+                *reinterpret_cast<float4*>(po) = make_float4(acc[py][0][m] + bias, acc[py][1][m] + bias,
+                                                             acc[py][2][m] + bias, acc[py][3][m] + bias);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (2 * X + q < Wout) po[q] = acc[py][q][m] + bias;
+            }
+        }
+}
+
+}  // namespace
+
+int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
+                 float* d_out, float* wf_update, int batch, hipStream_t s) {
+    const int n = ctx->tab.n, depth = ctx->depth;
+    const long L = ctx->state_len;
+    const Src none{nullptr, 0, 0, 1.f};
+    const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
+    auto plane = [&](int d) { const long m = n >> d; return m * m; };
+    auto feat = [&](float* p, int d) { return Dst{p, kFeat * plane(d), plane(d)}; };
+    auto featsrc = [&](const float* p, int d) { return Src{p, kFeat * plane(d), plane(d), 1.f}; };
+
+    // inc: DoubleConv(6 -> 8 -> 8) on [wf, 1e3*res, sigmas]  (architectures.py:442, hybridnet.py:566)
+    launch_dc<2, 2, 2, kFeat, kFeat, 0>(in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, noepi, n, n, batch, s);
+    for (int d = 0; d < depth; ++d) {
+        const int m = n >> d;
+        const Src st_old{states_in + ctx->state_off[d], 2 * L, L, 1.f};
+        const Dst st_new{states_out + ctx->state_off[d], 2 * L, L};
+        // out = conv_signal(cat[x, state])                               (architectures.py:246-247)
+        launch_dc<kFeat, kState, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d),
+                                                      ctx->sig[d], noepi, m, m, batch, s);
+        // state = conv_state(cat[out, state_old])                        (architectures.py:248)
+        launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
+                                                        noepi, m, m, batch, s);
+        // x = down(out)                                                  (architectures.py:252)
+        hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
+                           dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
+                           ctx->down[d], m, m);
+    }
+    // bottleneck: decode[depth]                                          (architectures.py:453)
+    launch_dc<kFeat, 0, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth),
+                                            ctx->dec[depth], noepi, n >> depth, n >> depth, batch, s);
+    for (int d = depth - 1; d >= 0; --d) {
+        const int m = n >> d;
+        // x = up[d](x)                                                   (architectures.py:456)
+        hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
+                           featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
+        // x = decode[d](cat[x, skip_d])                                  (architectures.py:458-460)
+        if (d > 0) {
+            launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none,
+                                                        feat(ctx->buf_y[d], d), ctx->dec[d], noepi, m, m, batch, s);
+        } else {
+            // + outc 1x1 (architectures.py:463) and wf <- d/1e3 + wf (hybridnet.py:570)
+            const DcEpi e{ctx->outc_w, ctx->outc_b, d_out, wf_update};
+            launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 1>(featsrc(ctx->buf_a[0], 0), featsrc(ctx->buf_o[0], 0), none,
+                                                        Dst{nullptr, 0, 0}, ctx->dec[0], e, m, m, batch, s);
+        }
+    }
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+}  // namespace hn

@@ -1,0 +1,190 @@
+"""Thin tensor-level wrapper over one ``hn_ctx`` of libhelmnet_hip.so.
+
+PyTorch is used for device memory and streams only: every method checks its tensors
+(device, dtype, contiguity, shape), passes raw device pointers plus the current HIP stream
+across the C ABI, and returns.  No arithmetic happens here.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+
+# state_dict order of the `f.*` tensors = order of the blob hn_load_weights expects
+# (reference helmnet/architectures.py:317-388)
+
+
+def weight_names(depth: int = 4) -> list:
+    def dc(prefix):
+        p = prefix + ".double_conv."
+        return [p + "0.weight", p + "0.bias", p + "1.weight", p + "2.weight", p + "2.bias"]
+
+    names = dc("inc")
+    for d in range(depth):
+        names += dc(f"enc.{d}.conv_signal") + [f"enc.{d}.down.weight", f"enc.{d}.down.bias"] + dc(f"enc.{d}.conv_state")
+    for d in range(depth + 1):
+        names += dc(f"decode.{d}")
+    for d in range(depth):
+        names += [f"up.{d}.weight", f"up.{d}.bias"]
+    return names + ["outc.conv.weight", "outc.conv.bias"]
+
+
+def pack_weights(state: dict, depth: int = 4, activation: str = "prelu") -> np.ndarray:
+    """Flatten a HybridNet state_dict (tensors or arrays) into the fp32 blob of hn_load_weights.
+    Parameter-free activations (relu / leakyrelu) get their constant slope written where the
+    PReLU weight would be, so the blob layout never changes."""
+    const_slope = {"relu": 0.0, "leakyrelu": 0.01}
+    parts = []
+    for name in weight_names(depth):
+        if name.endswith(".double_conv.1.weight") and name not in state:
+            if activation.lower() not in const_slope:
+                raise KeyError(f"missing {name} for activation {activation!r}")
+            parts.append(np.array([const_slope[activation.lower()]], np.float32))
+            continue
+        v = state[name]
+        if isinstance(v, torch.Tensor):
+            v = v.detach().to("cpu", torch.float32).numpy()
+        parts.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
+    return np.concatenate(parts)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class Engine:
+    """One library context bound to one HIP device."""
+
+    def __init__(self, device: torch.device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise _lib.HelmnetHipError(
+                f"helmnet_amd computes on MI355X (device type 'cuda' under ROCm) only, got {device}; "
+                "there is no CPU path in the product (the CPU oracle lives in oracle/ for tests)."
+            )
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        ctx = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.current_stream()  # make sure torch initialised HIP on this device first
+            _lib.check(self.lib.hn_create(ctypes.byref(ctx), self.device.index), None, "hn_create")
+        self.ctx = ctx
+        self.n = 0
+        self.depth = 0
+        self.weights_key = None
+        self.domain_key = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.hn_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup -------------------------------------------------------------------------
+    def load_weights(self, blob: np.ndarray, features: int, depth: int, state_channels: int, activation: str):
+        act = _lib.HN_ACT.get(activation.lower())
+        if act is None:
+            raise NotImplementedError(f"Unknown activation function {activation} (HIP kernels: prelu, relu, leakyrelu)")
+        blob = np.ascontiguousarray(blob, dtype=np.float32)
+        rc = self.lib.hn_load_weights(self.ctx, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), blob.size,
+                                      features, depth, state_channels, act)
+        _lib.check(rc, self.ctx, "hn_load_weights")
+        self.depth = depth
+
+    def set_domain(self, n: int, pml: int, sigma_max: float, k: float):
+        _lib.check(self.lib.hn_set_domain(self.ctx, int(n), int(pml), float(sigma_max), float(k)), self.ctx, "hn_set_domain")
+        self.n = int(n)
+        self.domain_key = (int(n), int(pml), float(sigma_max), float(k))
+
+    @property
+    def state_len(self) -> int:
+        return int(self.lib.hn_state_len(self.ctx))
+
+    def reserve(self, batch: int):
+        _lib.check(self.lib.hn_reserve(self.ctx, int(batch)), self.ctx, "hn_reserve")
+
+    # ---- helpers -----------------------------------------------------------------------
+    def _chk(self, t: torch.Tensor, shape: Sequence[int], name: str) -> torch.Tensor:
+        if not isinstance(t, torch.Tensor):
+            raise TypeError(f"{name} must be a tensor")
+        if t.device != self.device:
+            raise ValueError(f"{name} is on {t.device}, engine is on {self.device}")
+        if t.dtype != torch.float32:
+            raise TypeError(f"{name} must be float32, got {t.dtype}")
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+        if not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous")
+        return t
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- operators ---------------------------------------------------------------------
+    def sigmas(self) -> torch.Tensor:
+        out = torch.empty(2, self.n, self.n, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.hn_get_sigmas(self.ctx, _ptr(out), self._stream()), self.ctx, "hn_get_sigmas")
+        return out
+
+    def laplacian(self, wf: torch.Tensor) -> torch.Tensor:
+        b = wf.shape[0]
+        self._chk(wf, (b, 2, self.n, self.n), "wavefield")
+        out = torch.empty_like(wf)
+        _lib.check(self.lib.hn_laplacian(self.ctx, _ptr(wf), _ptr(out), b, self._stream()), self.ctx, "hn_laplacian")
+        return out
+
+    def residual(self, wf: torch.Tensor, k_sq: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+        b = wf.shape[0]
+        self._chk(wf, (b, 2, self.n, self.n), "wavefield")
+        self._chk(k_sq, (b, 1, self.n, self.n), "k_sq")
+        self._chk(src, (src.shape[0], 2, self.n, self.n), "source")
+        out = torch.empty_like(wf)
+        rc = self.lib.hn_residual(self.ctx, _ptr(wf), _ptr(k_sq), _ptr(src), src.shape[0], _ptr(out), b, self._stream())
+        _lib.check(rc, self.ctx, "hn_residual")
+        return out
+
+    def rmse(self, res: torch.Tensor) -> torch.Tensor:
+        b = res.shape[0]
+        self._chk(res, (b, 2, self.n, self.n), "residual")
+        out = torch.empty(b, device=self.device, dtype=torch.float32)
+        _lib.check(self.lib.hn_rmse(self.ctx, _ptr(res), _ptr(out), b, self._stream()), self.ctx, "hn_rmse")
+        return out
+
+    def unet(self, in6: torch.Tensor, states_in: torch.Tensor):
+        b = in6.shape[0]
+        self._chk(in6, (b, 6, self.n, self.n), "network input")
+        self._chk(states_in, (b, 2, self.state_len), "hidden state")
+        d = torch.empty(b, 2, self.n, self.n, device=self.device, dtype=torch.float32)
+        states_out = torch.empty_like(states_in)
+        rc = self.lib.hn_unet(self.ctx, _ptr(in6), _ptr(states_in), _ptr(states_out), _ptr(d), b, self._stream())
+        _lib.check(rc, self.ctx, "hn_unet")
+        return d, states_out
+
+    def step(self, wf, res, states, k_sq, src, n_iter: int, res_hist=None, wf_hist=None, st_hist=None, rmse_hist=None):
+        """n_iter solver iterations; wf, res, states updated in place."""
+        b = wf.shape[0]
+        self._chk(wf, (b, 2, self.n, self.n), "wavefield")
+        self._chk(res, (b, 2, self.n, self.n), "residual")
+        self._chk(states, (b, 2, self.state_len), "hidden state")
+        self._chk(k_sq, (b, 1, self.n, self.n), "k_sq")
+        self._chk(src, (src.shape[0], 2, self.n, self.n), "source")
+        if res_hist is not None:
+            self._chk(res_hist, (n_iter, b, 2, self.n, self.n), "res_hist")
+        if wf_hist is not None:
+            self._chk(wf_hist, (n_iter, b, 2, self.n, self.n), "wf_hist")
+        if st_hist is not None:
+            self._chk(st_hist, (n_iter, b, 2, self.state_len), "st_hist")
+        if rmse_hist is not None:
+            self._chk(rmse_hist, (n_iter, b), "rmse_hist")
+        rc = self.lib.hn_step(self.ctx, _ptr(wf), _ptr(res), _ptr(states), _ptr(k_sq), _ptr(src), src.shape[0], b,
+                              int(n_iter), _ptr(res_hist), _ptr(wf_hist), _ptr(st_hist), _ptr(rmse_hist), self._stream())
+        _lib.check(rc, self.ctx, "hn_step")

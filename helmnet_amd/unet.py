@@ -1,0 +1,178 @@
+"""Host-side mirror of the reference's stateful UNet (``HybridNet``).
+
+Mirrors reference helmnet/architectures.py: ``OutConv`` (:47-60), ``DoubleConv`` (:63-84),
+``EncoderBlock`` (:186-252) and ``HybridNet`` (:317-465) -- same constructor arguments, same
+sub-module / parameter names (so the shipped checkpoint's ``f.*`` state_dict loads unchanged),
+same state bookkeeping API (``clear_states / get_states / set_states / flatten_state /
+unflatten_state / init_by_size``, ``enc[d].state``, ``enc[d].domain_size``).
+
+The torch ``nn.Conv2d`` / ``nn.PReLU`` / ``nn.ConvTranspose2d`` objects below are PARAMETER
+CONTAINERS ONLY: they are never called.  ``HybridNet.forward`` hands the packed weights and the
+flat hidden state to libhelmnet_hip.so (``hn_unet``), which runs the whole network as fused
+HIP kernels; the per-iteration solver loop bypasses even that and uses ``hn_step``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine, pack_weights
+
+_PIECEWISE_LINEAR = ("prelu", "relu", "leakyrelu")
+
+
+def getActivationFunction(act_function_name: str, features=None, end=False) -> nn.Module:
+    """architectures.py:5-44.  The HIP kernels implement the piecewise-linear activations
+    (the shipped checkpoint uses 'prelu'); anything else raises NotImplementedError, as the
+    reference does for unknown names."""
+    name = act_function_name.lower()
+    if name == "prelu":
+        return nn.PReLU()
+    if name == "relu":
+        return nn.ReLU(inplace=True)
+    if name == "leakyrelu":
+        return nn.LeakyReLU(inplace=True)
+    raise NotImplementedError("Unknown activation function {} (implemented: {})".format(act_function_name, _PIECEWISE_LINEAR))
+
+
+class _ContainerOnly(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError(
+            f"{type(self).__name__} only holds parameters; run the network through HybridNet.forward "
+            "(libhelmnet_hip.so) -- there is no PyTorch compute path in helmnet_amd"
+        )
+
+
+class OutConv(_ContainerOnly):
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
+
+
+class DoubleConv(_ContainerOnly):
+    def __init__(self, in_channels: int, out_channels: int, mid_channels=None, activation_fun="relu"):
+        super().__init__()
+        mid_channels = out_channels if mid_channels is None else mid_channels
+        self.double_conv = nn.Sequential(
+            nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1),
+            getActivationFunction(activation_fun, mid_channels),
+            nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1),
+        )
+
+
+class EncoderBlock(_ContainerOnly):
+    def __init__(self, num_features: int, state_size=2, activation_function="prelu", use_state=True, domain_size=0):
+        super().__init__()
+        if not use_state:
+            raise NotImplementedError("state_depth < depth is not implemented by the HIP kernels")
+        self.state_size, self.use_state, self.domain_size, self.num_features = state_size, use_state, domain_size, num_features
+        self.conv_signal = DoubleConv(num_features + state_size, num_features, activation_fun=activation_function)
+        self.down = nn.Conv2d(num_features, num_features, kernel_size=8, padding=3, stride=2)
+        self.conv_state = DoubleConv(num_features + state_size, state_size, activation_fun=activation_function)
+        self.state: Optional[torch.Tensor] = None
+
+    def set_state(self, state):
+        self.state = state
+
+    def get_state(self):
+        return self.state
+
+    def clear_state(self, x):
+        self.state = torch.zeros([x.shape[0], 2, self.domain_size, self.domain_size], device=x.device)
+
+
+class HybridNet(nn.Module):
+    def __init__(self, activation_function: str, depth: int, domain_size: int, features: int, inchannels: int,
+                 state_channels: int, state_depth: int):
+        super().__init__()
+        if features != 8 or state_channels != 2 or inchannels != 6:
+            raise NotImplementedError("HIP kernels are built for features=8, state_channels=2, inchannels=6")
+        if state_depth != depth:
+            raise NotImplementedError("HIP kernels require state_depth == depth")
+        self.activation_function, self.depth, self.domain_size = activation_function, depth, domain_size
+        self.features, self.inchannels = features, inchannels
+        self.state_channels, self.state_depth = state_channels, state_depth
+        self.init_by_size()
+        self.inc = DoubleConv(inchannels, features, activation_fun=activation_function)
+        self.enc = nn.ModuleList([
+            EncoderBlock(features, state_size=state_channels, activation_function=activation_function,
+                         use_state=d < state_depth, domain_size=self.states_dimension[d]) for d in range(depth)])
+        self.decode = nn.ModuleList([
+            DoubleConv(features + features * (i < depth), features, activation_fun=activation_function)
+            for i in range(depth + 1)])
+        self.up = nn.ModuleList([
+            nn.ConvTranspose2d(features, features, kernel_size=8, padding=3, output_padding=0, stride=2)
+            for _ in range(depth)])
+        self.outc = OutConv(features, 2)
+        self._engine: Optional[Engine] = None
+        self._owns_engine = True
+
+    # ---- state bookkeeping (architectures.py:390-437) -----------------------------------
+    def init_by_size(self):
+        self.states_dimension = [self.domain_size // 2 ** x for x in range(self.depth)]
+        self.total_state_length = sum(x ** 2 for x in self.states_dimension)
+        self.state_boundaries, o = [], 0
+        for s in self.states_dimension:
+            self.state_boundaries.append([o, o + s * s])
+            o += s * s
+
+    def get_states(self, flatten=False):
+        h = [enc.get_state() for enc in self.enc]
+        return self.flatten_state(h) if flatten else h
+
+    def clear_states(self, x):
+        for enc in self.enc:
+            enc.clear_state(x)
+
+    def set_states(self, states, flatten=False):
+        h = self.unflatten_state(states) if flatten else states
+        for enc, state in zip(self.enc[: len(h)], h):
+            enc.set_state(state)
+
+    def flatten_state(self, h_list):
+        return torch.cat([x.reshape(x.shape[0], x.shape[1], -1) for x in h_list], 2)
+
+    def unflatten_state(self, h_flatten):
+        h, shp = [], h_flatten.shape
+        for (a, b), size in zip(self.state_boundaries, self.states_dimension):
+            h.append(h_flatten[:, :, a:b].reshape(shp[0], shp[1], size, size))
+        return h
+
+    # ---- engine plumbing -----------------------------------------------------------------
+    def bind(self, engine: Engine):
+        self._engine, self._owns_engine = engine, False
+
+    def weights_key(self):
+        return tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def sync_weights(self, engine: Engine):
+        """(Re-)upload the parameters if they changed since the last upload."""
+        key = self.weights_key()
+        if engine.weights_key != key:
+            sd = {k: v for k, v in self.state_dict().items()}
+            engine.load_weights(pack_weights(sd, self.depth, self.activation_function), self.features, self.depth,
+                                self.state_channels, self.activation_function)
+            engine.weights_key = key
+
+    def _get_engine(self, device) -> Engine:
+        if self._engine is None or self._engine.device != torch.device(device):
+            if not self._owns_engine and self._engine is not None:
+                raise RuntimeError(f"input on {device} but the solver's engine lives on {self._engine.device}")
+            self._engine = Engine(device)
+        if self._owns_engine and self._engine.n != self.domain_size:
+            # standalone use: the spectral tables are not needed, but the library wants a domain
+            self._engine.set_domain(self.domain_size, 1, 0.0, 1.0)
+        self.sync_weights(self._engine)
+        return self._engine
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [B, 6, N, N] -> d [B, 2, N, N]; updates every enc[d].state (architectures.py:439-465)."""
+        if any(enc.state is None for enc in self.enc):
+            raise ValueError("You must set or clear the state before using this module")
+        eng = self._get_engine(x.device)
+        flat = self.get_states(flatten=True).contiguous()
+        d, new_flat = eng.unet(x.contiguous(), flat)
+        self.set_states(new_flat, flatten=True)
+        return d

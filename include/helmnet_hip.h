@@ -1,0 +1,124 @@
+/*
+ * helmnet_hip.h -- C ABI of libhelmnet_hip.so, the MI355X (gfx950) implementation of the
+ * helmnet IterativeSolver inference hot path.
+ *
+ * The reference (ucl-bug/helmnet) is pure Python/PyTorch and defines NO plugin / operator /
+ * FFI interface: its boundary is the Python surface of
+ * `IterativeSolver`.  This header is the C boundary introduced underneath that surface; each
+ * entry point names the reference code it replaces (paths relative to the reference root).
+ * The Python class `helmnet_amd.IterativeSolver` binds these symbols with ctypes
+ * (INTEGRATION.md shows the stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns 0 on success and a negative hn_status on failure; the message
+ *     is available from hn_last_error(ctx) (or hn_last_error(NULL) for hn_create failures).
+ *     No exception crosses the ABI, no global mutable state except that last-error string.
+ *   - all tensor arguments are DEVICE pointers to contiguous fp32, NCHW, owned by the caller,
+ *     who guarantees their lifetime until `stream` has been synchronised.
+ *   - all work is enqueued asynchronously on the caller's `stream` (a hipStream_t passed as
+ *     void*; NULL = the default stream).  A ctx is bound to one device and is NOT thread-safe.
+ *   - the library owns only its ctx: a re-packed copy of the weights, the spectral tables
+ *     and the activation workspace (grown on demand by hn_reserve / the first call).
+ */
+#ifndef HELMNET_HIP_H
+#define HELMNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hn_ctx hn_ctx;
+
+enum hn_status {
+    HN_OK = 0,
+    HN_ERR_ARG = -1,      /* bad argument (shape, NULL pointer, unsupported size)            */
+    HN_ERR_STATE = -2,    /* call order: weights / domain not set yet                        */
+    HN_ERR_UNSUPPORTED = -3, /* architecture / activation the kernels do not implement       */
+    HN_ERR_HIP = -4,      /* a HIP runtime call failed                                       */
+    HN_ERR_NOMEM = -5
+};
+
+/* activation kinds accepted by hn_load_weights (architectures.py:5-44 getActivationFunction).
+ * Only piecewise-linear ones are implemented; everything else returns HN_ERR_UNSUPPORTED,
+ * mirroring the reference's NotImplementedError for unknown names. */
+enum hn_act { HN_ACT_PRELU = 0, HN_ACT_RELU = 1, HN_ACT_LEAKYRELU = 2 };
+
+#define HN_ABI_VERSION 1
+int hn_abi_version(void);
+
+/* Create / destroy a context on HIP device `device_id`. */
+int hn_create(hn_ctx** out, int device_id);
+void hn_destroy(hn_ctx* ctx);
+const char* hn_last_error(const hn_ctx* ctx);
+
+/* Number of fp32 values hn_load_weights expects for (features, depth, state_ch): the `f.*`
+ * tensors of the checkpoint in state_dict order (architectures.py:317-388). */
+size_t hn_weight_count(int features, int depth, int state_ch);
+
+/* Upload the HybridNet parameters (HOST pointer; copied and re-packed, caller keeps `blob`).
+ * Replaces: HybridNet.__init__ + load_state_dict (architectures.py:317-388).
+ * Order of `blob`: inc.double_conv.{0.weight,0.bias,1.weight,2.weight,2.bias};
+ *   for d in 0..depth-1: enc.d.conv_signal (5 tensors), enc.d.down.{weight,bias},
+ *                        enc.d.conv_state (5 tensors);
+ *   decode.0..depth (5 tensors each); up.0..depth-1 {weight,bias}; outc.conv.{weight,bias}.
+ * Supported: features == 8, state_ch == 2, 1 <= depth <= 6, state_depth == depth. */
+int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int features, int depth,
+                    int state_ch, int act_kind);
+
+/* Build the spectral-operator constants for an n x n domain (float64 on the host, fp32 on the
+ * device): k grids, PML coefficients ax/bx/ay/by, sigma maps, FFT twiddles.
+ * Replaces: FastLaplacianWithPML.init_variables / get_gamma_functions (spectral.py:267-363),
+ * FourierDerivative k-grid (spectral.py:126-146), IterativeSolver.set_laplacian
+ * (hybridnet.py:110-131).  n must be divisible by 2^depth (16 for the shipped net). */
+int hn_set_domain(hn_ctx* ctx, int n, int pml, float sigma_max, float k);
+
+/* Copy the sigma maps [2, n, n] (sigma_x, sigma_y) to `out` (device). hybridnet.py:126-131. */
+int hn_get_sigmas(hn_ctx* ctx, float* out, void* stream);
+
+/* Total hidden-state length per channel, sum_d (n / 2^d)^2 (architectures.py:390-404). */
+int64_t hn_state_len(const hn_ctx* ctx);
+
+/* Pre-allocate the activation workspace for batches up to `max_batch` (optional; otherwise
+ * grown by the first call, which then must not be under stream capture). */
+int hn_reserve(hn_ctx* ctx, int max_batch);
+
+/* out[B,2,n,n] = L(wf[B,2,n,n]), the spectral Laplacian with PML.
+ * Replaces: IterativeSolver.apply_laplacian (hybridnet.py:540-542) +
+ * fast_laplacian_with_pml (spectral.py:31-79). */
+int hn_laplacian(hn_ctx* ctx, const float* wf, float* out, int batch, void* stream);
+
+/* res[B,2,n,n] = L(wf) + k_sq * wf - src;  k_sq is [B,1,n,n]; src is [src_batch,2,n,n] with
+ * src_batch == 1 (broadcast) or == batch.  Replaces get_residual (hybridnet.py:544-556). */
+int hn_residual(hn_ctx* ctx, const float* wf, const float* k_sq, const float* src, int src_batch,
+                float* res, int batch, void* stream);
+
+/* rmse[B] = sqrt(mean_{c,h,w} res^2).  Replaces test_loss_function (hybridnet.py:295-297). */
+int hn_rmse(hn_ctx* ctx, const float* res, float* rmse, int batch, void* stream);
+
+/* d[B,2,n,n] = HybridNet(in6[B,6,n,n]); the hidden states are read from `states_in` and the new
+ * ones written to `states_out`, both in the reference's flat layout [B, 2, hn_state_len()]
+ * (architectures.py:419-437).  states_in must not alias states_out.
+ * Replaces HybridNet.forward + EncoderBlock.forward (architectures.py:439-465, 240-252). */
+int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states_out, float* d_out,
+            int batch, void* stream);
+
+/* n_iter fused solver iterations (hybridnet.py:558-584 single_step, looped as in
+ * forward :654-697 / n_steps :586-623):
+ *     d = HybridNet(cat[wf, 1e3*res, sigmas]); wf += d/1e3; res = L(wf) + k_sq*wf - src
+ * wf, res and states (flat layout) are updated IN PLACE.
+ * Optional outputs (NULL to skip):
+ *     res_hist  [n_iter, B, 2, n, n]  residual after every iteration (the reference keeps them all)
+ *     wf_hist   [n_iter, B, 2, n, n]  wavefield after every iteration (return_wavefields=True)
+ *     st_hist   [n_iter, B, 2, L]     flat hidden state after every iteration (return_states=True)
+ *     rmse_hist [n_iter, B]           per-sample residual RMSE after every iteration            */
+int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq, const float* src,
+            int src_batch, int batch, int n_iter, float* res_hist, float* wf_hist, float* st_hist,
+            float* rmse_hist, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HELMNET_HIP_H */

@@ -1,0 +1,263 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors and the CPU oracle.
+Needs a real MI355X: ``python -m pytest tests -m gpu``.
+
+Tolerances (fp32):
+  * teacher-forced single operators: L_inf <= 1e-5 * max|golden|
+  * free runs <= 300 iterations: L_inf(wavefield) <= 1e-4 absolute, RMSE trace within 2 %
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_inputs import teacher_inputs
+from helmnet_amd.phantoms import ring_sos_batch
+from oracle import helmnet_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+SRC = {96: [82, 48], 256: [30, 128], 512: [450, 256]}
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def solver():
+    from helmnet_amd import IterativeSolver
+    s = IterativeSolver.from_exported_weights()
+    s.freeze()
+    s.to(DEV)
+    return s
+
+
+def _err(name, got, g, n):
+    got = got.detach().float().cpu().contiguous().numpy()
+    scale = float(g[f"n{n}_{name}_absmax"])
+    if n == 96:
+        err = np.abs(got - g[f"n{n}_{name}"]).max()
+    elif got.ndim == 4:
+        err = max(np.abs(got[:, :, :40, :40] - g[f"n{n}_{name}_crop"]).max(),
+                  np.abs(got[:, :, 3::7, 5::11] - g[f"n{n}_{name}_stride"]).max())
+    else:
+        err = np.abs(got[:, :, 1::37] - g[f"n{n}_{name}_stride"]).max()
+    return err / scale
+
+
+def test_library_is_the_hip_build():
+    from helmnet_amd import _lib
+    lib = _lib.load()
+    assert lib.hn_abi_version() == 1
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize("n", [96, 256, 512])
+def test_device_tables_match_host_tables(solver, n, g_setup):
+    solver.set_domain_size(n, source_location=SRC[n])
+    eng = solver.engine()
+    sig = eng.sigmas().cpu()
+    assert torch.equal(sig, solver.sigmas.cpu())
+    assert np.array_equal(sig[0, 0].numpy(), g_setup[f"n{n}_sigma_x_row"])
+    assert np.array_equal(sig[1, :, 0].numpy(), g_setup[f"n{n}_sigma_y_col"])
+    assert np.allclose(solver.source[0, :, SRC[n][0], SRC[n][1]].cpu().numpy(), g_setup[f"n{n}_source_peak"], atol=1e-5)
+
+
+@pytest.mark.parametrize("n,b", [(96, 2), (256, 2), (512, 1)])
+def test_teacher_forced_ops_vs_reference_golden(solver, n, b, g_teacher):
+    ti = {k: torch.from_numpy(v).to(DEV) for k, v in teacher_inputs(n, b, seed=1000 + n).items()}
+    solver.set_domain_size(n, source_location=SRC[n])
+    k_sq, _ = solver.get_initials(ti["sos"])
+    errs = {}
+    errs["lap"] = _err("lap", solver.apply_laplacian(ti["wf"]), g_teacher, n)
+    errs["residual"] = _err("residual", solver.get_residual(ti["wf"], k_sq), g_teacher, n)
+    solver.f.set_states(ti["states"], flatten=True)
+    sig = solver.sigmas.unsqueeze(0).repeat(b, 1, 1, 1)
+    d = solver.f(torch.cat([ti["wf"], 1e3 * ti["res"], sig], 1))
+    errs["unet_d"] = _err("unet_d", d, g_teacher, n)
+    errs["states_new"] = _err("states_new", solver.f.get_states(flatten=True), g_teacher, n)
+    solver.f.set_states(ti["states"], flatten=True)
+    wf2, res2 = solver.single_step(ti["wf"], k_sq, ti["res"])
+    errs["step_wf"] = _err("step_wf", wf2, g_teacher, n)
+    errs["step_res"] = _err("step_res", res2, g_teacher, n)
+    assert all(e <= 1e-5 for e in errs.values()), errs
+
+
+@pytest.mark.parametrize("n,b", [(64, 3), (128, 2), (48, 2), (32, 1), (1024, 1)])
+def test_ops_vs_oracle_other_sizes(solver, n, b, weights):
+    """Sizes without golden vectors: compare with the CPU oracle on the same seeded inputs."""
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=77 + n).items()}
+    loc = [n // 4, n // 2]
+    solver.set_domain_size(n, source_location=loc)
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    src = O.point_source_map(n, loc, 10.0)
+    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+    st = O.unflatten_states(ti["states"], n, 4)
+    want_wf, want_res, want_st = O.single_step(ti["wf"], k_sq_o, ti["res"], st, weights, src, t)
+    want_lap = O.apply_laplacian(ti["wf"], t)
+    g = {k: v.to(DEV) for k, v in ti.items()}
+    k_sq, _ = solver.get_initials(g["sos"])
+    lap = solver.apply_laplacian(g["wf"]).cpu()
+    solver.f.set_states(g["states"], flatten=True)
+    wf2, res2 = solver.single_step(g["wf"], k_sq, g["res"])
+    st2 = solver.f.get_states(flatten=True).cpu()
+    errs = {
+        "lap": ((lap - want_lap).abs().max() / want_lap.abs().max()).item(),
+        "wf": ((wf2.cpu() - want_wf).abs().max() / want_wf.abs().max()).item(),
+        "res": ((res2.cpu() - want_res).abs().max() / want_res.abs().max()).item(),
+        "st": ((st2 - O.flatten_states(want_st)).abs().max() / O.flatten_states(want_st).abs().max()).item(),
+    }
+    assert all(e <= 1e-5 for e in errs.values()), errs
+
+
+def test_free_run_cfg1(solver, g_free):
+    """BASELINE.json config 1 on the GPU: 256^2 homogeneous, source [30,128], 100 iterations."""
+    solver.set_domain_size(256, source_location=[30, 128])
+    out = solver.forward(torch.ones(1, 1, 256, 256, device=DEV), num_iterations=100)
+    rm = out["residual_norms"].cpu().numpy()
+    assert np.allclose(rm, g_free["cfg1_rmse"], rtol=2e-2), np.abs(rm / g_free["cfg1_rmse"] - 1).max()
+    wf = out["wavefields"][0].cpu().numpy()
+    assert np.abs(wf - g_free["cfg1_wf_it100"]).max() <= 1e-4
+    assert len(out["residuals"]) == 100 and out["last_iteration"] == 99
+    # the kept residual tensors agree with the fused norms
+    r = torch.stack([solver.test_loss_function(x) for x in out["residuals"]]).cpu().numpy()
+    assert np.allclose(r, rm, rtol=1e-4)
+
+
+def test_free_run_readme_300(solver, g_free):
+    from helmnet_amd.phantoms import readme_sos
+    solver.set_domain_size(256, source_location=[30, 128])
+    out = solver.forward(torch.from_numpy(readme_sos()).to(DEV), num_iterations=300, residuals="norms")
+    rm = out["residual_norms"].cpu().numpy()
+    assert np.allclose(rm, g_free["readme_rmse"], rtol=2e-2), np.abs(rm / g_free["readme_rmse"] - 1).max()
+    assert np.abs(out["wavefields"][0].cpu().numpy() - g_free["readme_wf_it300"]).max() <= 1e-4
+
+
+def test_free_run_line_source_map(solver, g_free):
+    sos = np.ones((256, 256), np.float32)
+    sos[100:170, 30:240] = 1.5
+    smap = np.zeros((1, 2, 256, 256), np.float32)
+    smap[0, 0, 30, 120:130] = 1
+    solver.set_domain_size(256, source_map=torch.from_numpy(smap).to(DEV))
+    out = solver.forward(torch.from_numpy(sos)[None, None].to(DEV), num_iterations=100, residuals="last")
+    assert np.allclose(out["residual_norms"].cpu().numpy(), g_free["scatter_rmse"], rtol=2e-2)
+    assert np.abs(out["wavefields"][0].cpu().numpy() - g_free["scatter_wf_it100"]).max() <= 1e-4
+
+
+def test_free_run_ring96_dense_operator(solver, g_free):
+    """Native 96^2 training size (not a power of two -> dense spectral operator), batch 3."""
+    solver.set_domain_size(96, source_location=[82, 48])
+    out = solver.forward(torch.from_numpy(ring_sos_batch(96, 3, seed=7)).to(DEV), num_iterations=200,
+                         return_wavefields=True, residuals="norms")
+    assert np.allclose(out["residual_norms"].cpu().numpy(), g_free["ring96_rmse"], rtol=2e-2)
+    assert np.abs(out["wavefields"][49].cpu().numpy() - g_free["ring96_wf_it50"]).max() <= 1e-4
+    assert np.abs(out["wavefields"][199].cpu().numpy() - g_free["ring96_wf_it200"]).max() <= 1e-4
+
+
+def test_batch_samples_are_independent_and_deterministic(solver):
+    """BASELINE config 2 shape (B=32, 256^2): every sample of a batch equals the same sample
+    solved alone, bit for bit (samples never interact, hybridnet.py:654-697)."""
+    solver.set_domain_size(256, source_location=[30, 128])
+    sos = torch.from_numpy(ring_sos_batch(256, 32, seed=0)).to(DEV)
+    full = solver.forward(sos, num_iterations=20, residuals="norms")
+    again = solver.forward(sos, num_iterations=20, residuals="norms")
+    assert torch.equal(full["wavefields"][0], again["wavefields"][0])
+    for i in (0, 13, 31):
+        one = solver.forward(sos[i:i + 1], num_iterations=20, residuals="norms")
+        assert torch.equal(one["wavefields"][0][0], full["wavefields"][0][i])
+        assert torch.allclose(one["residual_norms"][:, 0], full["residual_norms"][:, i], rtol=1e-5)
+
+
+def test_laplacian_linearity_and_plane_wave(solver):
+    n, m = 512, 7
+    solver.set_domain_size(n, source_location=SRC[n])
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(2, 2, n, n, generator=g).to(DEV)
+    b = torch.randn(2, 2, n, n, generator=g).to(DEV)
+    lin = solver.apply_laplacian(a + 2 * b) - (solver.apply_laplacian(a) + 2 * solver.apply_laplacian(b))
+    assert lin.abs().max().item() <= 2e-4  # |L u| ~ 40 for white noise
+    x = torch.arange(n, dtype=torch.float64)
+    ph = 2 * np.pi * m * x / n
+    u = torch.stack([torch.cos(ph), torch.sin(ph)], 0).unsqueeze(1).repeat(1, n, 1).unsqueeze(0).float().to(DEV)
+    lap = solver.apply_laplacian(u)
+    want = -(2 * np.pi * m / n) ** 2 * u
+    assert (lap - want)[:, :, 8:-8, 8:-8].abs().max().item() < 5e-6
+    # transposed plane wave exercises the column pass
+    lap_t = solver.apply_laplacian(u.transpose(2, 3).contiguous())
+    assert (lap_t - want.transpose(2, 3))[:, :, 8:-8, 8:-8].abs().max().item() < 5e-6
+
+
+def test_loop_api_consistency(solver):
+    """forward == get_initials + n_steps chunks == repeated single_step; histories line up."""
+    solver.set_domain_size(128, source_location=[20, 64])
+    sos = torch.from_numpy(ring_sos_batch(128, 2, seed=5)).to(DEV)
+    ref = solver.forward(sos, num_iterations=7, return_wavefields=True, return_states=True)
+    assert len(ref["wavefields"]) == 7 and len(ref["states"]) == 7 and len(ref["residuals"]) == 7
+    k_sq, wf = solver.get_initials(sos)
+    solver.f.clear_states(wf)
+    res = solver.get_residual(wf, k_sq)
+    a = solver.n_steps(wf, k_sq, res, 3)
+    b = solver.n_steps(a["wavefields"][0], k_sq, a["residuals"][-1], 4, return_states=True)
+    assert torch.equal(b["wavefields"][0], ref["wavefields"][6])
+    assert torch.equal(b["states"][-1], ref["states"][6])
+    solver.f.clear_states(wf)
+    w, r = wf, res
+    for _ in range(7):
+        w, r = solver.single_step(w, k_sq, r)
+    assert torch.equal(w, ref["wavefields"][6]) and torch.equal(r, ref["residuals"][6])
+    assert torch.equal(solver.f.get_states(flatten=True), ref["states"][6])
+    assert torch.allclose(solver.engine().rmse(r), ref["residual_norms"][6], rtol=1e-5)
+
+
+def test_multiple_sources_and_variable_source(solver, weights):
+    n = 64
+    solver.set_domain_size(n, source_location=[10, 32])
+    solver.set_multiple_sources([[10, 32], [40, 20]])
+    assert solver.source.shape == (2, 2, n, n)
+    sos = torch.from_numpy(ring_sos_batch(n, 2, seed=9)).to(DEV)
+    out = solver.forward(sos, num_iterations=30, residuals="norms")
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    src = torch.cat([O.point_source_map(n, [10, 32], 10.0), O.point_source_map(n, [40, 20], 10.0)], 0)
+    want = O.solve(sos.cpu(), weights, src, t, 30)
+    assert (out["wavefields"][0].cpu() - want["wavefield"]).abs().max().item() <= 1e-4
+    # forward_variable_src: switch to a second map after 10 iterations
+    m1 = O.point_source_map(n, [10, 32], 10.0).to(DEV)
+    m2 = O.point_source_map(n, [50, 40], 5.0).to(DEV)
+    solver.set_source_maps(m1)
+    out = solver.forward_variable_src(sos, {"iteration": [10], "src_maps": [m2]}, num_iterations=25, residuals="norms")
+    k_sq, wf = O.get_initials(sos.cpu(), 1.0)
+    st = [torch.zeros(2, 2, s, s) for s in O.state_dims(n, 4)]
+    s_cpu = m1.cpu()
+    res = O.get_residual(wf, k_sq, s_cpu, t)
+    for it in range(25):
+        if it == 10:
+            s_cpu = m2.cpu()
+            res = O.get_residual(wf, k_sq, s_cpu, t)
+        wf, res, st = O.single_step(wf, k_sq, res, st, weights, s_cpu, t)
+    assert (out["wavefields"][0].cpu() - wf).abs().max().item() <= 1e-4
+    assert out["residual_norms"].shape == (25, 2)
+
+
+def test_error_behaviour(solver):
+    from helmnet_amd import HybridNet, IterativeSolver
+    with pytest.raises(NotImplementedError):
+        HybridNet("tanh", 4, 64, 8, 6, 2, 4)
+    net = HybridNet("prelu", 4, 64, 8, 6, 2, 4).to(DEV)
+    with pytest.raises(ValueError):  # state unset (architectures.py:242-245)
+        net(torch.zeros(1, 6, 64, 64, device=DEV))
+    with pytest.raises(ValueError):
+        solver.set_domain_size(72, source_location=[5, 5])  # 72 % 16 != 0
+        solver.forward(torch.ones(1, 1, 72, 72, device=DEV), num_iterations=1)
+    cpu = IterativeSolver.from_exported_weights()
+    with pytest.raises(RuntimeError):
+        cpu.forward(torch.ones(1, 1, 96, 96), num_iterations=1)
+
+
+def test_standalone_hybridnet_matches_oracle(weights):
+    from helmnet_amd import HybridNet
+    net = HybridNet("prelu", 4, 64, 8, 6, 2, 4)
+    net.load_state_dict(weights)
+    net.to(DEV)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 6, 64, 64, generator=g)
+    net.clear_states(x.to(DEV))
+    d = net(x.to(DEV)).cpu()
+    want, st = O.unet_forward(x, [torch.zeros(2, 2, s, s) for s in O.state_dims(64, 4)], weights)
+    assert (d - want).abs().max().item() <= 1e-5 * want.abs().max().item()
+    assert (net.get_states(flatten=True).cpu() - O.flatten_states(st)).abs().max().item() <= 1e-5
