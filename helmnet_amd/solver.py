@@ -145,7 +145,10 @@ class IterativeSolver(nn.Module):
         self.hparams.domain_size = domain_size
         self.f.domain_size = self.hparams.domain_size
         self.set_laplacian()
-        self.setup_source()
+        # the reference builds the source module at hparams.source_location first and only then
+        # moves it (hybridnet.py:96,101-104), which indexes out of bounds when the checkpoint's
+        # location does not fit the new domain; build it at the requested location directly.
+        self.setup_source(location=source_location)
         self.Lap.to(self.device)
         self.source_module.to(self.device)
         if source_location is not None:
@@ -168,11 +171,16 @@ class IterativeSolver(nn.Module):
         sx, sy = self.Lap.sigmas()
         self.sigmas = torch.stack([sx.detach().clone(), sy.detach().clone()]).float().to(dev)
 
-    def setup_source(self):
+    def setup_source(self, location=None):
+        n = self.hparams.domain_size
+        if location is None:
+            location = self.hparams.source_location
+            if not (0 <= location[0] < n and 0 <= location[1] < n):
+                location = [n // 2, n // 2]  # placeholder; a source map / location is set right after
         self.source_module = SourceModule(
-            image_size=self.hparams.domain_size,
+            image_size=n,
             omega=self.hparams.omega,
-            location=self.hparams.source_location,
+            location=location,
             amplitude=self.hparams.source_amplitude,
             phase=self.hparams.source_phase,
             smooth=self.hparams.source_smoothing,
