@@ -22,6 +22,21 @@ int fail(hn_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+ProfScope::ProfScope(hn_ctx* ctx, int id, hipStream_t st) : c(ctx), s(st) {
+    if (!(ctx->prof_mask >> id & 1ull)) return;
+    hn_ctx::ProfRec r{id, nullptr, nullptr};
+    for (hipEvent_t* e : {&r.a, &r.b}) {
+        if (!ctx->prof_pool.empty()) { *e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
+        else if (hipEventCreate(e) != hipSuccess) return;
+    }
+    if (hipEventRecord(r.a, st) != hipSuccess) return;
+    slot = (int)ctx->prof_recs.size();
+    ctx->prof_recs.push_back(r);
+}
+ProfScope::~ProfScope() {
+    if (slot >= 0) (void)hipEventRecord(c->prof_recs[slot].b, s);
+}
+
 namespace {
 
 constexpr size_t dc_count(int cin, int cm, int co) { return (size_t)cm * cin * 9 + cm + 1 + (size_t)co * cm * 9 + co; }
@@ -72,11 +87,11 @@ struct Packer {
 
 void free_workspace(hn_ctx* c) {
     for (int d = 0; d <= kMaxDepth; ++d) {
-        hipFree(c->buf_a[d]); c->buf_a[d] = nullptr;
-        hipFree(c->buf_y[d]); c->buf_y[d] = nullptr;
-        if (d < kMaxDepth) { hipFree(c->buf_o[d]); c->buf_o[d] = nullptr; }
+        (void)hipFree(c->buf_a[d]); c->buf_a[d] = nullptr;
+        (void)hipFree(c->buf_y[d]); c->buf_y[d] = nullptr;
+        if (d < kMaxDepth) { (void)hipFree(c->buf_o[d]); c->buf_o[d] = nullptr; }
     }
-    hipFree(c->st_tmp); c->st_tmp = nullptr;
+    (void)hipFree(c->st_tmp); c->st_tmp = nullptr;
     c->cap_batch = 0;
 }
 
@@ -141,7 +156,9 @@ void hn_destroy(hn_ctx* ctx) {
     hipSetDevice(ctx->device);
     free_workspace(ctx);
     spec_free(ctx->tab);
-    hipFree(ctx->wdev);
+    (void)hipFree(ctx->wdev);
+    for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -165,7 +182,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     const size_t want = hn_weight_count(features, depth, state_ch);
     if (n_floats != want) return fail(ctx, HN_ERR_ARG, "weight blob has %zu floats, expected %zu", n_floats, want);
     HN_HIP(ctx, hipSetDevice(ctx->device));
-    hipFree(ctx->wdev);
+    (void)hipFree(ctx->wdev);
     ctx->wdev = nullptr;
     HN_HIP(ctx, hipMalloc((void**)&ctx->wdev, want * sizeof(float)));
     std::vector<float> packed(want);
@@ -233,6 +250,33 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
     }
     HN_HIP(ctx, hipMalloc((void**)&ctx->st_tmp, sizeof(float) * (size_t)max_batch * kState * ctx->state_len));
     ctx->cap_batch = max_batch;
+    return HN_OK;
+}
+
+int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask) {
+    if (!ctx) return HN_ERR_ARG;
+    ctx->prof_mask = kernel_mask;
+    return HN_OK;
+}
+
+int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids) {
+    if (!ctx || !total_ms || !count) return fail(ctx, HN_ERR_ARG, "hn_profile_collect: NULL argument");
+    for (auto& r : ctx->prof_recs) {
+        HN_HIP(ctx, hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HN_HIP(ctx, hipEventElapsedTime(&ms, r.a, r.b));
+        ctx->prof_ms[r.id] += ms;
+        ctx->prof_cnt[r.id] += 1;
+        ctx->prof_pool.push_back(r.a);
+        ctx->prof_pool.push_back(r.b);
+    }
+    ctx->prof_recs.clear();
+    for (int i = 0; i < n_ids && i < KID_COUNT; ++i) {
+        total_ms[i] = ctx->prof_ms[i];
+        count[i] = ctx->prof_cnt[i];
+        ctx->prof_ms[i] = 0.0;
+        ctx->prof_cnt[i] = 0;
+    }
     return HN_OK;
 }
 

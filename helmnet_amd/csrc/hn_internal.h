@@ -82,8 +82,13 @@ struct hn_ctx {
     float* buf_o[hn::kMaxDepth]{};      // out_d (skip connections)
     float* buf_y[hn::kMaxDepth + 1]{};  // decoder outputs y_d
     float* st_tmp = nullptr;            // second flat state buffer for hn_step ping-pong
-    float* sumsq = nullptr;             // [cap_iter * cap_batch] scratch for the RMSE history
-    size_t sumsq_cap = 0;
+    // optional per-kernel timing with HIP events on the caller's stream (hn_profile_*)
+    uint64_t prof_mask = 0;
+    struct ProfRec { int id; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[64]{};
+    long prof_cnt[64]{};
 };
 
 namespace hn {
@@ -98,6 +103,29 @@ void set_global_error(const char* msg);
             return hn::fail((ctx), HN_ERR_HIP, "%s failed: %s (%s:%d)", #call,              \
                             hipGetErrorString(e_), __FILE__, __LINE__);                     \
     } while (0)
+
+// Kernel ids of the per-iteration launch sequence (hn_profile_*).
+enum KernelId : int {
+    KID_INC = 0,          // DoubleConv 6->8->8 at level 0
+    KID_SIG0 = 1,         // + 3*d : conv_signal DoubleConv 10->8->8 at level d
+    KID_STATE0 = 2,       // + 3*d : conv_state  DoubleConv 10->2->2 at level d
+    KID_DOWN0 = 3,        // + 3*d : 8x8 stride-2 conv at level d
+    KID_BOTTLENECK = 19,  // DoubleConv 8->8->8 at level depth
+    KID_UP0 = 20,         // + 2*d : 8x8 stride-2 transposed conv producing level d
+    KID_DEC0 = 21,        // + 2*d : decoder DoubleConv 16->8->8 at level d (d = 0: + outc + wf update)
+    KID_SPEC_COLS = 32,   // spectral column pass
+    KID_SPEC_ROWS = 33,   // spectral row pass + residual terms (or the dense operator)
+    KID_COUNT = 34
+};
+
+// RAII event pair around one launch when that kernel id is selected by hn_profile_enable.
+struct ProfScope {
+    hn_ctx* c;
+    hipStream_t s;
+    int slot = -1;
+    ProfScope(hn_ctx* ctx, int id, hipStream_t st);
+    ~ProfScope();
+};
 
 // ---- spectral (hn_spectral.hip) ----
 int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k);

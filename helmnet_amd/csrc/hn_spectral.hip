@@ -237,12 +237,16 @@ __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf
 }
 
 template <int N>
-void launch_pow2(const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch,
+void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch,
                  const SpecPtrs& p, bool resid, float* sumsq, hipStream_t s) {
     constexpr int T = N / 4;
     constexpr int C = (1024 / T) < 16 ? (1024 / T) : 16;
-    hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / C, batch), dim3(C, T), 0, s, wf, out, p);
+    {
+        ProfScope ps(ctx, KID_SPEC_COLS, s);
+        hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / C, batch), dim3(C, T), 0, s, wf, out, p);
+    }
     constexpr int R = RowCfg<N>::R;
+    ProfScope ps(ctx, KID_SPEC_ROWS, s);
     hipLaunchKernelGGL((k_spec_rows<N>), dim3(N / R, batch), dim3(T, R), 0, s, wf, out, ksq, src, src_sb, p,
                        1 | (resid ? 2 : 0), sumsq);
 }
@@ -257,7 +261,7 @@ int upload(hn_ctx* ctx, T** dst, const std::vector<T>& h) {
 }  // namespace
 
 void spec_free(SpecTables& t) {
-    hipFree(t.tw); hipFree(t.k1); hipFree(t.k2); hipFree(t.a); hipFree(t.b); hipFree(t.dense_t); hipFree(t.sigmas);
+    for (void* p : {(void*)t.tw, (void*)t.k1, (void*)t.k2, (void*)t.a, (void*)t.b, (void*)t.dense_t, (void*)t.sigmas}) (void)hipFree(p);
     t = SpecTables{};
 }
 
@@ -359,17 +363,18 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
     if (t.pow2) {
         const SpecPtrs p{t.tw, t.k1, t.k2, t.a, t.b};
         switch (t.n) {
-            case 16: launch_pow2<16>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 32: launch_pow2<32>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 64: launch_pow2<64>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 128: launch_pow2<128>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 256: launch_pow2<256>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 512: launch_pow2<512>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 1024: launch_pow2<1024>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 2048: launch_pow2<2048>(wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 16: launch_pow2<16>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 32: launch_pow2<32>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 64: launch_pow2<64>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 128: launch_pow2<128>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 256: launch_pow2<256>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 512: launch_pow2<512>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 1024: launch_pow2<1024>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 2048: launch_pow2<2048>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
             default: return fail(ctx, HN_ERR_ARG, "unsupported power-of-two size %d", t.n);
         }
     } else {
+        ProfScope ps(ctx, KID_SPEC_ROWS, s);
         hipLaunchKernelGGL(k_spec_dense, dim3((t.n + 255) / 256, t.n, batch), dim3(256), 0, s, wf, out, ksq, src,
                            src_sb, t.dense_t, t.n, resid ? 2 : 0, accum_sumsq);
     }

@@ -423,30 +423,47 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     auto featsrc = [&](const float* p, int d) { return Src{p, kFeat * plane(d), plane(d), 1.f}; };
 
     // inc: DoubleConv(6 -> 8 -> 8) on [wf, 1e3*res, sigmas]  (architectures.py:442, hybridnet.py:566)
+    {
+    ProfScope ps(ctx, KID_INC, s);
     launch_dc<2, 2, 2, kFeat, kFeat, 0>(in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, noepi, n, n, batch, s);
+    }
     for (int d = 0; d < depth; ++d) {
         const int m = n >> d;
         const Src st_old{states_in + ctx->state_off[d], 2 * L, L, 1.f};
         const Dst st_new{states_out + ctx->state_off[d], 2 * L, L};
         // out = conv_signal(cat[x, state])                               (architectures.py:246-247)
-        launch_dc<kFeat, kState, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d),
-                                                      ctx->sig[d], noepi, m, m, batch, s);
+        {
+            ProfScope ps(ctx, KID_SIG0 + 3 * d, s);
+            launch_dc<kFeat, kState, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d),
+                                                          ctx->sig[d], noepi, m, m, batch, s);
+        }
         // state = conv_state(cat[out, state_old])                        (architectures.py:248)
-        launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
-                                                        noepi, m, m, batch, s);
+        {
+            ProfScope ps(ctx, KID_STATE0 + 3 * d, s);
+            launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
+                                                            noepi, m, m, batch, s);
+        }
         // x = down(out)                                                  (architectures.py:252)
+        ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
         hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
                            dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                            ctx->down[d], m, m);
     }
     // bottleneck: decode[depth]                                          (architectures.py:453)
-    launch_dc<kFeat, 0, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth),
-                                            ctx->dec[depth], noepi, n >> depth, n >> depth, batch, s);
+    {
+        ProfScope ps(ctx, KID_BOTTLENECK, s);
+        launch_dc<kFeat, 0, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth),
+                                                ctx->dec[depth], noepi, n >> depth, n >> depth, batch, s);
+    }
     for (int d = depth - 1; d >= 0; --d) {
         const int m = n >> d;
         // x = up[d](x)                                                   (architectures.py:456)
-        hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
-                           featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
+        {
+            ProfScope ps(ctx, KID_UP0 + 2 * d, s);
+            hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
+                               featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
+        }
+        ProfScope ps(ctx, KID_DEC0 + 2 * d, s);
         // x = decode[d](cat[x, skip_d])                                  (architectures.py:458-460)
         if (d > 0) {
             launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none,

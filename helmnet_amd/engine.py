@@ -188,3 +188,30 @@ class Engine:
         rc = self.lib.hn_step(self.ctx, _ptr(wf), _ptr(res), _ptr(states), _ptr(k_sq), _ptr(src), src.shape[0], b,
                               int(n_iter), _ptr(res_hist), _ptr(wf_hist), _ptr(st_hist), _ptr(rmse_hist), self._stream())
         _lib.check(rc, self.ctx, "hn_step")
+
+    # ---- measurement hooks ---------------------------------------------------------------
+    KERNEL_IDS = 34
+
+    @staticmethod
+    def kernel_name(kid: int) -> str:
+        if kid == 0:
+            return "inc"
+        if 1 <= kid <= 18:
+            return ("conv_signal", "conv_state", "down")[(kid - 1) % 3] + str((kid - 1) // 3)
+        if kid == 19:
+            return "bottleneck"
+        if 20 <= kid <= 31:
+            return ("up", "decode")[(kid - 20) % 2] + str((kid - 20) // 2)
+        return {32: "spectral_cols", 33: "spectral_rows"}[kid]
+
+    def profile_enable(self, kernel_ids=None):
+        """Bracket the selected kernels (None = all, [] = none) with HIP events on the launch stream."""
+        mask = (1 << self.KERNEL_IDS) - 1 if kernel_ids is None else sum(1 << k for k in kernel_ids)
+        _lib.check(self.lib.hn_profile_enable(self.ctx, ctypes.c_uint64(mask)), self.ctx, "hn_profile_enable")
+
+    def profile_collect(self) -> dict:
+        """{kernel name: (total ms, launches)} since the last collect."""
+        ms = (ctypes.c_double * self.KERNEL_IDS)()
+        cnt = (ctypes.c_int64 * self.KERNEL_IDS)()
+        _lib.check(self.lib.hn_profile_collect(self.ctx, ms, cnt, self.KERNEL_IDS), self.ctx, "hn_profile_collect")
+        return {self.kernel_name(i): (ms[i], int(cnt[i])) for i in range(self.KERNEL_IDS) if cnt[i]}

@@ -118,6 +118,18 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
             int src_batch, int batch, int n_iter, float* res_hist, float* wf_hist, float* st_hist,
             float* rmse_hist, void* stream);
 
+/* Optional per-kernel timing (measurement only; bench.py's roofline block uses it).  While a
+ * kernel id's bit is set in `kernel_mask`, every launch of that kernel inside hn_step / hn_unet /
+ * hn_residual is bracketed by a HIP event pair recorded on the caller's stream.  Kernel ids:
+ *   0 inc | 1+3d conv_signal(d) | 2+3d conv_state(d) | 3+3d down(d) | 19 bottleneck |
+ *   20+2d up(d) | 21+2d decoder(d) (d=0 includes outc + wavefield update) |
+ *   32 spectral column pass | 33 spectral row pass (or the dense operator).
+ * hn_profile_collect synchronises the recorded events, returns per-id total milliseconds and
+ * launch counts for ids [0, n_ids) and resets the accumulators. */
+#define HN_KERNEL_IDS 34
+int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
+int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids);
+
 #ifdef __cplusplus
 }
 #endif
