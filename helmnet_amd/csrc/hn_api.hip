@@ -1,6 +1,7 @@
 // C ABI of libhelmnet_hip.so (see include/helmnet_hip.h): context, weight re-packing, workspace,
 // and the fused solver loop.  gfx950 only.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "hn_internal.h"
@@ -157,6 +158,7 @@ void hn_destroy(hn_ctx* ctx) {
     free_workspace(ctx);
     spec_free(ctx->tab);
     (void)hipFree(ctx->wdev);
+    (void)hipFree(ctx->fragdev);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -201,6 +203,39 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     ctx->outc_b = ctx->wdev + p.pos; p.pos += 2;
     if (p.pos != want) return fail(ctx, HN_ERR_ARG, "internal: packed %zu of %zu floats", p.pos, want);
     HN_HIP(ctx, hipMemcpy(ctx->wdev, packed.data(), want * sizeof(float), hipMemcpyHostToDevice));
+    {   // A-operand fragments for the matrix-core kernels, built from the original OIHW tensors
+        std::vector<float> fr;
+        std::vector<size_t> off;
+        size_t pos = 0;
+        auto dc = [&](int cin, int cm, int co) {  // returns offsets of (frag1, frag2) or (npos, npos)
+            const float* w1 = blob + pos; pos += (size_t)cm * cin * 9 + cm + 1;
+            const float* w2 = blob + pos; pos += (size_t)co * cm * 9 + co;
+            if (cm != kFeat || co != kFeat) { off.push_back((size_t)-1); off.push_back((size_t)-1); return; }
+            off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3(w1, cin, fr.data() + off.back());
+            off.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * 3 * 64); pack_frag_3x3(w2, kFeat, fr.data() + off.back());
+        };
+        auto k8 = [&](bool up) {
+            off.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * kFeat * 64);
+            if (up) pack_frag_up(blob + pos, fr.data() + off.back()); else pack_frag_down(blob + pos, fr.data() + off.back());
+            pos += k8_count();
+        };
+        dc(kInCh, kFeat, kFeat);
+        for (int d = 0; d < depth; ++d) { dc(kFeat + kState, kFeat, kFeat); k8(false); dc(kFeat + kState, kState, kState); }
+        for (int d = 0; d <= depth; ++d) dc(d < depth ? 2 * kFeat : kFeat, kFeat, kFeat);
+        for (int d = 0; d < depth; ++d) k8(true);
+        (void)hipFree(ctx->fragdev);
+        ctx->fragdev = nullptr;
+        HN_HIP(ctx, hipMalloc((void**)&ctx->fragdev, fr.size() * sizeof(float)));
+        HN_HIP(ctx, hipMemcpy(ctx->fragdev, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice));
+        size_t i = 0;
+        auto nxt = [&]() { const size_t o = off[i++]; return o == (size_t)-1 ? (const float*)nullptr : ctx->fragdev + o; };
+        ctx->f_inc[0] = nxt(); ctx->f_inc[1] = nxt();
+        for (int d = 0; d < depth; ++d) { ctx->f_sig[d][0] = nxt(); ctx->f_sig[d][1] = nxt(); ctx->f_down[d] = nxt(); nxt(); nxt(); }
+        for (int d = 0; d <= depth; ++d) { ctx->f_dec[d][0] = nxt(); ctx->f_dec[d][1] = nxt(); }
+        for (int d = 0; d < depth; ++d) ctx->f_up[d] = nxt();
+        const char* impl = getenv("HN_UNET_IMPL");
+        ctx->use_valu = impl && std::strcmp(impl, "valu") == 0;
+    }
     if (ctx->have_weights && ctx->depth != depth) free_workspace(ctx);
     ctx->depth = depth;
     ctx->have_weights = true;

@@ -70,6 +70,11 @@ struct hn_ctx {
     float* wdev = nullptr;  // all re-packed weights
     hn::DcW inc{}, sig[hn::kMaxDepth]{}, st[hn::kMaxDepth]{}, dec[hn::kMaxDepth + 1]{};
     hn::K8W down[hn::kMaxDepth]{}, up[hn::kMaxDepth]{};
+    // MFMA A-operand fragments (hn_mfma.hip): [cin][3][64] per 3x3 conv, [8][8][64] per 8x8 conv
+    float* fragdev = nullptr;
+    const float *f_inc[2]{}, *f_sig[hn::kMaxDepth][2]{}, *f_dec[hn::kMaxDepth + 1][2]{};
+    const float *f_down[hn::kMaxDepth]{}, *f_up[hn::kMaxDepth]{};
+    bool use_valu = false;  // HN_UNET_IMPL=valu selects the VALU direct-conv kernels (A/B testing)
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
     // domain
@@ -133,6 +138,16 @@ void spec_free(SpecTables& t);
 // out = L(wf) [+ ksq*wf - src]; `accum_sumsq` (nullable) receives sum over (c,h,w) of out^2 per sample.
 int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, int src_batch,
                int batch, float* accum_sumsq, hipStream_t s);
+
+// ---- matrix-core kernels (hn_mfma.hip) ----
+void pack_frag_3x3(const float* w_oihw, int cin, float* dst);  // -> [cin][3][64]
+void pack_frag_down(const float* w_oihw, float* dst);          // -> [8][8][64]
+void pack_frag_up(const float* w_iohw, float* dst);            // -> [8][2][4][64]
+// kind: 0 inc (2+2+2 ch), 1 conv_signal (8+2), 2 bottleneck (8), 3 decoder (8+8; final_epi adds outc + wf update)
+int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
+               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
+void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
+void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
 
 // ---- unet (hn_unet.hip) ----
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the

@@ -1,0 +1,536 @@
+// fp32 matrix-core (v_mfma_f32_16x16x4_f32) convolution kernels of the HybridNet for gfx950.
+//
+// The f32-input MFMA computes D(16x16) += A(16x4) * B(4x16) with exact fp32 FMA numerics at the
+// fp32 peak rate and -- unlike a VALU FMA stream -- saturates with one wavefront per SIMD, which is
+// what an LDS-tiled fp32 convolution can afford.  Operand layout (lane l of 64):
+//     A: one VGPR = A[i = l & 15][k = l >> 4]     B: one VGPR = B[k = l >> 4][j = l & 15]
+//     D: four VGPRs, D[4 * (l >> 4) + r][l & 15], r = 0..3
+// With only 8 output channels the M dimension is filled by pairing each channel with a second
+// output index, K carries 4 kernel taps, N carries 16 pixels:
+//   * 3x3 conv   : M = (co, dxo)   two horizontally adjacent outputs share a 4-tap input window
+//                  (3 of the 4 taps are useful per output: 75 % of the MFMA slots do work)
+//   * 8x8 s2 down: M = (co, h)     h = upper / lower half of the 8 vertical taps, both halves read
+//                  the same 4-row window; out[Y] = P0[Y] + P1[Y + 2] is a register add (100 %)
+//   * 8x8 s2 up  : M = (co, py)    the two output-row phases share the same 4 input rows (100 %)
+// The B operand is one ds_read_b32 per lane from the staged LDS tile, so the 16 "pixels" of an
+// MFMA may be ANY 16 positions; the mid region of a fused DoubleConv (18 x 66 pixels) is cut
+// into 16-pair groups with no rounding loss per row.
+//
+// Reference semantics: helmnet/architectures.py:63-84 (DoubleConv), :209-211 (down), :375-382
+// (up), :47-60 (outc), hybridnet.py:564-570 (input concat, wavefield update).
+#include "hn_internal.h"
+
+namespace hn {
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
+constexpr int cmax_(int a, int b) { return a > b ? a : b; }
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused DoubleConv (cin -> 8 -> 8), tile 16 x TW outputs, 4 wavefronts
+// ------------------------------------------------------------------------------------------
+template <int CA, int CB, int CC, int TW>
+struct McCfg {
+    static constexpr int TH = 16;
+    static constexpr int CIN = CA + CB + CC;
+    static constexpr int NG = CIN / 2;             // input is staged two channels at a time
+    static constexpr int IR = TH + 4, PI = TW + 4; // staged input tile (halo 2)
+    static constexpr int PLANE = IR * PI;
+    static constexpr int MR = TH + 2;              // mid rows (halo 1)
+    static constexpr int PM = TW + 4;              // mid pitch
+    static constexpr int MPLANE = MR * PM;
+    static constexpr int PPR1 = (TW + 2) / 2;      // pixel pairs per mid row
+    static constexpr int NS1 = MR * PPR1;          // conv1 slots (pixel pairs)
+    static constexpr int G1 = cdiv_(NS1, 16);      // conv1 MFMA groups per tile
+    static constexpr int GW1 = cdiv_(G1, 4);       // ... per wavefront
+    static constexpr int PPR2 = TW / 2;
+    static constexpr int G2 = TH * PPR2 / 16;
+    static constexpr int GW2 = G2 / 4;
+    static constexpr int NT = 256;
+    static constexpr int NL = cdiv_(PLANE, NT);    // staged positions per thread (x 2 channels)
+    static constexpr int LDS_FLOATS = cmax_(4 * PLANE, kFeat * MPLANE) + 8;
+};
+
+struct McW {
+    const float* a1;  // conv1 A fragments [cin][3][64]
+    const float* b1;  // [8]
+    const float* slope;
+    const float* a2;  // conv2 A fragments [8][3][64]
+    const float* b2;  // [8]
+};
+struct McEpi {
+    const float* ow;  // outc weight [8][2]
+    const float* ob;  // [2]
+    float* d_out;
+    float* wf;
+};
+
+template <int CA, int CB, int CC, int TW, int EPI>
+__global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
+    using C = McCfg<CA, CB, CC, TW>;
+    // one array: the staged input (2 buffers x 2 channels) is dead once conv1 is done, the mid
+    // tensor takes its place
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;  // q doubles as the K index t of the A/B operands
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * C::TH;
+
+    // ---- staging bookkeeping: unconditional loads from clamped addresses, masked at commit ----
+    int goff[C::NL];
+    unsigned okmask = 0, inmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * C::NT;
+        const int ir = e / C::PI, ic = e - ir * C::PI;
+        const int y = y0 - 2 + ir, x = x0 - 2 + ic;
+        const bool ok = (e < C::PLANE) && y >= 0 && y < H && x >= 0 && x < W;
+        goff[i] = ok ? y * W + x : 0;
+        okmask |= (ok ? 1u : 0u) << i;
+        inmask |= ((e < C::PLANE) ? 1u : 0u) << i;
+    }
+    float stage[C::NL][2], stage_scale = 1.f, afrag_next[6];
+    auto fetch = [&](int g) {
+        const float* p0; long cs;
+        int c = 2 * g;
+        if (c < CA) { p0 = sa.p + (long)b * sa.sb + (long)c * sa.sc; cs = sa.sc; stage_scale = sa.scale; }
+        else if (CB > 0 && c - CA < CB) { c -= CA; p0 = sb.p + (long)b * sb.sb + (long)c * sb.sc; cs = sb.sc; stage_scale = sb.scale; }
+        else { c -= CA + CB; p0 = sc.p + (long)b * sc.sb + (long)c * sc.sc; cs = sc.sc; stage_scale = sc.scale; }
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            stage[i][0] = p0[goff[i]];
+            stage[i][1] = p0[cs + goff[i]];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) afrag_next[j] = w.a1[(g * 6 + j) * 64 + lane];
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i)
+            if (inmask >> i & 1u) {
+                const bool ok = okmask >> i & 1u;
+                const int l = buf * 2 * C::PLANE + tid + i * C::NT;
+                lds[l] = ok ? stage[i][0] * stage_scale : 0.f;
+                lds[l + C::PLANE] = ok ? stage[i][1] * stage_scale : 0.f;
+            }
+    };
+
+    // ---- conv1: every lane owns slot (16*g + n) of each of its groups g = wave + 4*gi ----
+    int boff1[C::GW1];
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) {
+        int s = 16 * (wave + 4 * gi) + n;
+        s = s < C::NS1 ? s : C::NS1 - 1;  // surplus slots recompute the last pair and are not stored
+        const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+        boff1[gi] = mrow * C::PI + 2 * pc + q;
+    }
+    f32x4 acc1[C::GW1];
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) acc1[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+#pragma unroll 1
+    for (int g = 0; g < C::NG; ++g) {
+        const int buf = g & 1;
+        commit(buf);
+        float afrag[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) afrag[j] = afrag_next[j];
+        __syncthreads();
+        if (g + 1 < C::NG) fetch(g + 1);
+        const float* t = lds + buf * 2 * C::PLANE;
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int gi = 0; gi < C::GW1; ++gi)
+                    acc1[gi] = mfma4(afrag[c * 3 + dy], t[boff1[gi] + c * C::PLANE + dy * C::PI], acc1[gi]);
+    }
+    // conv2 A fragments: issue the loads now, they land while the mid tensor is written
+    float a2[kFeat * 3];
+#pragma unroll
+    for (int j = 0; j < kFeat * 3; ++j) a2[j] = w.a2[j * 64 + lane];
+    __syncthreads();  // all reads of the staged input are done: the mid tensor may overwrite it
+    {
+        const float slope = w.slope[0];
+        const float bias0 = w.b1[2 * q], bias1 = w.b1[2 * q + 1];
+#pragma unroll
+        for (int gi = 0; gi < C::GW1; ++gi) {
+            const int s = 16 * (wave + 4 * gi) + n;
+            if (s < C::NS1) {
+                const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+                const int y = y0 - 1 + mrow, x = x0 - 1 + 2 * pc;
+                const bool yin = y >= 0 && y < H;
+                const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
+                float v[4] = {acc1[gi][0] + bias0, acc1[gi][1] + bias0, acc1[gi][2] + bias1, acc1[gi][3] + bias1};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : slope * v[r];  // PReLU (architectures.py:32-33)
+                // conv2 zero-pads the MID tensor: outside the image it is zero, not conv1's value
+                float* m0 = lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
+                *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
+                *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 over the TH x TW outputs ----
+    int boff2[C::GW2];
+#pragma unroll
+    for (int gi = 0; gi < C::GW2; ++gi) {
+        const int s = 16 * (wave + 4 * gi) + n;
+        const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+        boff2[gi] = orow * C::PM + 2 * pc + q;
+    }
+    f32x4 acc2[C::GW2];
+#pragma unroll
+    for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int cm = 0; cm < kFeat; ++cm)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int gi = 0; gi < C::GW2; ++gi)
+                acc2[gi] = mfma4(a2[cm * 3 + dy], lds[boff2[gi] + cm * C::MPLANE + dy * C::PM], acc2[gi]);
+
+    const float bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
+    const bool vec = (W & 1) == 0;
+#pragma unroll
+    for (int gi = 0; gi < C::GW2; ++gi) {
+        const int s = 16 * (wave + 4 * gi) + n;
+        const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+        const int y = y0 + orow, x = x0 + 2 * pc;
+        const bool ok = y < H && x < W;
+        const float o00 = acc2[gi][0] + bo0, o01 = acc2[gi][1] + bo0;  // channel 2q,   pixels x, x+1
+        const float o10 = acc2[gi][2] + bo1, o11 = acc2[gi][3] + bo1;  // channel 2q+1
+        if (EPI == 0) {
+            if (ok) {
+                float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)y * W + x;
+                if (vec) {
+                    *reinterpret_cast<float2*>(p) = make_float2(o00, o01);
+                    *reinterpret_cast<float2*>(p + out.sc) = make_float2(o10, o11);
+                } else {
+                    p[0] = o00;
+                    p[out.sc] = o10;
+                    if (x + 1 < W) { p[1] = o01; p[out.sc + 1] = o11; }
+                }
+            }
+        } else {
+            // 1x1 out conv 8 -> 2 (architectures.py:57): partial sums over this lane's two channels,
+            // reduced over the four lanes (q = 0..3) that hold the other channels of the same pixels
+            const float w00 = epi.ow[(2 * q) * 2], w01 = epi.ow[(2 * q) * 2 + 1];
+            const float w10 = epi.ow[(2 * q + 1) * 2], w11 = epi.ow[(2 * q + 1) * 2 + 1];
+            float d[4] = {w00 * o00 + w10 * o10, w00 * o01 + w10 * o11,   // re: pixels x, x+1
+                          w01 * o00 + w11 * o10, w01 * o01 + w11 * o11};  // im
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                d[k] += __shfl_xor(d[k], 16, 64);
+                d[k] += __shfl_xor(d[k], 32, 64);
+            }
+            if (q == 0 && ok) {
+                const long plane = (long)H * W;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const long o = ((long)b * 2 + c2) * plane + (long)y * W + x;
+                    const float bias = epi.ob[c2];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        if (x + p < W) {
+                            const float dv = d[c2 * 2 + p] + bias;
+                            if (epi.d_out) epi.d_out[o + p] = dv;
+                            if (epi.wf) epi.wf[o + p] = dv / 1e3f + epi.wf[o + p];  // hybridnet.py:570
+                        }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 8x8 stride-2 down convolution (architectures.py:209-211)
+//   P_h[Yw][X] = sum_ci sum_kx sum_{k<4} w[co][ci][4h + k][kx] * in[ci][2 Yw - 3 + k][2 X - 3 + kx]
+//   out[Y][X]  = b + P_0[Y][X] + P_1[Y + 2][X]
+// Block = WX x WY wavefronts; a wavefront owns 16 output columns and R = 16 / WY output rows and
+// accumulates the R + 2 window rows they need.  The input is staged one channel at a time.
+// ------------------------------------------------------------------------------------------
+template <int WX>
+struct DnCfg {
+    static constexpr int WY = 4 / WX;
+    static constexpr int TH = 16, TW = 16 * WX;       // output tile
+    static constexpr int R = TH / WY;                 // output rows per wavefront
+    static constexpr int NWIN = R + 2;
+    static constexpr int IR = 2 * TH + 6;             // staged rows 2*Y0-3 .. 2*Y0+2*TH+2
+    static constexpr int IC = 2 * TW + 6;
+    static constexpr int PI = IC | 1;                 // odd pitch: the 4 window rows hit distinct banks
+    static constexpr int PLANE = IR * PI;
+    static constexpr int NT = 256;
+    static constexpr int NL = cdiv_(IR * IC, NT);
+};
+
+template <int WX>
+__global__ __launch_bounds__(256) void k_down_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][8][64]*/,
+                                                    const float* __restrict__ bias, int Hin, int Win) {
+    using C = DnCfg<WX>;
+    __shared__ float lds[2 * C::PLANE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int wx = wave % WX, wy = wave / WX;
+    const int b = blockIdx.z;
+    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const int Hout = Hin / 2, Wout = Win / 2;
+
+    int goff[C::NL], loff[C::NL];
+    unsigned okmask = 0, inmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * C::NT;
+        const int ir = e / C::IC, ic = e - ir * C::IC;
+        const int y = 2 * Y0 - 3 + ir, x = 2 * X0 - 3 + ic;
+        const bool ok = (e < C::IR * C::IC) && y >= 0 && y < Hin && x >= 0 && x < Win;
+        goff[i] = ok ? y * Win + x : 0;
+        loff[i] = ir * C::PI + ic;
+        okmask |= (ok ? 1u : 0u) << i;
+        inmask |= ((e < C::IR * C::IC) ? 1u : 0u) << i;
+    }
+    float stage[C::NL], afrag_next[8];
+    auto fetch = [&](int ci) {
+        const float* p0 = in.p + (long)b * in.sb + (long)ci * in.sc;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) stage[i] = p0[goff[i]];
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) afrag_next[kx] = afr[(ci * 8 + kx) * 64 + lane];
+    };
+    // B operand of window row wr, tap kx: staged[(2*(wy*R + wr) + q) * PI + 2*(16*wx + n) + kx]
+    const int bbase = (2 * wy * C::R + q) * C::PI + 2 * (16 * wx + n);
+    f32x4 acc[C::NWIN];
+#pragma unroll
+    for (int i = 0; i < C::NWIN; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+#pragma unroll 1
+    for (int ci = 0; ci < kFeat; ++ci) {
+        float* t = lds + (ci & 1) * C::PLANE;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i)
+            if (inmask >> i & 1u) t[loff[i]] = (okmask >> i & 1u) ? stage[i] : 0.f;
+        float afrag[8];
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) afrag[kx] = afrag_next[kx];
+        __syncthreads();
+        if (ci + 1 < kFeat) fetch(ci + 1);
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx)
+#pragma unroll
+            for (int wr = 0; wr < C::NWIN; ++wr) acc[wr] = mfma4(afrag[kx], t[bbase + 2 * wr * C::PI + kx], acc[wr]);
+    }
+    // D rows of lane (n, q): (co = 2q, h = 0), (2q, 1), (2q+1, 0), (2q+1, 1)
+    const int X = X0 + 16 * wx + n;
+    const float b0 = bias[2 * q], b1 = bias[2 * q + 1];
+    if (X < Wout) {
+#pragma unroll
+        for (int r = 0; r < C::R; ++r) {
+            const int Y = Y0 + wy * C::R + r;
+            if (Y < Hout) {
+                float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)Y * Wout + X;
+                p[0] = acc[r][0] + acc[r + 2][1] + b0;
+                p[out.sc] = acc[r][2] + acc[r + 2][3] + b1;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 8x8 stride-2 transposed convolution (architectures.py:375-382), y = 2 iy - 3 + ky
+// Window row Y (from -1 to Hin-1) produces output rows 2Y + 1 + py, py = 0, 1, from input rows
+// iy = Y - 1 + a (a = 0..3, the K dimension) with ky = 6 + py - 2a.  Along x each output parity
+// px has its own aligned 4-tap window: ix = X - 2 + px + bb, kx = 7 - px - 2 bb (bb = 0..3).
+// Block = WX x WY wavefronts, a wavefront owns 16 input columns X and R window rows.
+// ------------------------------------------------------------------------------------------
+template <int WX, int R_>
+struct UpCfg2 {
+    static constexpr int WY = 4 / WX;
+    static constexpr int R = R_;
+    static constexpr int TH = R * WY, TW = 16 * WX;   // window rows / input columns per block
+    static constexpr int IR = TH + 3;                 // input rows Yb-1 .. Yb+TH+1
+    static constexpr int IC = TW + 4;                 // input cols X0-2 .. X0+TW+1
+    static constexpr int PI = ((IC + 15) / 32) * 32 + 16;  // pitch = 16 (mod 32): rows a, a+1 on disjoint banks
+    static constexpr int PLANE = IR * PI;
+    static constexpr int NT = 256;
+    static constexpr int NL = cdiv_(IR * IC, NT);
+};
+
+template <int WX, int R_>
+__global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][2][4][64]*/,
+                                                  const float* __restrict__ bias, int Hin, int Win) {
+    using C = UpCfg2<WX, R_>;
+    __shared__ float lds[4 * C::PLANE];  // 2 buffers x 2 channels
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int wx = wave % WX, wy = wave / WX;
+    const int b = blockIdx.z;
+    const int X0 = blockIdx.x * C::TW, Yb = blockIdx.y * C::TH - 1;  // first window row of the block
+    const int Hout = 2 * Hin, Wout = 2 * Win;
+
+    int goff[C::NL], loff[C::NL];
+    unsigned okmask = 0, inmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * C::NT;
+        const int ir = e / C::IC, ic = e - ir * C::IC;
+        const int y = Yb - 1 + ir, x = X0 - 2 + ic;
+        const bool ok = (e < C::IR * C::IC) && y >= 0 && y < Hin && x >= 0 && x < Win;
+        goff[i] = ok ? y * Win + x : 0;
+        loff[i] = ir * C::PI + ic;
+        okmask |= (ok ? 1u : 0u) << i;
+        inmask |= ((e < C::IR * C::IC) ? 1u : 0u) << i;
+    }
+    float stage[C::NL][2], afrag_next[16];
+    auto fetch = [&](int g) {
+        const float* p0 = in.p + (long)b * in.sb + (long)(2 * g) * in.sc;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            stage[i][0] = p0[goff[i]];
+            stage[i][1] = p0[in.sc + goff[i]];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) afrag_next[j] = afr[(g * 16 + j) * 64 + lane];
+    };
+    // B operand for window row wr, column offset o (= ix - X + 2, 0..4): staged[(wy*R + wr + q) * PI + 16*wx + n + o]
+    const int bbase = (wy * C::R + q) * C::PI + 16 * wx + n;
+    f32x4 acc[C::R][2];
+#pragma unroll
+    for (int i = 0; i < C::R; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    fetch(0);
+#pragma unroll 1
+    for (int g = 0; g < kFeat / 2; ++g) {
+        float* t = lds + (g & 1) * 2 * C::PLANE;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i)
+            if (inmask >> i & 1u) {
+                const bool ok = okmask >> i & 1u;
+                t[loff[i]] = ok ? stage[i][0] : 0.f;
+                t[C::PLANE + loff[i]] = ok ? stage[i][1] : 0.f;
+            }
+        float afrag[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) afrag[j] = afrag_next[j];
+        __syncthreads();
+        if (g + 1 < kFeat / 2) fetch(g + 1);
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int o = 0; o < 5; ++o)
+#pragma unroll
+                for (int wr = 0; wr < C::R; ++wr) {
+                    const float bv = t[c * C::PLANE + bbase + wr * C::PI + o];
+                    if (o < 4) acc[wr][0] = mfma4(afrag[c * 8 + o], bv, acc[wr][0]);           // px = 0, bb = o
+                    if (o > 0) acc[wr][1] = mfma4(afrag[c * 8 + 4 + (o - 1)], bv, acc[wr][1]);  // px = 1, bb = o - 1
+                }
+    }
+    // D rows of lane (n, q): (co = 2q, py = 0), (2q, 1), (2q+1, 0), (2q+1, 1); acc[.][px]
+    const int X = X0 + 16 * wx + n;
+    const float b0 = bias[2 * q], b1 = bias[2 * q + 1];
+    if (X < Win) {
+#pragma unroll
+        for (int wr = 0; wr < C::R; ++wr) {
+            const int Y = Yb + wy * C::R + wr;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int y = 2 * Y + 1 + py;
+                if (y >= 0 && y < Hout) {
+                    float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)y * Wout + 2 * X;
+                    *reinterpret_cast<float2*>(p) = make_float2(acc[wr][0][py] + b0, acc[wr][1][py] + b0);
+                    *reinterpret_cast<float2*>(p + out.sc) = make_float2(acc[wr][0][2 + py] + b1, acc[wr][1][2 + py] + b1);
+                }
+            }
+        }
+    }
+}
+
+template <int CA, int CB, int CC, int EPI>
+void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
+    if (W > 32) {
+        hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 64, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+    } else if (W > 16) {
+        hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 32, EPI>), dim3(1, cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+    } else {
+        hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 16, EPI>), dim3(1, cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+// host: A-fragment packing
+// ------------------------------------------------------------------------------------------
+// 3x3 conv, weight [8][cin][3][3] -> [cin][3][64]: lane l -> (co = (l&15)>>1, dxo = l&1, t = l>>4),
+// value = w[co][ci][dy][t - dxo] if 0 <= t - dxo <= 2 else 0.
+void pack_frag_3x3(const float* w, int cin, float* dst) {
+    for (int ci = 0; ci < cin; ++ci)
+        for (int dy = 0; dy < 3; ++dy)
+            for (int l = 0; l < 64; ++l) {
+                const int co = (l & 15) >> 1, dxo = l & 1, t = l >> 4, dx = t - dxo;
+                dst[(ci * 3 + dy) * 64 + l] = (dx >= 0 && dx <= 2) ? w[((co * cin + ci) * 3 + dy) * 3 + dx] : 0.f;
+            }
+}
+// down conv, weight [8][8][8][8] (co, ci, ky, kx) -> [ci][kx][64]: lane -> (co, h = l&1, k = l>>4): w[co][ci][4h+k][kx]
+void pack_frag_down(const float* w, float* dst) {
+    for (int ci = 0; ci < kFeat; ++ci)
+        for (int kx = 0; kx < 8; ++kx)
+            for (int l = 0; l < 64; ++l) {
+                const int co = (l & 15) >> 1, h = l & 1, k = l >> 4;
+                dst[(ci * 8 + kx) * 64 + l] = w[((co * kFeat + ci) * 8 + 4 * h + k) * 8 + kx];
+            }
+}
+// transposed conv, weight [8][8][8][8] (ci, co, ky, kx) -> [ci][px][bb][64]:
+// lane -> (co, py = l&1, a = l>>4): w[ci][co][6 + py - 2a][7 - px - 2bb]
+void pack_frag_up(const float* w, float* dst) {
+    for (int ci = 0; ci < kFeat; ++ci)
+        for (int px = 0; px < 2; ++px)
+            for (int bb = 0; bb < 4; ++bb)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = (l & 15) >> 1, py = l & 1, a = l >> 4;
+                    dst[((ci * 2 + px) * 4 + bb) * 64 + l] = w[((ci * kFeat + co) * 8 + (6 + py - 2 * a)) * 8 + (7 - px - 2 * bb)];
+                }
+}
+
+int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
+               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s) {
+    const McW mw{frag1, w.b1, w.slope, frag2, w.b2};
+    const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf};
+    switch (kind) {
+        case 0: launch_dc_mfma<2, 2, 2, 0>(a, b, c, out, mw, e, H, W, batch, s); break;          // inc
+        case 1: launch_dc_mfma<kFeat, kState, 0, 0>(a, b, c, out, mw, e, H, W, batch, s); break;  // conv_signal
+        case 2: launch_dc_mfma<kFeat, 0, 0, 0>(a, b, c, out, mw, e, H, W, batch, s); break;       // bottleneck
+        case 3:
+            if (final_epi) launch_dc_mfma<kFeat, kFeat, 0, 1>(a, b, c, out, mw, e, H, W, batch, s);
+            else launch_dc_mfma<kFeat, kFeat, 0, 0>(a, b, c, out, mw, e, H, W, batch, s);
+            break;
+        default: return fail(ctx, HN_ERR_ARG, "internal: bad DoubleConv kind %d", kind);
+    }
+    return HN_OK;
+}
+
+void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
+    const int Wout = Win / 2, Hout = Hin / 2;
+    if (Wout > 32) hipLaunchKernelGGL((k_down_mfma<4>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    else if (Wout > 16) hipLaunchKernelGGL((k_down_mfma<2>), dim3(1, cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    else hipLaunchKernelGGL((k_down_mfma<1>), dim3(1, cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+}
+
+void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
+    // window rows -1 .. Hin-1
+    if (Win > 16) hipLaunchKernelGGL((k_up_mfma<2, 8>), dim3(cdiv_(Win, 32), cdiv_(Hin + 1, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    else hipLaunchKernelGGL((k_up_mfma<1, 5>), dim3(1, cdiv_(Hin + 1, 20), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+}
+
+}  // namespace hn

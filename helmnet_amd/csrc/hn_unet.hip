@@ -81,16 +81,20 @@ __global__ __launch_bounds__((DcCfg<CA, CB, CC, CM, CO, TW>::NT)) void k_double_
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * C::TH;
 
     // --- per-thread staging positions (identical for every channel pair) ---
-    int goff[C::NL];  // y*W + x, or -1 outside the image / the tile
-    int loff[C::NL];
+    // Loads are issued unconditionally from a clamped address and masked when they are written to
+    // LDS one chunk later, so the whole batch of global loads stays in flight behind the FMAs.
+    int goff[C::NL];       // y*W + x (0 when outside the image / the tile)
+    unsigned okmask = 0;   // bit i: position i lies inside the image
+    unsigned inmask = 0;   // bit i: position i lies inside the staged tile
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) {
         const int e = tid + i * C::NT;
         const int ir = e / C::PI, ic = e - ir * C::PI;
         const int y = y0 - 2 + ir, x = x0 - 2 + ic;
         const bool ok = (e < C::PLANE) && y >= 0 && y < H && x >= 0 && x < W;
-        goff[i] = ok ? y * W + x : -1;
-        loff[i] = (e < C::PLANE) ? e : -1;
+        goff[i] = ok ? y * W + x : 0;
+        okmask |= (ok ? 1u : 0u) << i;
+        inmask |= ((e < C::PLANE) ? 1u : 0u) << i;
     }
     auto chunk_src = [&](int g, const float*& p0, long& cs, float& scale) {
         // channel pair g of the implicit concatenation [A, B, C]
@@ -102,22 +106,24 @@ __global__ __launch_bounds__((DcCfg<CA, CB, CC, CM, CO, TW>::NT)) void k_double_
         p0 = sc.p + (long)b * sc.sb + (long)c * sc.sc; cs = sc.sc; scale = sc.scale;
     };
     float stage[C::NL][2];
+    float stage_scale = 1.f;
     auto fetch = [&](int g) {
-        const float* p0; long cs; float scale;
-        chunk_src(g, p0, cs, scale);
+        const float* p0; long cs;
+        chunk_src(g, p0, cs, stage_scale);
 #pragma unroll
         for (int i = 0; i < C::NL; ++i) {
-            const bool ok = goff[i] >= 0;
-            stage[i][0] = ok ? p0[goff[i]] * scale : 0.f;
-            stage[i][1] = ok ? p0[cs + goff[i]] * scale : 0.f;
+            stage[i][0] = p0[goff[i]];
+            stage[i][1] = p0[cs + goff[i]];
         }
     };
     auto commit = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < C::NL; ++i)
-            if (loff[i] >= 0) {
-                s_in[buf * 2 * C::PLANE + loff[i]] = stage[i][0];
-                s_in[buf * 2 * C::PLANE + C::PLANE + loff[i]] = stage[i][1];
+            if (inmask >> i & 1u) {
+                const bool ok = okmask >> i & 1u;
+                const int l = tid + i * C::NT;
+                s_in[buf * 2 * C::PLANE + l] = ok ? stage[i][0] * stage_scale : 0.f;
+                s_in[buf * 2 * C::PLANE + C::PLANE + l] = ok ? stage[i][1] * stage_scale : 0.f;
             }
     };
 
@@ -253,24 +259,25 @@ __global__ __launch_bounds__(DownCfg::NT) void k_down8x8(Src in, Dst out, K8W w,
     const int tid = threadIdx.x, b = blockIdx.z;
     const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
     const int Hout = Hin / 2, Wout = Win / 2;
-    int goff[C::NL], loff[C::NL];
+    int goff[C::NL];
+    unsigned okmask = 0, inmask = 0;
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) {
         const int e = tid + i * C::NT;
         const int ir = e / C::PI, ic = e - ir * C::PI;
         const int y = 2 * Y0 - 3 + ir, x = 2 * X0 - 3 + ic;
         const bool ok = (e < C::PLANE) && y >= 0 && y < Hin && x >= 0 && x < Win;
-        goff[i] = ok ? y * Win + x : -1;
-        loff[i] = (e < C::PLANE) ? e : -1;
+        goff[i] = ok ? y * Win + x : 0;
+        okmask |= (ok ? 1u : 0u) << i;
+        inmask |= ((e < C::PLANE) ? 1u : 0u) << i;
     }
     float stage[C::NL][2];
-    auto fetch = [&](int g) {
+    auto fetch = [&](int g) {  // unconditional loads from clamped addresses; masked at commit
         const float* p0 = in.p + (long)b * in.sb + (long)(2 * g) * in.sc;
 #pragma unroll
         for (int i = 0; i < C::NL; ++i) {
-            const bool ok = goff[i] >= 0;
-            stage[i][0] = ok ? p0[goff[i]] : 0.f;
-            stage[i][1] = ok ? p0[in.sc + goff[i]] : 0.f;
+            stage[i][0] = p0[goff[i]];
+            stage[i][1] = p0[in.sc + goff[i]];
         }
     };
     const int oy = tid >> 4, sx = tid & 15;  // outputs (Y0+oy, X0 + 2*sx + {0,1})
@@ -285,9 +292,10 @@ __global__ __launch_bounds__(DownCfg::NT) void k_down8x8(Src in, Dst out, K8W w,
         const int buf = g & 1;
 #pragma unroll
         for (int i = 0; i < C::NL; ++i)
-            if (loff[i] >= 0) {
-                s_in[buf][loff[i]] = stage[i][0];
-                s_in[buf][C::PLANE + loff[i]] = stage[i][1];
+            if (inmask >> i & 1u) {
+                const bool ok = okmask >> i & 1u;
+                s_in[buf][tid + i * C::NT] = ok ? stage[i][0] : 0.f;
+                s_in[buf][C::PLANE + tid + i * C::NT] = ok ? stage[i][1] : 0.f;
             }
         __syncthreads();
         if (g + 1 < kFeat / 2) fetch(g + 1);
@@ -418,6 +426,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     const long L = ctx->state_len;
     const Src none{nullptr, 0, 0, 1.f};
     const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
+    const bool mfma = !ctx->use_valu;
     auto plane = [&](int d) { const long m = n >> d; return m * m; };
     auto feat = [&](float* p, int d) { return Dst{p, kFeat * plane(d), plane(d)}; };
     auto featsrc = [&](const float* p, int d) { return Src{p, kFeat * plane(d), plane(d), 1.f}; };
@@ -425,7 +434,8 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     // inc: DoubleConv(6 -> 8 -> 8) on [wf, 1e3*res, sigmas]  (architectures.py:442, hybridnet.py:566)
     {
     ProfScope ps(ctx, KID_INC, s);
-    launch_dc<2, 2, 2, kFeat, kFeat, 0>(in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, noepi, n, n, batch, s);
+    if (mfma) launch_dc8(ctx, 0, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, ctx->f_inc[0], ctx->f_inc[1], false, nullptr, nullptr, n, n, batch, s);
+    else launch_dc<2, 2, 2, kFeat, kFeat, 0>(in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, noepi, n, n, batch, s);
     }
     for (int d = 0; d < depth; ++d) {
         const int m = n >> d;
@@ -434,8 +444,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // out = conv_signal(cat[x, state])                               (architectures.py:246-247)
         {
             ProfScope ps(ctx, KID_SIG0 + 3 * d, s);
-            launch_dc<kFeat, kState, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d),
-                                                          ctx->sig[d], noepi, m, m, batch, s);
+            if (mfma) launch_dc8(ctx, 1, featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d), ctx->sig[d], ctx->f_sig[d][0],
+                                 ctx->f_sig[d][1], false, nullptr, nullptr, m, m, batch, s);
+            else launch_dc<kFeat, kState, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d),
+                                                              ctx->sig[d], noepi, m, m, batch, s);
         }
         // state = conv_state(cat[out, state_old])                        (architectures.py:248)
         {
@@ -445,27 +457,34 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         }
         // x = down(out)                                                  (architectures.py:252)
         ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
-        hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
-                           dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
-                           ctx->down[d], m, m);
+        if (mfma) launch_down(featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
+        else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
+                                dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
+                                ctx->down[d], m, m);
     }
     // bottleneck: decode[depth]                                          (architectures.py:453)
     {
         ProfScope ps(ctx, KID_BOTTLENECK, s);
-        launch_dc<kFeat, 0, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth),
-                                                ctx->dec[depth], noepi, n >> depth, n >> depth, batch, s);
+        if (mfma) launch_dc8(ctx, 2, featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth), ctx->dec[depth],
+                             ctx->f_dec[depth][0], ctx->f_dec[depth][1], false, nullptr, nullptr, n >> depth, n >> depth, batch, s);
+        else launch_dc<kFeat, 0, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth),
+                                                     ctx->dec[depth], noepi, n >> depth, n >> depth, batch, s);
     }
     for (int d = depth - 1; d >= 0; --d) {
         const int m = n >> d;
         // x = up[d](x)                                                   (architectures.py:456)
         {
             ProfScope ps(ctx, KID_UP0 + 2 * d, s);
-            hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
-                               featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
+            if (mfma) launch_up(featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->f_up[d], ctx->up[d].b, m / 2, m / 2, batch, s);
+            else hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
+                                    featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
         }
         ProfScope ps(ctx, KID_DEC0 + 2 * d, s);
         // x = decode[d](cat[x, skip_d])                                  (architectures.py:458-460)
-        if (d > 0) {
+        if (mfma) {
+            launch_dc8(ctx, 3, featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none, d > 0 ? feat(ctx->buf_y[d], d) : Dst{nullptr, 0, 0},
+                       ctx->dec[d], ctx->f_dec[d][0], ctx->f_dec[d][1], d == 0, d_out, wf_update, m, m, batch, s);
+        } else if (d > 0) {
             launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none,
                                                         feat(ctx->buf_y[d], d), ctx->dec[d], noepi, m, m, batch, s);
         } else {
