@@ -18,6 +18,8 @@
 //
 // Reference semantics: helmnet/architectures.py:63-84 (DoubleConv), :209-211 (down), :375-382
 // (up), :47-60 (outc), hybridnet.py:564-570 (input concat, wavefield update).
+#include <cstdlib>
+
 #include "hn_internal.h"
 
 namespace hn {
@@ -25,11 +27,37 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build only (-DHN_STAMP): per-phase s_memtime stamps of the persistent DoubleConv,
+// written to a buffer nothing else reads.  Never enabled in the shipped library.
+#ifdef HN_STAMP
+__device__ unsigned long long g_stamps[256 * 4 * 64];
+__device__ int g_stamp_sel = 881;  // CA*100 + CB*10 + EPI of the instance that records
+#define STAMP(slot)                                                                                      \
+    do {                                                                                                 \
+        if (lane == 0 && stamp_i + (slot) < 64 && blockIdx.x < 256 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == 256) {                                                        \
+            unsigned long long t_;                                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+            g_stamps[(blockIdx.x * 4 + wave) * 64 + stamp_i + (slot)] = t_;                              \
+        }                                                                                                \
+    } while (0)
+#else
+#define STAMP(slot) do { } while (0)
+#endif
+
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 constexpr int cmax_(int a, int b) { return a > b ? a : b; }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// Scheduling hint for one pipelined step: N x (1 MFMA, then 1 LDS read issued in its shadow).
+template <int N>
+__device__ __forceinline__ void interleave_mfma_dsread() {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -146,13 +174,24 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
         __syncthreads();
         if (g + 1 < C::NG) fetch(g + 1);
         const float* t = lds + buf * 2 * C::PLANE;
+        // software pipeline: the B operands of step k+1 are read from LDS while the MFMAs of step k
+        // issue; sched_barrier pins that order (hipcc otherwise waits lgkmcnt(0) in front of every MFMA)
+        float bv[2][C::GW1];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int gi = 0; gi < C::GW1; ++gi) bv[0][gi] = t[boff1[gi]];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+        for (int st = 0; st < 6; ++st) {
+            if (st + 1 < 6) {
+                const int c = (st + 1) / 3, dy = (st + 1) % 3;
 #pragma unroll
-                for (int gi = 0; gi < C::GW1; ++gi)
-                    acc1[gi] = mfma4(afrag[c * 3 + dy], t[boff1[gi] + c * C::PLANE + dy * C::PI], acc1[gi]);
+                for (int gi = 0; gi < C::GW1; ++gi) bv[(st + 1) & 1][gi] = t[boff1[gi] + c * C::PLANE + dy * C::PI];
+            }
+#pragma unroll
+            for (int gi = 0; gi < C::GW1; ++gi) acc1[gi] = mfma4(afrag[st], bv[st & 1][gi], acc1[gi]);
+            interleave_mfma_dsread<C::GW1>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // conv2 A fragments: issue the loads now, they land while the mid tensor is written
     float a2[kFeat * 3];
@@ -193,16 +232,54 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
     f32x4 acc2[C::GW2];
 #pragma unroll
     for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        float bv[2][C::GW2];
 #pragma unroll
-    for (int cm = 0; cm < kFeat; ++cm)
+        for (int gi = 0; gi < C::GW2; ++gi) bv[0][gi] = lds[boff2[gi]];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
+        for (int st = 0; st < kFeat * 3; ++st) {
+            if (st + 1 < kFeat * 3) {
+                const int cm = (st + 1) / 3, dy = (st + 1) % 3;
 #pragma unroll
-            for (int gi = 0; gi < C::GW2; ++gi)
-                acc2[gi] = mfma4(a2[cm * 3 + dy], lds[boff2[gi] + cm * C::MPLANE + dy * C::PM], acc2[gi]);
+                for (int gi = 0; gi < C::GW2; ++gi) bv[(st + 1) & 1][gi] = lds[boff2[gi] + cm * C::MPLANE + dy * C::PM];
+            }
+#pragma unroll
+            for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = mfma4(a2[st], bv[st & 1][gi], acc2[gi]);
+            interleave_mfma_dsread<C::GW2>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 
     const float bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
     const bool vec = (W & 1) == 0;
+    // final layer: out-conv fragments A_j[m][k = q] = ow[2q + j][m] (m < 2) and the old wavefield values,
+    // all fetched up front so the epilogue has no dependent global round trips
+    float aoc0 = 0.f, aoc1 = 0.f, ob_re = 0.f, ob_im = 0.f;
+    float wf_old[EPI == 1 ? C::GW2 : 1][2][2];
+    if (EPI == 1) {
+        const int m = lane & 15;
+        if (m < 2) {
+            aoc0 = epi.ow[(2 * q) * 2 + m];
+            aoc1 = epi.ow[(2 * q + 1) * 2 + m];
+        }
+        ob_re = epi.ob[0];
+        ob_im = epi.ob[1];
+        if (epi.wf != nullptr && q == 0) {
+            const long plane = (long)H * W;
+#pragma unroll
+            for (int gi = 0; gi < C::GW2; ++gi) {
+                const int s = 16 * (wave + 4 * gi) + n;
+                const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+                const int y = y0 + orow, x = x0 + 2 * pc;
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        wf_old[gi][c2][p] = (y < H && x + p < W) ? epi.wf[((long)b * 2 + c2) * plane + (long)y * W + x + p] : 0.f;
+            }
+        }
+    }
 #pragma unroll
     for (int gi = 0; gi < C::GW2; ++gi) {
         const int s = 16 * (wave + 4 * gi) + n;
@@ -224,35 +301,301 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
                 }
             }
         } else {
-            // 1x1 out conv 8 -> 2 (architectures.py:57): partial sums over this lane's two channels,
-            // reduced over the four lanes (q = 0..3) that hold the other channels of the same pixels
-            const float w00 = epi.ow[(2 * q) * 2], w01 = epi.ow[(2 * q) * 2 + 1];
-            const float w10 = epi.ow[(2 * q + 1) * 2], w11 = epi.ow[(2 * q + 1) * 2 + 1];
-            float d[4] = {w00 * o00 + w10 * o10, w00 * o01 + w10 * o11,   // re: pixels x, x+1
-                          w01 * o00 + w11 * o10, w01 * o01 + w11 * o11};  // im
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                d[k] += __shfl_xor(d[k], 16, 64);
-                d[k] += __shfl_xor(d[k], 32, 64);
-            }
+            // 1x1 out conv 8 -> 2 (architectures.py:57) on the matrix core: B = this lane's own outputs
+            // (k = q selects the channel pair), rows 0/1 of D land in the q == 0 lanes
+            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 dA = mfma4(aoc1, o10, mfma4(aoc0, o00, z));  // pixel x
+            const f32x4 dB = mfma4(aoc1, o11, mfma4(aoc0, o01, z));  // pixel x + 1
             if (q == 0 && ok) {
                 const long plane = (long)H * W;
+                const long o = (long)b * 2 * plane + (long)y * W + x;
+                const float dv[2][2] = {{dA[0] + ob_re, dB[0] + ob_re}, {dA[1] + ob_im, dB[1] + ob_im}};
 #pragma unroll
-                for (int c2 = 0; c2 < 2; ++c2) {
-                    const long o = ((long)b * 2 + c2) * plane + (long)y * W + x;
-                    const float bias = epi.ob[c2];
+                for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
                         if (x + p < W) {
-                            const float dv = d[c2 * 2 + p] + bias;
-                            if (epi.d_out) epi.d_out[o + p] = dv;
-                            if (epi.wf) epi.wf[o + p] = dv / 1e3f + epi.wf[o + p];  // hybridnet.py:570
+                            if (epi.d_out) epi.d_out[o + c2 * plane + p] = dv[c2][p];
+                            if (epi.wf) epi.wf[o + c2 * plane + p] = dv[c2][p] / 1e3f + wf_old[gi][c2][p];  // hybridnet.py:570
                         }
-                }
             }
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// Persistent full-tile DoubleConv for the big levels (W even, tile 16 x 64, one block per CU).
+// All input channels of a tile (with halo 2) are resident in LDS (up to 87 KB) next to the mid
+// tensor (39 KB), so conv1 runs its cin*3 MFMA steps back to back with no barrier; the NEXT
+// tile's input is already in flight into registers (float2 loads issued before conv1) and is
+// committed to LDS after conv1.  Two barriers per tile; one wavefront per SIMD owns its matrix
+// pipe.  A-operand fragments of both convolutions stay in registers for the whole launch.
+// ------------------------------------------------------------------------------------------
+template <int CA, int CB, int CC>
+struct PcCfg {
+    static constexpr int TH = 16, TW = 64;
+    static constexpr int CIN = CA + CB + CC;
+    static constexpr int IR = TH + 4, PI = TW + 4, PLANE = IR * PI;
+    static constexpr int MR = TH + 2, PM = TW + 4, MPLANE = MR * PM;
+    static constexpr int PPR1 = (TW + 2) / 2, NS1 = MR * PPR1, G1 = cdiv_(NS1, 16), GW1 = cdiv_(G1, 4);
+    static constexpr int PPR2 = TW / 2, GW2 = TH * PPR2 / 16 / 4;
+    static constexpr int NP2 = PLANE / 2;             // float2 positions per channel
+    static constexpr int NL = cdiv_(NP2, 256);        // per thread
+    static constexpr int MID_OFF = CIN * PLANE;
+    static constexpr int AF_OFF = MID_OFF + kFeat * MPLANE;  // A fragments: conv1 [cin*3][64], conv2 [24][64]
+    static constexpr int LDS_FLOATS = AF_OFF + (CIN * 3 + kFeat * 3 + 6) * 64 + 8;  // +6: fragments are read one channel pair ahead
+};
+
+template <int CA, int CB, int CC, int EPI>
+__global__ __launch_bounds__(256, 1) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W,
+                                                       int tiles_x, int tiles_y, int ntiles) {
+    using C = PcCfg<CA, CB, CC>;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+
+    // ---- launch-invariant state: A fragments (kept in LDS so that the channel loops stay rolled and
+    // the kernel's code stays small), operand offsets ----
+    for (int j = tid; j < C::CIN * 3 * 64; j += 256) lds[C::AF_OFF + j] = w.a1[j];
+    for (int j = tid; j < kFeat * 3 * 64; j += 256) lds[C::AF_OFF + C::CIN * 3 * 64 + j] = w.a2[j];
+    int boff1[C::GW1], boff2[C::GW2];
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) {
+        int s = 16 * (wave + 4 * gi) + n;
+        s = s < C::NS1 ? s : C::NS1 - 1;
+        const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+        boff1[gi] = mrow * C::PI + 2 * pc + q;
+    }
+#pragma unroll
+    for (int gi = 0; gi < C::GW2; ++gi) {
+        const int s = 16 * (wave + 4 * gi) + n;
+        const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+        boff2[gi] = C::MID_OFF + orow * C::PM + 2 * pc + q;
+    }
+    const float slope = w.slope[0];
+    const float bm0 = w.b1[2 * q], bm1 = w.b1[2 * q + 1], bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
+    // staged float2 positions of this thread inside a tile (same for every tile)
+    int lrow[C::NL], lcol[C::NL];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * 256;
+        lrow[i] = e / (C::PI / 2);
+        lcol[i] = 2 * (e - lrow[i] * (C::PI / 2));
+    }
+
+    float2 stage[C::CIN][C::NL];
+    unsigned okmask = 0;
+    auto issue = [&](int tile) {  // start the float2 loads of a whole tile (all channels)
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * C::TW, y0 = ty * C::TH;
+        int goff[C::NL];
+        okmask = 0;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            const int y = y0 - 2 + lrow[i], x = x0 - 2 + lcol[i];
+            const bool ok = (tid + i * 256 < C::NP2) && y >= 0 && y < H && x >= 0 && x < W;  // W even: pairs never straddle
+            goff[i] = ok ? y * W + x : 0;
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int c = 0; c < C::CIN; ++c) {
+            const float* p0 = c < CA ? sa.p + (long)b * sa.sb + (long)c * sa.sc
+                            : c < CA + CB ? sb.p + (long)b * sb.sb + (long)(c - CA) * sb.sc
+                                          : sc.p + (long)b * sc.sb + (long)(c - CA - CB) * sc.sc;
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i) stage[c][i] = *reinterpret_cast<const float2*>(p0 + goff[i]);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int c = 0; c < C::CIN; ++c) {
+            const float sc_ = c < CA ? sa.scale : c < CA + CB ? sb.scale : sc.scale;
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i)
+                if (tid + i * 256 < C::NP2) {
+                    const bool ok = okmask >> i & 1u;
+                    *reinterpret_cast<float2*>(&lds[c * C::PLANE + lrow[i] * C::PI + lcol[i]]) =
+                        ok ? make_float2(stage[c][i].x * sc_, stage[c][i].y * sc_) : make_float2(0.f, 0.f);
+                }
+        }
+    };
+
+    // 1x1 out conv (architectures.py:57) as two MFMA A fragments: A_j[m][k = q] = ow[2q + j][c2 = m], m < 2
+    float aoc0 = 0.f, aoc1 = 0.f, ob_lane = 0.f;
+    if (EPI == 1) {
+        const int m = lane & 15;
+        if (m < 2) {
+            aoc0 = epi.ow[(2 * q) * 2 + m];
+            aoc1 = epi.ow[(2 * q + 1) * 2 + m];
+        }
+        ob_lane = epi.ob[0];
+    }
+    const float ob_im = EPI == 1 ? epi.ob[1] : 0.f;
+    int tile = blockIdx.x;
+    int stamp_i = 0;
+    (void)stamp_i;
+    if (tile < ntiles) issue(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+        const int x0 = tx * C::TW, y0 = ty * C::TH;
+        STAMP(0);
+        commit();
+        STAMP(1);
+        __syncthreads();  // (1) input tile visible; every wave is past conv2 of the previous tile
+        STAMP(2);
+        if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
+        STAMP(3);
+
+        // ---- conv1: cin*3 steps, LDS reads of step k+1 behind the MFMAs of step k ----
+        f32x4 acc1[C::GW1];
+#pragma unroll
+        for (int gi = 0; gi < C::GW1; ++gi) acc1[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            // rolled over pairs of input channels, 6 pipelined steps (c, dy) per iteration: the B operands
+            // of step k+1 and the A fragments of the next channel pair are read while step k's MFMAs issue
+            float bv[2][C::GW1], af[6], afn[6];
+#pragma unroll
+            for (int gi = 0; gi < C::GW1; ++gi) bv[0][gi] = lds[boff1[gi]];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) af[j] = lds[C::AF_OFF + j * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+            for (int c2 = 0; c2 < C::CIN / 2; ++c2) {
+                const float* tc = lds + 2 * c2 * C::PLANE;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    // next step; past the last channel this reads the mid region (value unused)
+                    const int nx = st + 1, nxt = (nx / 3) * C::PLANE + (nx % 3) * C::PI;
+#pragma unroll
+                    for (int gi = 0; gi < C::GW1; ++gi) bv[(st + 1) & 1][gi] = tc[boff1[gi] + nxt];
+                    afn[st] = lds[C::AF_OFF + ((c2 + 1) * 6 + st) * 64 + lane];
+#pragma unroll
+                    for (int gi = 0; gi < C::GW1; ++gi) acc1[gi] = mfma4(af[st], bv[st & 1][gi], acc1[gi]);
+                    interleave_mfma_dsread<C::GW1>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) af[j] = afn[j];
+            }
+        }
+        STAMP(4);
+        // ---- mid tensor: bias, PReLU, zero outside the image ----
+#pragma unroll
+        for (int gi = 0; gi < C::GW1; ++gi) {
+            const int s = 16 * (wave + 4 * gi) + n;
+            if (s < C::NS1) {
+                const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+                const int y = y0 - 1 + mrow, x = x0 - 1 + 2 * pc;
+                const bool yin = y >= 0 && y < H;
+                const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
+                float v[4] = {acc1[gi][0] + bm0, acc1[gi][1] + bm0, acc1[gi][2] + bm1, acc1[gi][3] + bm1};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : slope * v[r];
+                float* m0 = lds + C::MID_OFF + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
+                *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
+                *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
+            }
+        }
+        STAMP(5);
+        __syncthreads();  // (2) mid complete; the input region may be overwritten by the next commit
+        STAMP(6);
+
+        // ---- conv2 ----
+        f32x4 acc2[C::GW2];
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // final layer: fetch the wavefield values this lane will update now, so that the
+        // read-modify-write below does not expose one global round trip per group
+        float2 wf_old[EPI == 1 ? C::GW2 : 1][2];
+        if (EPI == 1 && epi.wf != nullptr && q == 0) {
+            const long plane = (long)H * W;
+#pragma unroll
+            for (int gi = 0; gi < C::GW2; ++gi) {
+                const int s = 16 * (wave + 4 * gi) + n;
+                const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+                const int y = y0 + orow, x = x0 + 2 * pc;
+                const long o = (long)b * 2 * plane + (long)(y < H ? y : 0) * W + (x < W ? x : 0);
+                wf_old[gi][0] = *reinterpret_cast<const float2*>(epi.wf + o);
+                wf_old[gi][1] = *reinterpret_cast<const float2*>(epi.wf + o + plane);
+            }
+        }
+        {
+            float bv[2][C::GW2], af[6], afn[6];
+#pragma unroll
+            for (int gi = 0; gi < C::GW2; ++gi) bv[0][gi] = lds[boff2[gi]];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) af[j] = lds[C::AF_OFF + (C::CIN * 3 + j) * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+            for (int c2 = 0; c2 < kFeat / 2; ++c2) {
+                const float* tc = lds + 2 * c2 * C::MPLANE;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    const int nx = st + 1, nxt = (nx / 3) * C::MPLANE + (nx % 3) * C::PM;  // past the end: fragment region (unused)
+#pragma unroll
+                    for (int gi = 0; gi < C::GW2; ++gi) bv[(st + 1) & 1][gi] = tc[boff2[gi] + nxt];
+                    afn[st] = lds[C::AF_OFF + (C::CIN * 3 + (c2 + 1) * 6 + st) * 64 + lane];
+#pragma unroll
+                    for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = mfma4(af[st], bv[st & 1][gi], acc2[gi]);
+                    interleave_mfma_dsread<C::GW2>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) af[j] = afn[j];
+            }
+        }
+        STAMP(7);
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) {
+            const int s = 16 * (wave + 4 * gi) + n;
+            const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+            const int y = y0 + orow, x = x0 + 2 * pc;
+            const bool ok = y < H && x < W;
+            const float o00 = acc2[gi][0] + bo0, o01 = acc2[gi][1] + bo0;
+            const float o10 = acc2[gi][2] + bo1, o11 = acc2[gi][3] + bo1;
+            if (EPI == 0) {
+                if (ok) {
+                    float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)y * W + x;
+                    *reinterpret_cast<float2*>(p) = make_float2(o00, o01);
+                    *reinterpret_cast<float2*>(p + out.sc) = make_float2(o10, o11);
+                }
+            } else {
+                // d[c2][pixel] = sum_co ow[co][c2] * o[co][pixel] on the matrix core: B = this lane's own
+                // outputs (k = q selects the channel pair), rows 0/1 of D land in the q == 0 lanes
+                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+                const f32x4 dA = mfma4(aoc1, o10, mfma4(aoc0, o00, z));  // pixel x
+                const f32x4 dB = mfma4(aoc1, o11, mfma4(aoc0, o01, z));  // pixel x + 1
+                if (q == 0 && ok) {
+                    const long plane = (long)H * W;
+                    const long o = (long)b * 2 * plane + (long)y * W + x;
+                    const float re0 = dA[0] + ob_lane, re1 = dB[0] + ob_lane, im0 = dA[1] + ob_im, im1 = dB[1] + ob_im;
+                    if (epi.d_out) {
+                        *reinterpret_cast<float2*>(epi.d_out + o) = make_float2(re0, re1);
+                        *reinterpret_cast<float2*>(epi.d_out + o + plane) = make_float2(im0, im1);
+                    }
+                    if (epi.wf) {  // wf <- d / 1e3 + wf (hybridnet.py:570)
+                        const float2 o0 = wf_old[EPI == 1 ? gi : 0][0], o1 = wf_old[EPI == 1 ? gi : 0][1];
+                        *reinterpret_cast<float2*>(epi.wf + o) = make_float2(re0 / 1e3f + o0.x, re1 / 1e3f + o0.y);
+                        *reinterpret_cast<float2*>(epi.wf + o + plane) = make_float2(im0 / 1e3f + o1.x, im1 / 1e3f + o1.y);
+                    }
+                }
+            }
+        }
+        STAMP(8);
+#ifdef HN_STAMP
+        stamp_i += 9;
+#endif
+    }
+}
+
+#ifdef HN_STAMP
+}  // namespace
+extern "C" int hn_debug_set_stamp_sel(int sel) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &sel, sizeof(int)); }
+extern "C" int hn_debug_read_stamps(unsigned long long* host, int count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * count);
+}
+namespace {
+#endif
 
 // ------------------------------------------------------------------------------------------
 // 8x8 stride-2 down convolution (architectures.py:209-211)
@@ -326,10 +669,21 @@ __global__ __launch_bounds__(256) void k_down_mfma(Src in, Dst out, const float*
         for (int kx = 0; kx < 8; ++kx) afrag[kx] = afrag_next[kx];
         __syncthreads();
         if (ci + 1 < kFeat) fetch(ci + 1);
+        float bv[2][C::NWIN];
 #pragma unroll
-        for (int kx = 0; kx < 8; ++kx)
+        for (int wr = 0; wr < C::NWIN; ++wr) bv[0][wr] = t[bbase + 2 * wr * C::PI];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int wr = 0; wr < C::NWIN; ++wr) acc[wr] = mfma4(afrag[kx], t[bbase + 2 * wr * C::PI + kx], acc[wr]);
+        for (int kx = 0; kx < 8; ++kx) {
+            if (kx + 1 < 8) {
+#pragma unroll
+                for (int wr = 0; wr < C::NWIN; ++wr) bv[(kx + 1) & 1][wr] = t[bbase + 2 * wr * C::PI + kx + 1];
+            }
+#pragma unroll
+            for (int wr = 0; wr < C::NWIN; ++wr) acc[wr] = mfma4(afrag[kx], bv[kx & 1][wr], acc[wr]);
+            interleave_mfma_dsread<C::NWIN>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // D rows of lane (n, q): (co = 2q, h = 0), (2q, 1), (2q+1, 0), (2q+1, 1)
     const int X = X0 + 16 * wx + n;
@@ -425,16 +779,26 @@ __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* _
         for (int j = 0; j < 16; ++j) afrag[j] = afrag_next[j];
         __syncthreads();
         if (g + 1 < kFeat / 2) fetch(g + 1);
+        float bv[2][C::R];
 #pragma unroll
-        for (int c = 0; c < 2; ++c)
+        for (int wr = 0; wr < C::R; ++wr) bv[0][wr] = t[bbase + wr * C::PI];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int o = 0; o < 5; ++o)
+        for (int st = 0; st < 10; ++st) {
+            const int c = st / 5, o = st % 5;
+            if (st + 1 < 10) {
+                const int c1 = (st + 1) / 5, o1 = (st + 1) % 5;
 #pragma unroll
-                for (int wr = 0; wr < C::R; ++wr) {
-                    const float bv = t[c * C::PLANE + bbase + wr * C::PI + o];
-                    if (o < 4) acc[wr][0] = mfma4(afrag[c * 8 + o], bv, acc[wr][0]);           // px = 0, bb = o
-                    if (o > 0) acc[wr][1] = mfma4(afrag[c * 8 + 4 + (o - 1)], bv, acc[wr][1]);  // px = 1, bb = o - 1
-                }
+                for (int wr = 0; wr < C::R; ++wr) bv[(st + 1) & 1][wr] = t[c1 * C::PLANE + bbase + wr * C::PI + o1];
+            }
+#pragma unroll
+            for (int wr = 0; wr < C::R; ++wr) {
+                if (o < 4) acc[wr][0] = mfma4(afrag[c * 8 + o], bv[st & 1][wr], acc[wr][0]);           // px = 0, bb = o
+                if (o > 0) acc[wr][1] = mfma4(afrag[c * 8 + 4 + (o - 1)], bv[st & 1][wr], acc[wr][1]);  // px = 1, bb = o - 1
+            }
+            interleave_mfma_dsread<C::R>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     // D rows of lane (n, q): (co = 2q, py = 0), (2q, 1), (2q+1, 0), (2q+1, 1); acc[.][px]
     const int X = X0 + 16 * wx + n;
@@ -458,7 +822,14 @@ __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* _
 
 template <int CA, int CB, int CC, int EPI>
 void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
-    if (W > 32) {
+    static const bool chunked_only = getenv("HN_DC_CHUNKED") != nullptr;
+    if (W >= 64 && (W & 1) == 0 && !chunked_only) {
+        using C = PcCfg<CA, CB, CC>;
+        const int tx = cdiv_(W, 64), ty = cdiv_(H, 16), nt = tx * ty * batch;
+        const int per_cu = (160 * 1024) / (int)(C::LDS_FLOATS * sizeof(float));
+        const int grid = nt < 256 * per_cu ? nt : 256 * per_cu;
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI>), dim3(grid), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+    } else if (W > 32) {
         hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 64, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
     } else if (W > 16) {
         hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 32, EPI>), dim3(1, cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);

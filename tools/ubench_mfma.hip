@@ -1,0 +1,75 @@
+// Micro-benchmark: fp32 MFMA 16x16x4 fed by one ds_read_b32 per MFMA (the conv inner loop shape).
+// Variants: G accumulator groups per step; PIPE 0 = [reads][MFMAs] phases, 1 = MFMA/read interleaved
+// (sched_group_barrier), 2 = registers only.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int G, int PIPE>
+__global__ __launch_bounds__(256) void k(const float* __restrict__ in, float* __restrict__ out, int steps, int big) {
+    __shared__ float lds[32768];
+    for (int i = threadIdx.x; i < 32768; i += 256) lds[i] = in[i & 1023];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, n = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    int boff[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) boff[g] = big + ((wave * G + g) >> 1) * 68 + 32 * (g & 1) + 2 * n + q;
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = (f32x4){0, 0, 0, 0};
+    const float a = in[lane];
+    float bv[2][G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bv[0][g] = lds[boff[g]];
+    __builtin_amdgcn_sched_barrier(0);
+    for (int st = 0; st < steps; st += 24) {
+#pragma unroll
+        for (int h = 0; h < 24; ++h) {
+            if (PIPE != 2) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) bv[(h + 1) & 1][g] = lds[boff[g] + ((h + 1) % 24) * 204];
+            }
+            if (PIPE == 0) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bv[PIPE == 2 ? 0 : (h & 1)][g], acc[g], 0, 0, 0);
+            if (PIPE == 1) {
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float s = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) s += acc[g][0] + acc[g][1] + acc[g][2] + acc[g][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int G, int PIPE>
+void run(const char* name, const float* in, float* out, int big) {
+    hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    const int steps = 2400;
+    float ms = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        (void)hipEventRecord(a);
+        hipLaunchKernelGGL((k<G, PIPE>), dim3(256), dim3(256), 0, 0, in, out, steps, big);
+        (void)hipEventRecord(b); (void)hipEventSynchronize(b);
+        (void)hipEventElapsedTime(&ms, a, b);
+    }
+    printf("%-34s G=%2d big=%5d: %.3f ms  %.1f cycles/MFMA/SIMD at 2.4 GHz\n", name, G, big, ms, ms * 1e-3 * 2.4e9 / ((double)G * steps));
+}
+int main() {
+    float *in, *out;
+    (void)hipMalloc(&in, 4096); (void)hipMalloc(&out, 256 * 4096 * 4);
+    (void)hipMemset(in, 0, 4096);
+    run<10, 0>("phases", in, out, 0);
+    run<10, 1>("interleaved", in, out, 0);
+    run<8, 0>("phases", in, out, 0);
+    run<8, 1>("interleaved", in, out, 0);
+    run<8, 1>("interleaved, base beyond 64KB imm", in, out, 17000);
+    run<4, 1>("interleaved", in, out, 0);
+    run<16, 1>("interleaved", in, out, 0);
+    run<10, 2>("registers only", in, out, 0);
+    return 0;
+}
