@@ -159,6 +159,12 @@ void hn_destroy(hn_ctx* ctx) {
     spec_free(ctx->tab);
     (void)hipFree(ctx->wdev);
     (void)hipFree(ctx->fragdev);
+    for (int j = 0; j < ctx->n_streams; ++j) {
+        (void)hipStreamDestroy(ctx->sub_stream[j]);
+        (void)hipEventDestroy(ctx->ev_join[j]);
+        (void)hipEventDestroy(ctx->ev_stagger[j]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -366,22 +372,63 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const long plane = (long)ctx->tab.n * ctx->tab.n;
-    const size_t field_bytes = sizeof(float) * (size_t)batch * 2 * plane;
-    const size_t state_bytes = sizeof(float) * (size_t)batch * kState * ctx->state_len;
-    const Src s_wf{wf, 2 * plane, plane, 1.f};
-    const Src s_res{res, 2 * plane, plane, 1e3f};               // 1e3 * residual (hybridnet.py:566)
-    const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};            // sigmas.repeat(B) without the copy
+    const long L = ctx->state_len;
     if (rmse_hist && n_iter > 0) HN_HIP(ctx, hipMemsetAsync(rmse_hist, 0, sizeof(float) * (size_t)n_iter * batch, s));
-    for (int it = 0; it < n_iter; ++it) {
-        float* st_in = (it & 1) ? ctx->st_tmp : states;
-        float* st_out = (it & 1) ? states : ctx->st_tmp;
-        if ((rc = unet_forward(ctx, s_wf, s_res, s_sig, st_in, st_out, nullptr, wf, batch, s)) != HN_OK) return rc;
-        if ((rc = spec_apply(ctx, wf, res, k_sq, src, src_batch, batch, rmse_hist ? rmse_hist + (size_t)it * batch : nullptr, s)) != HN_OK) return rc;
-        if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + (size_t)it * batch * 2 * plane, res, field_bytes, hipMemcpyDeviceToDevice, s));
-        if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf_hist + (size_t)it * batch * 2 * plane, wf, field_bytes, hipMemcpyDeviceToDevice, s));
-        if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + (size_t)it * batch * kState * ctx->state_len, st_out, state_bytes, hipMemcpyDeviceToDevice, s));
+    // ---- sub-batch pipelining over internal streams ----
+    if (ctx->n_streams == 0) {
+        const char* e = getenv("HN_STREAMS");
+        int ns = e ? atoi(e) : 1;  // 2-3 streams measured +0..3 %: kernels of both sub-batches fill the chip, overlap is zero-sum
+        ns = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
+        for (int j = 0; j < ns; ++j) {
+            HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));
+            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming));
+            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[j], hipEventDisableTiming));
+        }
+        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+        ctx->n_streams = ns;
     }
-    if (n_iter & 1) HN_HIP(ctx, hipMemcpyAsync(states, ctx->st_tmp, state_bytes, hipMemcpyDeviceToDevice, s));
+    int ns = ctx->n_streams;
+    if (batch < 2 * ns) ns = 1;                       // tiny batches: not worth splitting
+    if (n_iter == 0) ns = 1;
+    if (ns > 1) HN_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+    int lo[9];
+    for (int j = 0; j <= ns; ++j) lo[j] = (int)((long)batch * j / ns);
+    for (int it = 0; it < n_iter; ++it) {
+        for (int j = 0; j < ns; ++j) {
+            hipStream_t sj = ns > 1 ? ctx->sub_stream[j] : s;
+            const int b0 = lo[j], nb = lo[j + 1] - lo[j];
+            if (ns > 1 && it == 0) {
+                HN_HIP(ctx, hipStreamWaitEvent(sj, ctx->ev_fork, 0));
+                // stagger: sub-batch j starts once sub-batch j-1 is past its first level-0 encoder kernels
+                if (j > 0) HN_HIP(ctx, hipStreamWaitEvent(sj, ctx->ev_stagger[j - 1], 0));
+            }
+            float* wf_j = wf + (size_t)b0 * 2 * plane;
+            float* res_j = res + (size_t)b0 * 2 * plane;
+            float* st_user = states + (size_t)b0 * kState * L;
+            float* st_tmp = ctx->st_tmp + (size_t)b0 * kState * L;
+            float* st_in = (it & 1) ? st_tmp : st_user;
+            float* st_out = (it & 1) ? st_user : st_tmp;
+            const Src s_wf{wf_j, 2 * plane, plane, 1.f};
+            const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
+            const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
+            hipEvent_t stg = (ns > 1 && it == 0 && j + 1 < ns) ? ctx->ev_stagger[j] : nullptr;
+            if ((rc = unet_forward(ctx, s_wf, s_res, s_sig, st_in, st_out, nullptr, wf_j, nb, sj, b0, stg)) != HN_OK) return rc;
+            const float* src_j = src_batch == 1 ? src : src + (size_t)b0 * 2 * plane;
+            if ((rc = spec_apply(ctx, wf_j, res_j, k_sq + (size_t)b0 * plane, src_j, src_batch == 1 ? 1 : nb, nb,
+                                 rmse_hist ? rmse_hist + (size_t)it * batch + b0 : nullptr, sj)) != HN_OK) return rc;
+            const size_t fb = sizeof(float) * (size_t)nb * 2 * plane, sb = sizeof(float) * (size_t)nb * kState * L;
+            if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + ((size_t)it * batch + b0) * 2 * plane, res_j, fb, hipMemcpyDeviceToDevice, sj));
+            if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf_hist + ((size_t)it * batch + b0) * 2 * plane, wf_j, fb, hipMemcpyDeviceToDevice, sj));
+            if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + ((size_t)it * batch + b0) * kState * L, st_out, sb, hipMemcpyDeviceToDevice, sj));
+            if (it == n_iter - 1) {
+                if (n_iter & 1) HN_HIP(ctx, hipMemcpyAsync(st_user, st_tmp, sb, hipMemcpyDeviceToDevice, sj));
+                if (ns > 1) {
+                    HN_HIP(ctx, hipEventRecord(ctx->ev_join[j], sj));
+                    HN_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join[j], 0));
+                }
+            }
+        }
+    }
     if (rmse_hist && n_iter > 0) {
         const int count = n_iter * batch;
         hipLaunchKernelGGL(k_rmse_finalize, dim3((count + 255) / 256), dim3(256), 0, s, rmse_hist, count, 1.0f / (float)(2 * plane));

@@ -87,6 +87,11 @@ struct hn_ctx {
     float* buf_o[hn::kMaxDepth]{};      // out_d (skip connections)
     float* buf_y[hn::kMaxDepth + 1]{};  // decoder outputs y_d
     float* st_tmp = nullptr;            // second flat state buffer for hn_step ping-pong
+    // hn_step pipelines sub-batches on internal streams (samples are independent): while one
+    // sub-batch walks the small, latency-bound UNet levels the other one keeps the CUs busy
+    int n_streams = 0;
+    hipStream_t sub_stream[8]{};
+    hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};
     // optional per-kernel timing with HIP events on the caller's stream (hn_profile_*)
     uint64_t prof_mask = 0;
     struct ProfRec { int id; hipEvent_t a, b; };
@@ -153,6 +158,6 @@ void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, i
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the
 // wavefield is updated in place (wf += d / 1e3) by the last kernel; if d_out != nullptr d is stored.
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
-                 float* d_out, float* wf_update, int batch, hipStream_t s);
+                 float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off = 0, hipEvent_t after_down0 = nullptr);
 
 }  // namespace hn

@@ -67,7 +67,8 @@ template <int CA, int CB, int CC, int TW>
 struct McCfg {
     static constexpr int TH = 16;
     static constexpr int CIN = CA + CB + CC;
-    static constexpr int NG = CIN / 2;             // input is staged two channels at a time
+    static constexpr int CK = 2;                   // input channels staged per chunk (4 measured slower: registers cut occupancy)
+    static constexpr int NG = cdiv_(CIN, CK);
     static constexpr int IR = TH + 4, PI = TW + 4; // staged input tile (halo 2)
     static constexpr int PLANE = IR * PI;
     static constexpr int MR = TH + 2;              // mid rows (halo 1)
@@ -82,7 +83,7 @@ struct McCfg {
     static constexpr int GW2 = G2 / 4;
     static constexpr int NT = 256;
     static constexpr int NL = cdiv_(PLANE, NT);    // staged positions per thread (x 2 channels)
-    static constexpr int LDS_FLOATS = cmax_(4 * PLANE, kFeat * MPLANE) + 8;
+    static constexpr int LDS_FLOATS = cmax_(2 * CK * PLANE, kFeat * MPLANE) + 8;
 };
 
 struct McW {
@@ -124,30 +125,32 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
         okmask |= (ok ? 1u : 0u) << i;
         inmask |= ((e < C::PLANE) ? 1u : 0u) << i;
     }
-    float stage[C::NL][2], stage_scale = 1.f, afrag_next[6];
-    auto fetch = [&](int g) {
-        const float* p0; long cs;
-        int c = 2 * g;
-        if (c < CA) { p0 = sa.p + (long)b * sa.sb + (long)c * sa.sc; cs = sa.sc; stage_scale = sa.scale; }
-        else if (CB > 0 && c - CA < CB) { c -= CA; p0 = sb.p + (long)b * sb.sb + (long)c * sb.sc; cs = sb.sc; stage_scale = sb.scale; }
-        else { c -= CA + CB; p0 = sc.p + (long)b * sc.sb + (long)c * sc.sc; cs = sc.sc; stage_scale = sc.scale; }
+    float stage[C::CK][C::NL], stage_scale[C::CK], afrag_next[C::CK * 3];
+    auto fetch = [&](int g) {  // channels g*CK .. g*CK+CK-1 of the implicit concatenation [A, B, C]
 #pragma unroll
-        for (int i = 0; i < C::NL; ++i) {
-            stage[i][0] = p0[goff[i]];
-            stage[i][1] = p0[cs + goff[i]];
+        for (int j = 0; j < C::CK; ++j) {
+            const int c = g * C::CK + j;
+            const float* p0;
+            if (c < CA) { p0 = sa.p + (long)b * sa.sb + (long)c * sa.sc; stage_scale[j] = sa.scale; }
+            else if (c < CA + CB) { p0 = sb.p + (long)b * sb.sb + (long)(c - CA) * sb.sc; stage_scale[j] = sb.scale; }
+            else if (c < C::CIN) { p0 = sc.p + (long)b * sc.sb + (long)(c - CA - CB) * sc.sc; stage_scale[j] = sc.scale; }
+            else { p0 = sa.p + (long)b * sa.sb; stage_scale[j] = 0.f; }  // past the last channel: staged as zeros
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i) stage[j][i] = p0[goff[i]];
+            const int cf = c < C::CIN ? c : C::CIN - 1;
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) afrag_next[j * 3 + dy] = w.a1[(cf * 3 + dy) * 64 + lane];
         }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) afrag_next[j] = w.a1[(g * 6 + j) * 64 + lane];
     };
     auto commit = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < C::NL; ++i)
-            if (inmask >> i & 1u) {
-                const bool ok = okmask >> i & 1u;
-                const int l = buf * 2 * C::PLANE + tid + i * C::NT;
-                lds[l] = ok ? stage[i][0] * stage_scale : 0.f;
-                lds[l + C::PLANE] = ok ? stage[i][1] * stage_scale : 0.f;
-            }
+        for (int j = 0; j < C::CK; ++j)
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i)
+                if (inmask >> i & 1u) {
+                    const bool ok = okmask >> i & 1u;
+                    lds[(buf * C::CK + j) * C::PLANE + tid + i * C::NT] = ok ? stage[j][i] * stage_scale[j] : 0.f;
+                }
     };
 
     // ---- conv1: every lane owns slot (16*g + n) of each of its groups g = wave + 4*gi ----
@@ -168,21 +171,22 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
     for (int g = 0; g < C::NG; ++g) {
         const int buf = g & 1;
         commit(buf);
-        float afrag[6];
+        float afrag[C::CK * 3];
 #pragma unroll
-        for (int j = 0; j < 6; ++j) afrag[j] = afrag_next[j];
+        for (int j = 0; j < C::CK * 3; ++j) afrag[j] = afrag_next[j];
         __syncthreads();
         if (g + 1 < C::NG) fetch(g + 1);
-        const float* t = lds + buf * 2 * C::PLANE;
+        const float* t = lds + buf * C::CK * C::PLANE;
         // software pipeline: the B operands of step k+1 are read from LDS while the MFMAs of step k
-        // issue; sched_barrier pins that order (hipcc otherwise waits lgkmcnt(0) in front of every MFMA)
+        // issue (hipcc otherwise waits lgkmcnt(0) in front of every MFMA).  A short last chunk
+        // (cin not a multiple of CK) was staged as zeros, its steps add nothing.
         float bv[2][C::GW1];
 #pragma unroll
         for (int gi = 0; gi < C::GW1; ++gi) bv[0][gi] = t[boff1[gi]];
-    __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int st = 0; st < 6; ++st) {
-            if (st + 1 < 6) {
+        for (int st = 0; st < C::CK * 3; ++st) {
+            if (st + 1 < C::CK * 3) {
                 const int c = (st + 1) / 3, dy = (st + 1) % 3;
 #pragma unroll
                 for (int gi = 0; gi < C::GW1; ++gi) bv[(st + 1) & 1][gi] = t[boff1[gi] + c * C::PLANE + dy * C::PI];
@@ -822,8 +826,10 @@ __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* _
 
 template <int CA, int CB, int CC, int EPI>
 void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
-    static const bool chunked_only = getenv("HN_DC_CHUNKED") != nullptr;
-    if (W >= 64 && (W & 1) == 0 && !chunked_only) {
+    // the persistent full-tile variant measured slower than the chunked one (1 wave per SIMD leaves
+    // staging / epilogue phases uncovered); kept opt-in for experiments
+    static const bool persistent = getenv("HN_DC_PERSISTENT") != nullptr;
+    if (W >= 64 && (W & 1) == 0 && persistent) {
         using C = PcCfg<CA, CB, CC>;
         const int tx = cdiv_(W, 64), ty = cdiv_(H, 16), nt = tx * ty * batch;
         const int per_cu = (160 * 1024) / (int)(C::LDS_FLOATS * sizeof(float));

@@ -421,15 +421,16 @@ __global__ __launch_bounds__(UpCfg::NT) void k_up8x8(Src in, Dst out, K8W w, int
 }  // namespace
 
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
-                 float* d_out, float* wf_update, int batch, hipStream_t s) {
+                 float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off, hipEvent_t after_down0) {
     const int n = ctx->tab.n, depth = ctx->depth;
     const long L = ctx->state_len;
     const Src none{nullptr, 0, 0, 1.f};
     const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
     const bool mfma = !ctx->use_valu;
     auto plane = [&](int d) { const long m = n >> d; return m * m; };
-    auto feat = [&](float* p, int d) { return Dst{p, kFeat * plane(d), plane(d)}; };
-    auto featsrc = [&](const float* p, int d) { return Src{p, kFeat * plane(d), plane(d), 1.f}; };
+    // ws_off: first sample slot of the workspace this call may use (sub-batches on parallel streams)
+    auto feat = [&](float* p, int d) { return Dst{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d)}; };
+    auto featsrc = [&](const float* p, int d) { return Src{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d), 1.f}; };
 
     // inc: DoubleConv(6 -> 8 -> 8) on [wf, 1e3*res, sigmas]  (architectures.py:442, hybridnet.py:566)
     {
@@ -461,6 +462,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
                                 dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                                 ctx->down[d], m, m);
+        if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
     }
     // bottleneck: decode[depth]                                          (architectures.py:453)
     {
