@@ -45,6 +45,26 @@ def kernel_macs(n: int, depth: int = 4) -> dict:
     return m
 
 
+# rocprofv3 kernel names of the kernels that are launched once per step (the per-level kernels share
+# one name across levels); used to look the dominant kernel's measured HBM traffic up in
+# profiles/*_traffic.json (FETCH_SIZE + WRITE_SIZE of the same command, tools/summarize_profiles.py)
+ROCPROF_NAME = {"decode0": "k_dc_mfma<8, 8, 0, 64, 1>", "inc": "k_dc_mfma<2, 2, 2, 64, 0>",
+                "spectral_rows": "k_spec_rows<256>", "spectral_cols": "k_spec_cols<256, 16>"}
+
+
+def measured_traffic(kernel: str, n: int, batch: int):
+    """HBM bytes per launch from the committed PMC summary (valid for the default 256^2 x 32 workload only)."""
+    if n != 256 or batch != 32 or kernel not in ROCPROF_NAME:
+        return None, None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        with open(path) as f:
+            t = json.load(f)
+        if ROCPROF_NAME[kernel] in t:
+            return t[ROCPROF_NAME[kernel]]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+    return None, None
+
+
 def spectral_bytes(n: int) -> int:
     """Compulsory HBM bytes per sample of the residual: read wf(2)+k_sq(1), write res(2) planes."""
     return 5 * 4 * n * n
@@ -157,19 +177,22 @@ def main():
         total_flops = 2.0 * sum(macs.values()) * B
         dom_flops = 2.0 * macs[dominant] * B if dominant in macs else 0.0
         roof = None
+        traffic, traffic_src = measured_traffic(dominant, n, B)
         if dom_cnt:
             avg_s = dom_ms / dom_cnt * 1e-3
             if dominant in macs:
                 ach = dom_flops / avg_s / 1e12
                 roof = {"kernel": dominant, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_cnt,
                         "flops_per_launch": dom_flops}
             else:
                 byts = spectral_bytes(n) * B
                 ach = byts / avg_s / 1e9
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "traffic_source": traffic_src,
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_cnt, "bytes_per_launch": byts}
         cpu = None
         if not args.no_cpu_baseline:
