@@ -40,8 +40,27 @@ __device__ int g_stamp_sel = 881;  // CA*100 + CB*10 + EPI of the instance that 
             g_stamps[(blockIdx.x * 4 + wave) * 64 + stamp_i + (slot)] = t_;                              \
         }                                                                                                \
     } while (0)
+__device__ unsigned long long g_stamps2[2048 * 4 * 16];
+__device__ __forceinline__ unsigned long long stamp_now() {
+    unsigned long long t_;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    return t_;
+}
+#define STAMP2_DECL unsigned long long st_[16] = {0}; unsigned long long st_t0_ = stamp_now(), st_prev_ = st_t0_;
+#define STAMP2(slot) do { unsigned long long now_ = stamp_now(); st_[slot] += now_ - st_prev_; st_prev_ = now_; } while (0)
+#define STAMP2_FLUSH()                                                                                    \
+    do {                                                                                                  \
+        const int blk_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                  \
+        if (lane == 0 && blk_ < 2048 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == 256) {            \
+            st_[15] = st_t0_;                                                                             \
+            for (int i_ = 0; i_ < 16; ++i_) g_stamps2[(blk_ * 4 + wave) * 16 + i_] = st_[i_];              \
+        }                                                                                                 \
+    } while (0)
 #else
 #define STAMP(slot) do { } while (0)
+#define STAMP2_DECL
+#define STAMP2(slot) do { } while (0)
+#define STAMP2_FLUSH() do { } while (0)
 #endif
 
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
@@ -49,6 +68,15 @@ constexpr int cmax_(int a, int b) { return a > b ? a : b; }
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// x / 1000 (hybridnet.py:570 divides the network output by 1e3): reciprocal multiply plus one
+// residual correction -- the correctly rounded quotient for a normal x (1000 is exact in fp32), in
+// 3 instructions instead of the ~12 of a full IEEE division sequence.
+__device__ __forceinline__ float div1000(float x) {
+    const float r = 1e-3f;
+    const float qv = x * r;
+    const float e = fmaf(-qv, 1000.0f, x);
+    return fmaf(e, r, qv);
 }
 // Scheduling hint for one pipelined step: N x (1 MFMA, then 1 LDS read issued in its shadow).
 template <int N>
@@ -320,11 +348,254 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
                     for (int p = 0; p < 2; ++p)
                         if (x + p < W) {
                             if (epi.d_out) epi.d_out[o + c2 * plane + p] = dv[c2][p];
-                            if (epi.wf) epi.wf[o + c2 * plane + p] = dv[c2][p] / 1e3f + wf_old[gi][c2][p];  // hybridnet.py:570
+                            if (epi.wf) epi.wf[o + c2 * plane + p] = div1000(dv[c2][p]) + wf_old[gi][c2][p];  // hybridnet.py:570
                         }
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Strip-mapped DoubleConv for the big levels (W even, W >= 64): same tiling / chunking as
+// k_dc_mfma<.., 64, ..> but every wavefront owns a 32-pixel-wide column strip of consecutive rows,
+// so one LDS row read feeds the MFMAs of three output rows (dy = 0, 1, 2): 0.4 LDS reads per MFMA
+// instead of 1, and the input is staged with 8-byte loads / stores.  The SIMD issue port, not the
+// matrix pipe, limited the generic kernel (about 6 non-MFMA instructions per MFMA).
+//   conv1: mid region 18 rows x 33 pixel pairs = 2 strips x (9 rows per wave) + the 33rd pair column,
+//          which waves 0 and 1 handle as "vertical" groups (n = row).
+//   conv2: 16 rows x 32 pairs = 2 strips x (8 rows per wave).
+// ------------------------------------------------------------------------------------------
+template <int CA, int CB, int CC>
+struct ScCfg {
+    static constexpr int TH = 16, TW = 64;
+    static constexpr int CIN = CA + CB + CC, NG = CIN / 2;
+    static constexpr int IR = TH + 4, PI = TW + 4, PLANE = IR * PI;
+    static constexpr int MR = TH + 2, PM = TW + 4, MPLANE = MR * PM;
+    static constexpr int NR1 = 9, NR2 = 8;         // rows per wave in conv1 / conv2
+    static constexpr int NP2 = PLANE / 2;          // float2 positions per channel
+    static constexpr int NL = cdiv_(NP2, 256);
+    static constexpr int LDS_FLOATS = cmax_(4 * PLANE, kFeat * MPLANE) + 8;
+};
+
+template <int CA, int CB, int CC, int EPI>
+__global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
+    using C = ScCfg<CA, CB, CC>;
+    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    const int strip = wave & 1, half = wave >> 1;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+
+    // ---- staging: float2 positions of this thread (W even: a pair never straddles the image edge) ----
+    int goff[C::NL], loff[C::NL];
+    unsigned okmask = 0, inmask = 0;
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * 256;
+        const int ir = e / (C::PI / 2), ic = 2 * (e - ir * (C::PI / 2));
+        const int y = y0 - 2 + ir, x = x0 - 2 + ic;
+        const bool ok = (e < C::NP2) && y >= 0 && y < H && x >= 0 && x < W;
+        goff[i] = ok ? y * W + x : 0;
+        loff[i] = ir * C::PI + ic;
+        okmask |= (ok ? 1u : 0u) << i;
+        inmask |= ((e < C::NP2) ? 1u : 0u) << i;
+    }
+    float2 stage[2][C::NL];
+    float stage_scale[2], afrag_next[6];
+    auto fetch = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = 2 * g + j;
+            const float* p0;
+            if (c < CA) { p0 = sa.p + (long)b * sa.sb + (long)c * sa.sc; stage_scale[j] = sa.scale; }
+            else if (c < CA + CB) { p0 = sb.p + (long)b * sb.sb + (long)(c - CA) * sb.sc; stage_scale[j] = sb.scale; }
+            else { p0 = sc.p + (long)b * sc.sb + (long)(c - CA - CB) * sc.sc; stage_scale[j] = sc.scale; }
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i) stage[j][i] = *reinterpret_cast<const float2*>(p0 + goff[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) afrag_next[j] = w.a1[(g * 6 + j) * 64 + lane];
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i)
+                if (inmask >> i & 1u) {
+                    const bool ok = okmask >> i & 1u;
+                    *reinterpret_cast<float2*>(&lds[(buf * 2 + j) * C::PLANE + loff[i]]) =
+                        ok ? make_float2(stage[j][i].x * stage_scale[j], stage[j][i].y * stage_scale[j]) : make_float2(0.f, 0.f);
+                }
+    };
+
+    // ---- conv1 ----
+    // strip groups: mid rows 9*half .. 9*half+8, pairs 16*strip + n; operand row j of the wave = staged row 9*half + j
+    const int rb1 = C::NR1 * half;
+    const int bs1 = rb1 * C::PI + 2 * (16 * strip + n) + q;
+    // vertical group (waves 0, 1): pair column 32 (mid cols 64, 65), mid rows vrow0 + n
+    const bool has_v = wave < 2;
+    const int vrow0 = wave == 0 ? 0 : 2;
+    const int bsv = (vrow0 + n) * C::PI + 64 + q;
+    f32x4 acc1[C::NR1], accv = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    STAMP2_DECL
+    fetch(0);
+    STAMP2(0);  // prologue
+#pragma unroll 1
+    for (int g = 0; g < C::NG; ++g) {
+        const int buf = g & 1;
+        commit(buf);
+        float afrag[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) afrag[j] = afrag_next[j];
+        STAMP2(1);  // commit (includes waiting for the staged loads)
+        __syncthreads();
+        STAMP2(2);  // chunk barrier
+        if (g + 1 < C::NG) fetch(g + 1);
+        STAMP2(3);  // fetch issue
+        const float* t = lds + buf * 2 * C::PLANE;
+        float br[2][C::NR1 + 2], bvv[2][3];
+#pragma unroll
+        for (int j = 0; j < C::NR1 + 2; ++j) br[0][j] = t[bs1 + j * C::PI];
+        if (has_v) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) bvv[0][dy] = t[bsv + dy * C::PI];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            if (c == 0) {  // rows of the second channel are read behind the first channel's MFMAs
+#pragma unroll
+                for (int j = 0; j < C::NR1 + 2; ++j) br[1][j] = t[C::PLANE + bs1 + j * C::PI];
+                if (has_v) {
+#pragma unroll
+                    for (int dy = 0; dy < 3; ++dy) bvv[1][dy] = t[C::PLANE + bsv + dy * C::PI];
+                }
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int r = 0; r < C::NR1; ++r) acc1[r] = mfma4(afrag[c * 3 + dy], br[c][r + dy], acc1[r]);
+            if (has_v) {
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) accv = mfma4(afrag[c * 3 + dy], bvv[c][dy], accv);
+            }
+            if (c == 0) interleave_mfma_dsread<C::NR1 + 2>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STAMP2(4);  // conv1 MFMAs of the chunk
+    }
+    float a2[kFeat * 3];
+#pragma unroll
+    for (int j = 0; j < kFeat * 3; ++j) a2[j] = w.a2[j * 64 + lane];
+    __syncthreads();  // staged input is dead: the mid tensor takes its place
+    {
+        const float slope = w.slope[0];
+        const float bias0 = w.b1[2 * q], bias1 = w.b1[2 * q + 1];
+        auto put = [&](const f32x4& a, int mrow, int pc) {
+            const int y = y0 - 1 + mrow, x = x0 - 1 + 2 * pc;
+            const bool yin = y >= 0 && y < H;
+            const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
+            float v[4] = {a[0] + bias0, a[1] + bias0, a[2] + bias1, a[3] + bias1};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : slope * v[r];  // PReLU (architectures.py:32-33)
+            float* m0 = lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;  // zero outside the image: conv2 pads the MID tensor
+            *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
+            *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
+        };
+#pragma unroll
+        for (int r = 0; r < C::NR1; ++r) put(acc1[r], rb1 + r, 16 * strip + n);
+        if (has_v && (wave == 0 || n >= 14)) put(accv, vrow0 + n, 32);
+    }
+    STAMP2(5);  // barrier + mid write
+    __syncthreads();
+    STAMP2(6);  // mid barrier
+
+    // ---- conv2: output rows 8*half .. +7, pairs 16*strip + n ----
+    const int rb2 = C::NR2 * half;
+    const int bs2 = rb2 * C::PM + 2 * (16 * strip + n) + q;
+    f32x4 acc2[C::NR2];
+#pragma unroll
+    for (int r = 0; r < C::NR2; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
+    const int ox = x0 + 2 * (16 * strip + n);
+    float aoc0 = 0.f, aoc1 = 0.f, ob_re = 0.f, ob_im = 0.f;
+    float2 wf_old[EPI == 1 ? C::NR2 : 1][2];
+    if (EPI == 1) {  // out-conv fragments A_j[m][k = q] = ow[2q + j][m] (m < 2); old wavefield values
+        const int m = lane & 15;
+        if (m < 2) {
+            aoc0 = epi.ow[(2 * q) * 2 + m];
+            aoc1 = epi.ow[(2 * q + 1) * 2 + m];
+        }
+        ob_re = epi.ob[0];
+        ob_im = epi.ob[1];
+        if (epi.wf != nullptr && q == 0) {
+            const long plane = (long)H * W;
+#pragma unroll
+            for (int r = 0; r < C::NR2; ++r) {
+                const int y = y0 + rb2 + r;
+                const long o = (long)b * 2 * plane + (long)(y < H ? y : 0) * W + (ox < W ? ox : 0);
+                wf_old[r][0] = *reinterpret_cast<const float2*>(epi.wf + o);
+                wf_old[r][1] = *reinterpret_cast<const float2*>(epi.wf + o + plane);
+            }
+        }
+    }
+    {
+        float br[2][C::NR2 + 2];
+#pragma unroll
+        for (int j = 0; j < C::NR2 + 2; ++j) br[0][j] = lds[bs2 + j * C::PM];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cm = 0; cm < kFeat; ++cm) {
+            if (cm + 1 < kFeat) {
+#pragma unroll
+                for (int j = 0; j < C::NR2 + 2; ++j) br[(cm + 1) & 1][j] = lds[(cm + 1) * C::MPLANE + bs2 + j * C::PM];
+            }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int r = 0; r < C::NR2; ++r) acc2[r] = mfma4(a2[cm * 3 + dy], br[cm & 1][r + dy], acc2[r]);
+            if (cm + 1 < kFeat) interleave_mfma_dsread<C::NR2 + 2>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    STAMP2(7);  // conv2
+#pragma unroll
+    for (int r = 0; r < C::NR2; ++r) {
+        const int y = y0 + rb2 + r;
+        const bool ok = y < H && ox < W;
+        const float o00 = acc2[r][0] + bo0, o01 = acc2[r][1] + bo0;  // channel 2q,   pixels ox, ox+1
+        const float o10 = acc2[r][2] + bo1, o11 = acc2[r][3] + bo1;  // channel 2q+1
+        if (EPI == 0) {
+            if (ok) {
+                float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)y * W + ox;
+                *reinterpret_cast<float2*>(p) = make_float2(o00, o01);
+                *reinterpret_cast<float2*>(p + out.sc) = make_float2(o10, o11);
+            }
+        } else {
+            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const f32x4 dA = mfma4(aoc1, o10, mfma4(aoc0, o00, z));  // pixel ox
+            const f32x4 dB = mfma4(aoc1, o11, mfma4(aoc0, o01, z));  // pixel ox + 1
+            if (q == 0 && ok) {
+                const long plane = (long)H * W;
+                const long o = (long)b * 2 * plane + (long)y * W + ox;
+                const float re0 = dA[0] + ob_re, re1 = dB[0] + ob_re, im0 = dA[1] + ob_im, im1 = dB[1] + ob_im;
+                if (epi.d_out) {
+                    *reinterpret_cast<float2*>(epi.d_out + o) = make_float2(re0, re1);
+                    *reinterpret_cast<float2*>(epi.d_out + o + plane) = make_float2(im0, im1);
+                }
+                if (epi.wf) {  // wf <- d / 1e3 + wf (hybridnet.py:570)
+                    *reinterpret_cast<float2*>(epi.wf + o) = make_float2(div1000(re0) + wf_old[r][0].x, div1000(re1) + wf_old[r][0].y);
+                    *reinterpret_cast<float2*>(epi.wf + o + plane) = make_float2(div1000(im0) + wf_old[r][1].x, div1000(im1) + wf_old[r][1].y);
+                }
+            }
+        }
+    }
+    STAMP2(8);  // epilogue
+    STAMP2_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -579,8 +850,8 @@ __global__ __launch_bounds__(256, 1) void k_dc_mfma_p(Src sa, Src sb, Src sc, Ds
                     }
                     if (epi.wf) {  // wf <- d / 1e3 + wf (hybridnet.py:570)
                         const float2 o0 = wf_old[EPI == 1 ? gi : 0][0], o1 = wf_old[EPI == 1 ? gi : 0][1];
-                        *reinterpret_cast<float2*>(epi.wf + o) = make_float2(re0 / 1e3f + o0.x, re1 / 1e3f + o0.y);
-                        *reinterpret_cast<float2*>(epi.wf + o + plane) = make_float2(im0 / 1e3f + o1.x, im1 / 1e3f + o1.y);
+                        *reinterpret_cast<float2*>(epi.wf + o) = make_float2(div1000(re0) + o0.x, div1000(re1) + o0.y);
+                        *reinterpret_cast<float2*>(epi.wf + o + plane) = make_float2(div1000(im0) + o1.x, div1000(im1) + o1.y);
                     }
                 }
             }
@@ -595,6 +866,9 @@ __global__ __launch_bounds__(256, 1) void k_dc_mfma_p(Src sa, Src sb, Src sc, Ds
 #ifdef HN_STAMP
 }  // namespace
 extern "C" int hn_debug_set_stamp_sel(int sel) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &sel, sizeof(int)); }
+extern "C" int hn_debug_read_stamps2(unsigned long long* host, int count) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * count);
+}
 extern "C" int hn_debug_read_stamps(unsigned long long* host, int count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * count);
 }
@@ -829,7 +1103,11 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     // the persistent full-tile variant measured slower than the chunked one (1 wave per SIMD leaves
     // staging / epilogue phases uncovered); kept opt-in for experiments
     static const bool persistent = getenv("HN_DC_PERSISTENT") != nullptr;
-    if (W >= 64 && (W & 1) == 0 && persistent) {
+    static const bool generic = getenv("HN_DC_GENERIC") != nullptr;
+    if (W >= 64 && (W & 1) == 0 && !persistent && !generic) {
+        static const int dyn_lds = getenv("HN_DC_DYNLDS") ? atoi(getenv("HN_DC_DYNLDS")) : 0;  // experiments: caps blocks per CU
+        hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), dyn_lds, s, a, b, c, out, w, e, H, W);
+    } else if (W >= 64 && (W & 1) == 0 && persistent) {
         using C = PcCfg<CA, CB, CC>;
         const int tx = cdiv_(W, 64), ty = cdiv_(H, 16), nt = tx * ty * batch;
         const int per_cu = (160 * 1024) / (int)(C::LDS_FLOATS * sizeof(float));
