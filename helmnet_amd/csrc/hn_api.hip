@@ -165,6 +165,11 @@ void hn_destroy(hn_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_stagger[j]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->side_stream) {
+        (void)hipStreamDestroy(ctx->side_stream);
+        for (int d = 0; d < kMaxDepth; ++d) (void)hipEventDestroy(ctx->ev_side[d]);
+        (void)hipEventDestroy(ctx->ev_side_done);
+    }
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -355,6 +360,7 @@ int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states
     if (rc != HN_OK) return rc;
     if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
     const long plane = (long)ctx->tab.n * ctx->tab.n;
+    ctx->side_batch = -1;  // single-shot network call: everything on the caller's stream
     const Src wf{in6, kInCh * plane, plane, 1.f};
     const Src res{in6 + 2 * plane, kInCh * plane, plane, 1.f};
     const Src sig{in6 + 4 * plane, kInCh * plane, plane, 1.f};
@@ -389,6 +395,15 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     }
     int ns = ctx->n_streams;
     if (batch < 2 * ns) ns = 1;                       // tiny batches: not worth splitting
+    {   // side stream for the conv_state kernels (single main stream only)
+        static const bool want_side = getenv("HN_SIDE_STREAM") == nullptr || atoi(getenv("HN_SIDE_STREAM")) != 0;
+        if (want_side && ctx->side_stream == nullptr) {
+            HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+            for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side[d], hipEventDisableTiming));
+            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming));
+        }
+        ctx->side_batch = (want_side && ns == 1) ? batch : -1;
+    }
     if (n_iter == 0) ns = 1;
     if (ns > 1) HN_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
     int lo[9];

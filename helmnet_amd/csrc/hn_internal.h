@@ -89,6 +89,9 @@ struct hn_ctx {
     float* st_tmp = nullptr;            // second flat state buffer for hn_step ping-pong
     // hn_step pipelines sub-batches on internal streams (samples are independent): while one
     // sub-batch walks the small, latency-bound UNet levels the other one keeps the CUs busy
+    hipStream_t side_stream = nullptr;   // conv_state kernels (HN_SIDE_STREAM, hn_step only)
+    int side_batch = 0;
+    hipEvent_t ev_side[hn::kMaxDepth]{}, ev_side_done = nullptr;
     int n_streams = 0;
     hipStream_t sub_stream[8]{};
     hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};

@@ -32,9 +32,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #ifdef HN_STAMP
 __device__ unsigned long long g_stamps[256 * 4 * 64];
 __device__ int g_stamp_sel = 881;  // CA*100 + CB*10 + EPI of the instance that records
+__device__ int g_stamp_w = 256;    // ... and the image width it must be running on
 #define STAMP(slot)                                                                                      \
     do {                                                                                                 \
-        if (lane == 0 && stamp_i + (slot) < 64 && blockIdx.x < 256 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == 256) {                                                        \
+        if (lane == 0 && stamp_i + (slot) < 64 && blockIdx.x < 256 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == g_stamp_w) {                                                        \
             unsigned long long t_;                                                                       \
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
             g_stamps[(blockIdx.x * 4 + wave) * 64 + stamp_i + (slot)] = t_;                              \
@@ -51,7 +52,7 @@ __device__ __forceinline__ unsigned long long stamp_now() {
 #define STAMP2_FLUSH()                                                                                    \
     do {                                                                                                  \
         const int blk_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                  \
-        if (lane == 0 && blk_ < 2048 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == 256) {            \
+        if (lane == 0 && blk_ < 2048 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == g_stamp_w) {            \
             st_[15] = st_t0_;                                                                             \
             for (int i_ = 0; i_ < 16; ++i_) g_stamps2[(blk_ * 4 + wave) * 16 + i_] = st_[i_];              \
         }                                                                                                 \
@@ -606,9 +607,9 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
 // committed to LDS after conv1.  Two barriers per tile; one wavefront per SIMD owns its matrix
 // pipe.  A-operand fragments of both convolutions stay in registers for the whole launch.
 // ------------------------------------------------------------------------------------------
-template <int CA, int CB, int CC>
+template <int CA, int CB, int CC, int TH_ = 16, int TW_ = 64>
 struct PcCfg {
-    static constexpr int TH = 16, TW = 64;
+    static constexpr int TH = TH_, TW = TW_;
     static constexpr int CIN = CA + CB + CC;
     static constexpr int IR = TH + 4, PI = TW + 4, PLANE = IR * PI;
     static constexpr int MR = TH + 2, PM = TW + 4, MPLANE = MR * PM;
@@ -621,10 +622,10 @@ struct PcCfg {
     static constexpr int LDS_FLOATS = AF_OFF + (CIN * 3 + kFeat * 3 + 6) * 64 + 8;  // +6: fragments are read one channel pair ahead
 };
 
-template <int CA, int CB, int CC, int EPI>
-__global__ __launch_bounds__(256, 1) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W,
-                                                       int tiles_x, int tiles_y, int ntiles) {
-    using C = PcCfg<CA, CB, CC>;
+template <int CA, int CB, int CC, int EPI, int TH_, int TW_>
+__global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W,
+                                                    int tiles_x, int tiles_y, int ntiles) {
+    using C = PcCfg<CA, CB, CC, TH_, TW_>;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
@@ -866,6 +867,7 @@ __global__ __launch_bounds__(256, 1) void k_dc_mfma_p(Src sa, Src sb, Src sc, Ds
 #ifdef HN_STAMP
 }  // namespace
 extern "C" int hn_debug_set_stamp_sel(int sel) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &sel, sizeof(int)); }
+extern "C" int hn_debug_set_stamp_w(int w) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_w), &w, sizeof(int)); }
 extern "C" int hn_debug_read_stamps2(unsigned long long* host, int count) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * count);
 }
@@ -1104,15 +1106,24 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     // staging / epilogue phases uncovered); kept opt-in for experiments
     static const bool persistent = getenv("HN_DC_PERSISTENT") != nullptr;
     static const bool generic = getenv("HN_DC_GENERIC") != nullptr;
-    if (W >= 64 && (W & 1) == 0 && !persistent && !generic) {
+    const bool even = (W & 1) == 0;
+    if (W >= 128 && even && !persistent && !generic) {
         static const int dyn_lds = getenv("HN_DC_DYNLDS") ? atoi(getenv("HN_DC_DYNLDS")) : 0;  // experiments: caps blocks per CU
         hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), dyn_lds, s, a, b, c, out, w, e, H, W);
-    } else if (W >= 64 && (W & 1) == 0 && persistent) {
+    } else if (W >= 64 && even && persistent) {
         using C = PcCfg<CA, CB, CC>;
         const int tx = cdiv_(W, 64), ty = cdiv_(H, 16), nt = tx * ty * batch;
         const int per_cu = (160 * 1024) / (int)(C::LDS_FLOATS * sizeof(float));
         const int grid = nt < 256 * per_cu ? nt : 256 * per_cu;
-        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI>), dim3(grid), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 16, 64>), dim3(grid), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+    } else if (even && !generic && W > 16) {
+        // small levels are latency-bound: whole input tile staged at once (one barrier), small 8 x 32
+        // tiles so that even a 32^2 image spreads over many CUs
+        const int tx = cdiv_(W, 32), ty = cdiv_(H, 8), nt = tx * ty * batch;
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 32>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+    } else if (even && !generic) {
+        const int tx = cdiv_(W, 16), ty = cdiv_(H, 8), nt = tx * ty * batch;
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 16>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
     } else if (W > 32) {
         hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 64, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
     } else if (W > 16) {

@@ -427,6 +427,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     const Src none{nullptr, 0, 0, 1.f};
     const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
     const bool mfma = !ctx->use_valu;
+    hipStream_t side = (ctx->side_stream != nullptr && ws_off == 0 && batch == ctx->side_batch) ? ctx->side_stream : nullptr;
     auto plane = [&](int d) { const long m = n >> d; return m * m; };
     // ws_off: first sample slot of the workspace this call may use (sub-batches on parallel streams)
     auto feat = [&](float* p, int d) { return Dst{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d)}; };
@@ -451,7 +452,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                                               ctx->sig[d], noepi, m, m, batch, s);
         }
         // state = conv_state(cat[out, state_old])                        (architectures.py:248)
-        {
+        // Nothing downstream in this iteration reads the new state, so with a side stream the four
+        // conv_state kernels are deferred until the main chain is in the small, latency-bound levels
+        // (they start after down(d+1)) and fill the CUs those leave idle.
+        if (side == nullptr) {
             ProfScope ps(ctx, KID_STATE0 + 3 * d, s);
             launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
                                                             noepi, m, m, batch, s);
@@ -463,6 +467,19 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                 dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                                 ctx->down[d], m, m);
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
+        if (side != nullptr) {
+            // after down(d): release conv_state(d-1) (and, at the last level, conv_state(d) as well)
+            HN_HIP(ctx, hipEventRecord(ctx->ev_side[d], s));
+            const int e_lo = d > 0 ? d - 1 : depth, e_hi = d == depth - 1 ? d : d - 1;
+            for (int e = e_lo; e <= e_hi && e < depth; ++e) {
+                const int me = n >> e;
+                const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
+                const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
+                HN_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_side[d], 0));
+                ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
+                launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
+            }
+        }
     }
     // bottleneck: decode[depth]                                          (architectures.py:453)
     {
@@ -495,6 +512,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 1>(featsrc(ctx->buf_a[0], 0), featsrc(ctx->buf_o[0], 0), none,
                                                         Dst{nullptr, 0, 0}, ctx->dec[0], e, m, m, batch, s);
         }
+    }
+    if (side != nullptr) {  // the next iteration's conv_signal reads the new states
+        HN_HIP(ctx, hipEventRecord(ctx->ev_side_done, side));
+        HN_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_side_done, 0));
     }
     HN_HIP(ctx, hipGetLastError());
     return HN_OK;

@@ -11,7 +11,8 @@ s = IterativeSolver.from_exported_weights(); s.freeze(); s.to("cuda:0"); s.set_d
 sos = torch.from_numpy(ring_sos_batch(256, 32, seed=0)).cuda()
 lib0 = _lib.load()
 sel = int(sys.argv[1]) if len(sys.argv) > 1 else 881
-print("stamp selector", sel, "rc", lib0.hn_debug_set_stamp_sel(sel))
+wsel = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+print("stamp selector", sel, "width", wsel, "rc", lib0.hn_debug_set_stamp_sel(sel), lib0.hn_debug_set_stamp_w(wsel))
 out = s.forward(sos, num_iterations=3, residuals="norms")
 torch.cuda.synchronize()
 lib = _lib.load()
@@ -21,7 +22,7 @@ lib.hn_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 print("rc", lib.hn_debug_read_stamps(buf, n))
 a = np.frombuffer(buf, dtype=np.uint64).reshape(256, 4, 64).astype(np.int64)
 names = ["commit", "barrier1", "issue_next", "conv1", "mid", "barrier2", "conv2", "epilogue"]
-ntile = 7
+ntile = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 for w in range(4):
     d = []
     for t in range(ntile):
