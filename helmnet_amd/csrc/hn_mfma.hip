@@ -632,8 +632,32 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
 
     // ---- launch-invariant state: A fragments (kept in LDS so that the channel loops stay rolled and
     // the kernel's code stays small), operand offsets ----
-    for (int j = tid; j < C::CIN * 3 * 64; j += 256) lds[C::AF_OFF + j] = w.a1[j];
-    for (int j = tid; j < kFeat * 3 * 64; j += 256) lds[C::AF_OFF + C::CIN * 3 * 64 + j] = w.a2[j];
+    {   // all loads are issued before the first LDS store (a load-store loop would expose one global
+        // round trip per iteration, which dominated the run time of the small-level launches)
+        constexpr int N1 = C::CIN * 3 * 16, N2 = kFeat * 3 * 16;       // float4 counts
+        constexpr int L1 = cdiv_(N1, 256), L2 = cdiv_(N2, 256);
+        float4 f1[L1], f2[L2];
+#pragma unroll
+        for (int i = 0; i < L1; ++i) {
+            const int j = tid + i * 256;
+            f1[i] = reinterpret_cast<const float4*>(w.a1)[j < N1 ? j : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < L2; ++i) {
+            const int j = tid + i * 256;
+            f2[i] = reinterpret_cast<const float4*>(w.a2)[j < N2 ? j : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < L1; ++i) {
+            const int j = tid + i * 256;
+            if (j < N1) *reinterpret_cast<float4*>(&lds[C::AF_OFF + 4 * j]) = f1[i];
+        }
+#pragma unroll
+        for (int i = 0; i < L2; ++i) {
+            const int j = tid + i * 256;
+            if (j < N2) *reinterpret_cast<float4*>(&lds[C::AF_OFF + C::CIN * 3 * 64 + 4 * j]) = f2[i];
+        }
+    }
     int boff1[C::GW1], boff2[C::GW2];
 #pragma unroll
     for (int gi = 0; gi < C::GW1; ++gi) {
@@ -898,11 +922,13 @@ struct DnCfg {
     static constexpr int NL = cdiv_(IR * IC, NT);
 };
 
-template <int WX>
+// ALL = true (small, latency-bound levels): all 8 input channels are staged at once behind a single
+// barrier instead of one channel per double-buffered chunk.
+template <int WX, bool ALL>
 __global__ __launch_bounds__(256) void k_down_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][8][64]*/,
                                                     const float* __restrict__ bias, int Hin, int Win) {
     using C = DnCfg<WX>;
-    __shared__ float lds[2 * C::PLANE];
+    __shared__ float lds[(ALL ? kFeat : 2) * C::PLANE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int wx = wave % WX, wy = wave / WX;
@@ -937,18 +963,41 @@ __global__ __launch_bounds__(256) void k_down_mfma(Src in, Dst out, const float*
 #pragma unroll
     for (int i = 0; i < C::NWIN; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
+    if (ALL) {
+        float st[kFeat][C::NL];
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c)
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i) st[c][i] = in.p[(long)b * in.sb + (long)c * in.sc + goff[i]];
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) afrag_next[kx] = afr[kx * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c)
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i)
+                if (inmask >> i & 1u) lds[c * C::PLANE + loff[i]] = (okmask >> i & 1u) ? st[c][i] : 0.f;
+        __syncthreads();
+    } else {
+        fetch(0);
+    }
 #pragma unroll 1
     for (int ci = 0; ci < kFeat; ++ci) {
-        float* t = lds + (ci & 1) * C::PLANE;
+        float* t = lds + (ALL ? ci : (ci & 1)) * C::PLANE;
+        if (!ALL) {
 #pragma unroll
-        for (int i = 0; i < C::NL; ++i)
-            if (inmask >> i & 1u) t[loff[i]] = (okmask >> i & 1u) ? stage[i] : 0.f;
+            for (int i = 0; i < C::NL; ++i)
+                if (inmask >> i & 1u) t[loff[i]] = (okmask >> i & 1u) ? stage[i] : 0.f;
+        }
         float afrag[8];
 #pragma unroll
         for (int kx = 0; kx < 8; ++kx) afrag[kx] = afrag_next[kx];
-        __syncthreads();
-        if (ci + 1 < kFeat) fetch(ci + 1);
+        if (!ALL) {
+            __syncthreads();
+            if (ci + 1 < kFeat) fetch(ci + 1);
+        } else if (ci + 1 < kFeat) {
+#pragma unroll
+            for (int kx = 0; kx < 8; ++kx) afrag_next[kx] = afr[((ci + 1) * 8 + kx) * 64 + lane];
+        }
         float bv[2][C::NWIN];
 #pragma unroll
         for (int wr = 0; wr < C::NWIN; ++wr) bv[0][wr] = t[bbase + 2 * wr * C::PI];
@@ -1001,11 +1050,11 @@ struct UpCfg2 {
     static constexpr int NL = cdiv_(IR * IC, NT);
 };
 
-template <int WX, int R_>
+template <int WX, int R_, bool ALL>
 __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][2][4][64]*/,
                                                   const float* __restrict__ bias, int Hin, int Win) {
     using C = UpCfg2<WX, R_>;
-    __shared__ float lds[4 * C::PLANE];  // 2 buffers x 2 channels
+    __shared__ float lds[(ALL ? kFeat : 4) * C::PLANE];  // ALL: every channel at once; else 2 buffers x 2 channels
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;
     const int wx = wave % WX, wy = wave / WX;
@@ -1043,22 +1092,45 @@ __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* _
 #pragma unroll
     for (int i = 0; i < C::R; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    fetch(0);
+    if (ALL) {
+        float st[kFeat][C::NL];
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c)
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i) st[c][i] = in.p[(long)b * in.sb + (long)c * in.sc + goff[i]];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) afrag_next[j] = afr[j * 64 + lane];
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c)
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i)
+                if (inmask >> i & 1u) lds[c * C::PLANE + loff[i]] = (okmask >> i & 1u) ? st[c][i] : 0.f;
+        __syncthreads();
+    } else {
+        fetch(0);
+    }
 #pragma unroll 1
     for (int g = 0; g < kFeat / 2; ++g) {
-        float* t = lds + (g & 1) * 2 * C::PLANE;
+        float* t = lds + (ALL ? 2 * g : (g & 1) * 2) * C::PLANE;
+        if (!ALL) {
 #pragma unroll
-        for (int i = 0; i < C::NL; ++i)
-            if (inmask >> i & 1u) {
-                const bool ok = okmask >> i & 1u;
-                t[loff[i]] = ok ? stage[i][0] : 0.f;
-                t[C::PLANE + loff[i]] = ok ? stage[i][1] : 0.f;
-            }
+            for (int i = 0; i < C::NL; ++i)
+                if (inmask >> i & 1u) {
+                    const bool ok = okmask >> i & 1u;
+                    t[loff[i]] = ok ? stage[i][0] : 0.f;
+                    t[C::PLANE + loff[i]] = ok ? stage[i][1] : 0.f;
+                }
+        }
         float afrag[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) afrag[j] = afrag_next[j];
-        __syncthreads();
-        if (g + 1 < kFeat / 2) fetch(g + 1);
+        if (!ALL) {
+            __syncthreads();
+            if (g + 1 < kFeat / 2) fetch(g + 1);
+        } else if (g + 1 < kFeat / 2) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) afrag_next[j] = afr[((g + 1) * 16 + j) * 64 + lane];
+        }
         float bv[2][C::R];
 #pragma unroll
         for (int wr = 0; wr < C::R; ++wr) bv[0][wr] = t[bbase + wr * C::PI];
@@ -1100,6 +1172,18 @@ __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* _
     }
 }
 
+// Experiment knob (HN_SPREAD=1): extra dynamic LDS that caps the blocks per CU of a small launch at
+// ceil(nblocks / 256).  Measured 2 % SLOWER on the small levels (co-located blocks were not the
+// problem), so it is off by default.
+inline unsigned spread_lds(size_t static_bytes, long nblocks) {
+    static const bool off = getenv("HN_SPREAD") == nullptr;
+    const long per_cu = (nblocks + 255) / 256;
+    if (off || per_cu >= 8) return 0;
+    const size_t want = (160 * 1024) / (size_t)per_cu;          // LDS share that admits exactly per_cu blocks
+    const size_t need = want > 512 ? want - 512 : 0;            // a little slack below the exact share
+    return need > static_bytes ? (unsigned)(need - static_bytes) & ~15u : 0;
+}
+
 template <int CA, int CB, int CC, int EPI>
 void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
     // the persistent full-tile variant measured slower than the chunked one (1 wave per SIMD leaves
@@ -1120,10 +1204,12 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
         // small levels are latency-bound: whole input tile staged at once (one barrier), small 8 x 32
         // tiles so that even a 32^2 image spreads over many CUs
         const int tx = cdiv_(W, 32), ty = cdiv_(H, 8), nt = tx * ty * batch;
-        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 32>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+        const unsigned dl = spread_lds(PcCfg<CA, CB, CC, 8, 32>::LDS_FLOATS * sizeof(float), nt);
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 32>), dim3(nt), dim3(256), dl, s, a, b, c, out, w, e, H, W, tx, ty, nt);
     } else if (even && !generic) {
         const int tx = cdiv_(W, 16), ty = cdiv_(H, 8), nt = tx * ty * batch;
-        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 16>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+        const unsigned dl = spread_lds(PcCfg<CA, CB, CC, 8, 16>::LDS_FLOATS * sizeof(float), nt);
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 16>), dim3(nt), dim3(256), dl, s, a, b, c, out, w, e, H, W, tx, ty, nt);
     } else if (W > 32) {
         hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 64, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
     } else if (W > 16) {
@@ -1188,15 +1274,30 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
 
 void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     const int Wout = Win / 2, Hout = Hin / 2;
-    if (Wout > 32) hipLaunchKernelGGL((k_down_mfma<4>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
-    else if (Wout > 16) hipLaunchKernelGGL((k_down_mfma<2>), dim3(1, cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
-    else hipLaunchKernelGGL((k_down_mfma<1>), dim3(1, cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    // tile shape by level size: 64x16 outputs per block for the big levels, 32x16 at 64 < Wout... (more, shorter blocks
+    // when there are few tiles: 17 us instead of 26 us at Wout = 64), all channels at once for the small ones
+    if (Wout > 64) hipLaunchKernelGGL((k_down_mfma<4, false>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    else if (Wout > 32) {
+        const dim3 g(cdiv_(Wout, 32), cdiv_(Hout, 16), batch);
+        const unsigned dl = spread_lds(2 * DnCfg<2>::PLANE * sizeof(float), (long)g.x * g.y * g.z);
+        hipLaunchKernelGGL((k_down_mfma<2, false>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
+    }
+    else {
+        const dim3 g(cdiv_(Wout, 16), cdiv_(Hout, 16), batch);
+        const unsigned dl = spread_lds(kFeat * DnCfg<1>::PLANE * sizeof(float), (long)g.x * g.y * g.z);
+        hipLaunchKernelGGL((k_down_mfma<1, true>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
+    }
 }
 
 void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     // window rows -1 .. Hin-1
-    if (Win > 16) hipLaunchKernelGGL((k_up_mfma<2, 8>), dim3(cdiv_(Win, 32), cdiv_(Hin + 1, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
-    else hipLaunchKernelGGL((k_up_mfma<1, 5>), dim3(1, cdiv_(Hin + 1, 20), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    static const int up_small = getenv("HN_UP_SMALL") ? atoi(getenv("HN_UP_SMALL")) : 64;
+    if (Win > up_small) hipLaunchKernelGGL((k_up_mfma<2, 8, false>), dim3(cdiv_(Win, 32), cdiv_(Hin + 1, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    else {
+        const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
+        const unsigned dl = spread_lds(kFeat * UpCfg2<1, 5>::PLANE * sizeof(float), (long)g.x * g.y * g.z);
+        hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
+    }
 }
 
 }  // namespace hn
