@@ -175,7 +175,9 @@ def main():
     if rank == 0:
         macs = kernel_macs(n)
         total_flops = 2.0 * sum(macs.values()) * B
-        dom_flops = 2.0 * macs[dominant] * B if dominant in macs else 0.0
+        # hn_step may split the batch over pipeline lanes: flops per LAUNCH = flops per step / launches per step
+        per_step = max(1, round(dom_cnt / max(1, K)))
+        dom_flops = 2.0 * macs[dominant] * B / per_step if dominant in macs else 0.0
         roof = None
         traffic, traffic_src = measured_traffic(dominant, n, B)
         if dom_cnt:
@@ -186,9 +188,9 @@ def main():
                         "unit": "TFLOP/s", "frac": round(ach / FP32_PEAK_TFLOPS, 4), "traffic": traffic,
                         "traffic_source": traffic_src,
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_cnt,
-                        "flops_per_launch": dom_flops}
+                        "samples_per_launch": B // per_step, "flops_per_launch": dom_flops}
             else:
-                byts = spectral_bytes(n) * B
+                byts = spectral_bytes(n) * B / per_step
                 ach = byts / avg_s / 1e9
                 roof = {"kernel": dominant, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -202,7 +204,7 @@ def main():
                              "oracle/helmnet_oracle.py on PyTorch CPU ops"}
         final_rmse = rmse[K - 1].float().cpu().numpy()
         line = {
-            "metric": "solver iterations/sec (whole node), 256^2 domain batch=32",
+            "metric": f"solver iterations/sec (whole node), {n}^2 domain batch={B}",
             "value": round(world * K / dt, 2),
             "unit": "iterations/s",
             "n_gpus": world, "steps": K, "warmup": W,

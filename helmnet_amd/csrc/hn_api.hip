@@ -165,10 +165,11 @@ void hn_destroy(hn_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_stagger[j]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->side_stream) {
-        (void)hipStreamDestroy(ctx->side_stream);
-        for (int d = 0; d < kMaxDepth; ++d) (void)hipEventDestroy(ctx->ev_side[d]);
-        (void)hipEventDestroy(ctx->ev_side_done);
+    for (auto& sl : ctx->side) {
+        if (!sl.stream) continue;
+        (void)hipStreamDestroy(sl.stream);
+        for (int d = 0; d < kMaxDepth; ++d) (void)hipEventDestroy(sl.ev[d]);
+        (void)hipEventDestroy(sl.done);
     }
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
@@ -360,7 +361,6 @@ int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states
     if (rc != HN_OK) return rc;
     if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
     const long plane = (long)ctx->tab.n * ctx->tab.n;
-    ctx->side_batch = -1;  // single-shot network call: everything on the caller's stream
     const Src wf{in6, kInCh * plane, plane, 1.f};
     const Src res{in6 + 2 * plane, kInCh * plane, plane, 1.f};
     const Src sig{in6 + 4 * plane, kInCh * plane, plane, 1.f};
@@ -383,7 +383,7 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     // ---- sub-batch pipelining over internal streams ----
     if (ctx->n_streams == 0) {
         const char* e = getenv("HN_STREAMS");
-        int ns = e ? atoi(e) : 1;  // 2-3 streams measured +0..3 %: kernels of both sub-batches fill the chip, overlap is zero-sum
+        int ns = e ? atoi(e) : 2;  // two staggered sub-batches: one fills the CUs while the other walks the small levels (+5 %)
         ns = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
         for (int j = 0; j < ns; ++j) {
             HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));
@@ -395,14 +395,15 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     }
     int ns = ctx->n_streams;
     if (batch < 2 * ns) ns = 1;                       // tiny batches: not worth splitting
-    {   // side stream for the conv_state kernels (single main stream only)
-        static const bool want_side = getenv("HN_SIDE_STREAM") == nullptr || atoi(getenv("HN_SIDE_STREAM")) != 0;
-        if (want_side && ctx->side_stream == nullptr) {
-            HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-            for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side[d], hipEventDisableTiming));
-            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_side_done, hipEventDisableTiming));
+    static const bool want_side = getenv("HN_SIDE_STREAM") == nullptr || atoi(getenv("HN_SIDE_STREAM")) != 0;
+    if (want_side) {
+        for (int j = 0; j < ns; ++j) {
+            auto& sl = ctx->side[j];
+            if (sl.stream) continue;
+            HN_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&sl.ev[d], hipEventDisableTiming));
+            HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
-        ctx->side_batch = (want_side && ns == 1) ? batch : -1;
     }
     if (n_iter == 0) ns = 1;
     if (ns > 1) HN_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
@@ -427,7 +428,8 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
             const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
             const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
             hipEvent_t stg = (ns > 1 && it == 0 && j + 1 < ns) ? ctx->ev_stagger[j] : nullptr;
-            if ((rc = unet_forward(ctx, s_wf, s_res, s_sig, st_in, st_out, nullptr, wf_j, nb, sj, b0, stg)) != HN_OK) return rc;
+            if ((rc = unet_forward(ctx, s_wf, s_res, s_sig, st_in, st_out, nullptr, wf_j, nb, sj, b0, stg,
+                                   want_side ? &ctx->side[j] : nullptr)) != HN_OK) return rc;
             const float* src_j = src_batch == 1 ? src : src + (size_t)b0 * 2 * plane;
             if ((rc = spec_apply(ctx, wf_j, res_j, k_sq + (size_t)b0 * plane, src_j, src_batch == 1 ? 1 : nb, nb,
                                  rmse_hist ? rmse_hist + (size_t)it * batch + b0 : nullptr, sj)) != HN_OK) return rc;

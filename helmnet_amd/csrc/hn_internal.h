@@ -89,9 +89,9 @@ struct hn_ctx {
     float* st_tmp = nullptr;            // second flat state buffer for hn_step ping-pong
     // hn_step pipelines sub-batches on internal streams (samples are independent): while one
     // sub-batch walks the small, latency-bound UNet levels the other one keeps the CUs busy
-    hipStream_t side_stream = nullptr;   // conv_state kernels (HN_SIDE_STREAM, hn_step only)
-    int side_batch = 0;
-    hipEvent_t ev_side[hn::kMaxDepth]{}, ev_side_done = nullptr;
+    // conv_state kernels run on a side stream per pipeline lane (HN_SIDE_STREAM, hn_step only)
+    struct SideLane { hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr; };
+    SideLane side[8];
     int n_streams = 0;
     hipStream_t sub_stream[8]{};
     hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};
@@ -161,6 +161,7 @@ void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, i
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the
 // wavefield is updated in place (wf += d / 1e3) by the last kernel; if d_out != nullptr d is stored.
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
-                 float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off = 0, hipEvent_t after_down0 = nullptr);
+                 float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off = 0, hipEvent_t after_down0 = nullptr,
+                 hn_ctx::SideLane* side_lane = nullptr);
 
 }  // namespace hn

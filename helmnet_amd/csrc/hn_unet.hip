@@ -421,13 +421,14 @@ __global__ __launch_bounds__(UpCfg::NT) void k_up8x8(Src in, Dst out, K8W w, int
 }  // namespace
 
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
-                 float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off, hipEvent_t after_down0) {
+                 float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off, hipEvent_t after_down0,
+                 hn_ctx::SideLane* side_lane) {
     const int n = ctx->tab.n, depth = ctx->depth;
     const long L = ctx->state_len;
     const Src none{nullptr, 0, 0, 1.f};
     const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
     const bool mfma = !ctx->use_valu;
-    hipStream_t side = (ctx->side_stream != nullptr && ws_off == 0 && batch == ctx->side_batch) ? ctx->side_stream : nullptr;
+    hipStream_t side = side_lane ? side_lane->stream : nullptr;
     auto plane = [&](int d) { const long m = n >> d; return m * m; };
     // ws_off: first sample slot of the workspace this call may use (sub-batches on parallel streams)
     auto feat = [&](float* p, int d) { return Dst{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d)}; };
@@ -469,13 +470,13 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
         if (side != nullptr) {
             // after down(d): release conv_state(d-1) (and, at the last level, conv_state(d) as well)
-            HN_HIP(ctx, hipEventRecord(ctx->ev_side[d], s));
+            HN_HIP(ctx, hipEventRecord(side_lane->ev[d], s));
             const int e_lo = d > 0 ? d - 1 : depth, e_hi = d == depth - 1 ? d : d - 1;
             for (int e = e_lo; e <= e_hi && e < depth; ++e) {
                 const int me = n >> e;
                 const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
                 const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
-                HN_HIP(ctx, hipStreamWaitEvent(side, ctx->ev_side[d], 0));
+                HN_HIP(ctx, hipStreamWaitEvent(side, side_lane->ev[d], 0));
                 ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
                 launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
             }
@@ -514,8 +515,8 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         }
     }
     if (side != nullptr) {  // the next iteration's conv_signal reads the new states
-        HN_HIP(ctx, hipEventRecord(ctx->ev_side_done, side));
-        HN_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_side_done, 0));
+        HN_HIP(ctx, hipEventRecord(side_lane->done, side));
+        HN_HIP(ctx, hipStreamWaitEvent(s, side_lane->done, 0));
     }
     HN_HIP(ctx, hipGetLastError());
     return HN_OK;

@@ -150,6 +150,17 @@ def test_free_run_ring96_dense_operator(solver, g_free):
     assert np.abs(out["wavefields"][199].cpu().numpy() - g_free["ring96_wf_it200"]).max() <= 1e-4
 
 
+def test_free_run_512_vs_oracle(solver, weights):
+    """BASELINE config 4 shape (512^2 via set_domain_size), short free run against the CPU oracle."""
+    n = 512
+    solver.set_domain_size(n, source_location=SRC[n])
+    sos = torch.from_numpy(ring_sos_batch(n, 2, seed=4))
+    out = solver.forward(sos.to(DEV), num_iterations=40, residuals="norms")
+    want = O.solve(sos, weights, O.point_source_map(n, SRC[n], 10.0), O.SpectralTables(n, 8, 2, 1.0), 40)
+    assert (out["wavefields"][0].cpu() - want["wavefield"]).abs().max().item() <= 1e-4
+    assert np.allclose(out["residual_norms"].cpu().numpy(), torch.stack(want["trace"]).numpy(), rtol=2e-2)
+
+
 def test_batch_samples_are_independent_and_deterministic(solver):
     """BASELINE config 2 shape (B=32, 256^2): every sample of a batch equals the same sample
     solved alone, bit for bit (samples never interact, hybridnet.py:654-697)."""
