@@ -34,18 +34,40 @@ __device__ __forceinline__ float2 cmul(float2 x, float2 y) {
     return make_float2(x.x * y.x - x.y * y.y, x.x * y.y + x.y * y.x);
 }
 
+// Per-thread twiddle factors of every stage, fetched once per kernel (the stage loop would otherwise
+// expose a global-memory round trip per stage -- these kernels are latency-bound).
+template <int N>
+struct Twiddles {
+    static constexpr int NS = (N >= 1024 ? 4 : N >= 256 ? 3 : N >= 64 ? 2 : N >= 16 ? 1 : 0);  // radix-4 stages after the first
+    float2 w[NS > 0 ? NS : 1][3];
+    float2 wa, wb;  // final radix-2 stage (N = 2 * 4^m)
+    __device__ __forceinline__ void load(int j, const float2* __restrict__ tw) {
+        int s = 0;
+#pragma unroll
+        for (int ns = 4; ns * 4 <= N; ns *= 4, ++s) {
+            const int idx = (j & (ns - 1)) * (N / (4 * ns));
+            w[s][0] = tw[idx];
+            w[s][1] = tw[2 * idx];
+            w[s][2] = tw[3 * idx];
+        }
+        wa = tw[j];
+        wb = tw[j + N / 4];
+    }
+};
+
 // In-LDS Stockham FFT of length N distributed over N/4 threads.  On entry thread j holds
 // x[j + t*N/4] in v[t]; on exit it holds X[j + t*N/4] (natural order).  Element idx of this
 // transform lives at buf[idx * STRIDE].  INV selects the conjugate (unnormalised) transform.
 template <int N, int STRIDE, bool INV>
-__device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, const float2* __restrict__ tw) {
+__device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, const Twiddles<N>& tw) {
     constexpr int T = N / 4;
+    int s = 0;
 #pragma unroll
     for (int ns = 1; ns * 4 <= N; ns *= 4) {
         const int k = j & (ns - 1);
         if (ns > 1) {
-            const int idx = k * (N / (4 * ns));
-            float2 w1 = tw[idx], w2 = tw[2 * idx], w3 = tw[3 * idx];
+            float2 w1 = tw.w[s][0], w2 = tw.w[s][1], w3 = tw.w[s][2];
+            ++s;
             if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
             v[1] = cmul(v[1], w1);
             v[2] = cmul(v[2], w2);
@@ -70,7 +92,7 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, con
     // N = 2 * 4^m: one radix-2 stage; its operands are already in this thread's registers.
     constexpr bool kOdd = (N == 32 || N == 128 || N == 512 || N == 2048);
     if (kOdd) {
-        float2 wa = tw[j], wb = tw[j + T];
+        float2 wa = tw.wa, wb = tw.wb;
         if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
         const float2 p = cmul(v[2], wa), q = cmul(v[3], wb);
         const float2 x0 = v[0], x1 = v[1];
@@ -86,26 +108,36 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, con
 template <int N, int STRIDE>
 __device__ __forceinline__ void axis_operator(float2 (&v)[4], float2 (&acc)[4], float2* buf, int j, const SpecPtrs& t) {
     constexpr int T = N / 4;
-    fft_pass<N, STRIDE, false>(v, buf, j, t.tw);
+    // all table reads up front (one memory round trip together with the caller's loads)
+    Twiddles<N> tw;
+    tw.load(j, t.tw);
+    float k1[4], k2[4];
+    float2 ca[4], cb[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        k1[q] = t.k1[j + q * T];
+        k2[q] = t.k2[j + q * T];
+        ca[q] = t.a[j + q * T];
+        cb[q] = t.b[j + q * T];
+    }
+    fft_pass<N, STRIDE, false>(v, buf, j, tw);
     float2 U[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         U[q] = v[q];
-        const float k = t.k1[j + q * T];
-        v[q] = make_float2(-U[q].y * k, U[q].x * k);  // (0, k) * U   (spectral.py:50, 281)
+        v[q] = make_float2(-U[q].y * k1[q], U[q].x * k1[q]);  // (0, k) * U   (spectral.py:50, 281)
     }
-    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
+    fft_pass<N, STRIDE, true>(v, buf, j, tw);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        acc[q] = cmul(t.a[j + q * T], v[q]);
-        const float k2 = t.k2[j + q * T];
-        v[q] = make_float2(k2 * U[q].x, k2 * U[q].y);  // (-k^2, 0) * U (spectral.py:52, 283)
+        acc[q] = cmul(ca[q], v[q]);
+        v[q] = make_float2(k2[q] * U[q].x, k2[q] * U[q].y);  // (-k^2, 0) * U (spectral.py:52, 283)
     }
-    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
+    fft_pass<N, STRIDE, true>(v, buf, j, tw);
     constexpr float inv_n = 1.0f / N;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float2 d = cmul(t.b[j + q * T], v[q]);
+        const float2 d = cmul(cb[q], v[q]);
         acc[q] = make_float2((acc[q].x + d.x) * inv_n, (acc[q].y + d.y) * inv_n);
     }
 }
@@ -164,22 +196,33 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
         u[q] = make_float2(pre[j + q * T], pre[plane + j + q * T]);
         v[q] = u[q];
     }
-    axis_operator<N, 1>(v, acc, buf + ry * N, j, t);
+    // everything this row still needs from HBM is requested NOW, so that there is one memory round trip
+    // per wave instead of two (the kernel is latency-bound: waves spend 80 % of their life in s_waitcnt)
     float* po = out + (long)b * 2 * plane + ro;
+    float2 part[4], sv[4];
+    float kq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int x = j + q * T;
+        part[q] = make_float2(0.f, 0.f);
+        sv[q] = make_float2(0.f, 0.f);
+        kq[q] = 0.f;
+        if (flags & 1) part[q] = make_float2(po[x], po[plane + x]);
+        if (flags & 2) {
+            kq[q] = ksq[(long)b * plane + ro + x];
+            const float* ps = src + (long)b * src_sb + ro + x;
+            sv[q] = make_float2(ps[0], ps[plane]);
+        }
+    }
+    axis_operator<N, 1>(v, acc, buf + ry * N, j, t);
     float ss = 0.f;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int x = j + q * T;
-        float re = acc[q].x, im = acc[q].y;
-        if (flags & 1) {
-            re += po[x];
-            im += po[plane + x];
-        }
+        float re = acc[q].x + part[q].x, im = acc[q].y + part[q].y;
         if (flags & 2) {
-            const float kq = ksq[(long)b * plane + ro + x];
-            const float* ps = src + (long)b * src_sb + ro + x;
-            re = re + kq * u[q].x - ps[0];
-            im = im + kq * u[q].y - ps[plane];
+            re = re + kq[q] * u[q].x - sv[q].x;
+            im = im + kq[q] * u[q].y - sv[q].y;
         }
         po[x] = re;
         po[plane + x] = im;
