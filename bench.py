@@ -153,9 +153,12 @@ def main():
         eng.step(wf, res, st, k_sq, src, W, rmse_hist=rmse[:W])
     torch.cuda.synchronize()
     prof = eng.profile_collect()
-    dominant = max(prof, key=lambda k: prof[k][0]) if prof else "decode0"
+    pmin = eng.profile_min()    # shortest launch per kernel: the host cannot keep up with ~70 API calls per step
+    dominant = max(pmin, key=pmin.get) if pmin else "decode0"
     dom_id = [i for i in range(eng.KERNEL_IDS) if eng.kernel_name(i) == dominant][0]
-    eng.profile_enable([dom_id])                      # only 2 event records per step in the timed region
+    eng.profile_enable([dom_id])
+    stride = max(1, K // 32)                          # ~32 sampled launches: event pairs cost ~6 us of stream gap each
+    eng.profile_stride(stride)
 
     def barrier():
         if dist is not None:
@@ -174,12 +177,13 @@ def main():
         dt = tmax.item()
     dom_ms, dom_cnt = eng.profile_collect().get(dominant, (0.0, 0))
     eng.profile_enable([])
+    eng.profile_stride(1)
 
     if rank == 0:
         macs = kernel_macs(n)
         total_flops = 2.0 * sum(macs.values()) * B
         # hn_step may split the batch over pipeline lanes: flops per LAUNCH = flops per step / launches per step
-        per_step = max(1, round(dom_cnt / max(1, K)))
+        per_step = max(1, round(dom_cnt * stride / max(1, K)))
         dom_flops = 2.0 * macs[dominant] * B / per_step if dominant in macs else 0.0
         roof = None
         traffic, traffic_src = measured_traffic(dominant, n, B)

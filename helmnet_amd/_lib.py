@@ -38,6 +38,8 @@ SYMBOLS = {
     "hn_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hn_profile_enable": (c_int, [c_void_p, ctypes.c_uint64]),
+    "hn_profile_min": (c_int, [c_void_p, POINTER(ctypes.c_double), c_int]),
+    "hn_profile_stride": (c_int, [c_void_p, c_int]),
     "hn_profile_collect": (c_int, [c_void_p, POINTER(ctypes.c_double), POINTER(c_int64), c_int]),
 }
 

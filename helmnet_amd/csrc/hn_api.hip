@@ -25,6 +25,7 @@ int fail(hn_ctx* ctx, int code, const char* fmt, ...) {
 
 ProfScope::ProfScope(hn_ctx* ctx, int id, hipStream_t st) : c(ctx), s(st) {
     if (!(ctx->prof_mask >> id & 1ull)) return;
+    if (ctx->prof_seen[id]++ % ctx->prof_stride != 0) return;   // sampling keeps the event overhead (~6 us of gap each) negligible
     hn_ctx::ProfRec r{id, nullptr, nullptr};
     for (hipEvent_t* e : {&r.a, &r.b}) {
         if (!ctx->prof_pool.empty()) { *e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); }
@@ -306,6 +307,19 @@ int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask) {
     return HN_OK;
 }
 
+int hn_profile_min(hn_ctx* ctx, double* min_ms, int n_ids) {
+    if (!ctx || !min_ms) return fail(ctx, HN_ERR_ARG, "hn_profile_min: NULL argument");
+    for (int i = 0; i < n_ids && i < KID_COUNT; ++i) min_ms[i] = ctx->prof_min_last[i];
+    return HN_OK;
+}
+
+int hn_profile_stride(hn_ctx* ctx, int every_nth) {
+    if (!ctx || every_nth < 1) return fail(ctx, HN_ERR_ARG, "hn_profile_stride: stride must be >= 1");
+    ctx->prof_stride = every_nth;
+    for (auto& v : ctx->prof_seen) v = 0;
+    return HN_OK;
+}
+
 int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids) {
     if (!ctx || !total_ms || !count) return fail(ctx, HN_ERR_ARG, "hn_profile_collect: NULL argument");
     for (auto& r : ctx->prof_recs) {
@@ -313,6 +327,7 @@ int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids)
         float ms = 0.f;
         HN_HIP(ctx, hipEventElapsedTime(&ms, r.a, r.b));
         ctx->prof_ms[r.id] += ms;
+        if (ctx->prof_cnt[r.id] == 0 || ms < ctx->prof_min[r.id]) ctx->prof_min[r.id] = ms;
         ctx->prof_cnt[r.id] += 1;
         ctx->prof_pool.push_back(r.a);
         ctx->prof_pool.push_back(r.b);
@@ -322,6 +337,7 @@ int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids)
         total_ms[i] = ctx->prof_ms[i];
         count[i] = ctx->prof_cnt[i];
         ctx->prof_ms[i] = 0.0;
+        ctx->prof_min_last[i] = ctx->prof_cnt[i] ? ctx->prof_min[i] : 0.0;
         ctx->prof_cnt[i] = 0;
     }
     return HN_OK;

@@ -97,10 +97,13 @@ struct hn_ctx {
     hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};
     // optional per-kernel timing with HIP events on the caller's stream (hn_profile_*)
     uint64_t prof_mask = 0;
+    int prof_stride = 1;          // bracket every prof_stride-th launch of a selected kernel
+    long prof_seen[64]{};
     struct ProfRec { int id; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[64]{};
+    double prof_min[64]{}, prof_min_last[64]{};  // shortest bracketed launch (robust to host stalls): running / last collect
     long prof_cnt[64]{};
 };
 

@@ -209,6 +209,16 @@ class Engine:
         mask = (1 << self.KERNEL_IDS) - 1 if kernel_ids is None else sum(1 << k for k in kernel_ids)
         _lib.check(self.lib.hn_profile_enable(self.ctx, ctypes.c_uint64(mask)), self.ctx, "hn_profile_enable")
 
+    def profile_min(self) -> dict:
+        """{kernel name: shortest bracketed launch in ms} for the interval closed by the last profile_collect()."""
+        ms = (ctypes.c_double * self.KERNEL_IDS)()
+        _lib.check(self.lib.hn_profile_min(self.ctx, ms, self.KERNEL_IDS), self.ctx, "hn_profile_min")
+        return {self.kernel_name(i): ms[i] for i in range(self.KERNEL_IDS) if ms[i] > 0}
+
+    def profile_stride(self, every_nth: int):
+        """Bracket only every n-th launch of the selected kernels (an event pair costs microseconds of gap)."""
+        _lib.check(self.lib.hn_profile_stride(self.ctx, int(every_nth)), self.ctx, "hn_profile_stride")
+
     def profile_collect(self) -> dict:
         """{kernel name: (total ms, launches)} since the last collect."""
         ms = (ctypes.c_double * self.KERNEL_IDS)()

@@ -128,7 +128,13 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
  * launch counts for ids [0, n_ids) and resets the accumulators. */
 #define HN_KERNEL_IDS 34
 int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
+/* Bracket only every `every_nth` launch of a selected kernel (default 1).  An event pair costs a few
+ * microseconds of stream gap, so timed runs sample instead of bracketing every launch. */
+int hn_profile_stride(hn_ctx* ctx, int every_nth);
 int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids);
+/* Shortest bracketed launch per kernel id in the interval closed by the last hn_profile_collect
+ * (robust against host-side launch stalls, which inflate event-bracketed times). */
+int hn_profile_min(hn_ctx* ctx, double* min_ms, int n_ids);
 
 #ifdef __cplusplus
 }
