@@ -44,7 +44,7 @@ __device__ int g_stamp_w = 256;    // ... and the image width it must be running
 __device__ unsigned long long g_stamps2[2048 * 4 * 16];
 __device__ __forceinline__ unsigned long long stamp_now() {
     unsigned long long t_;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  // 100 MHz wall clock (s_memtime is load-dependent)
     return t_;
 }
 #define STAMP2_DECL unsigned long long st_[16] = {0}; unsigned long long st_t0_ = stamp_now(), st_prev_ = st_t0_;
@@ -924,8 +924,10 @@ struct DnCfg {
 
 // ALL = true (small, latency-bound levels): all 8 input channels are staged at once behind a single
 // barrier instead of one channel per double-buffered chunk.
+// Two blocks per CU (<= 256 registers): the second block's MFMAs fill the first one's staging /
+// barrier gaps (56 -> 49 us at 256^2 x 32; one wavefront per SIMD cannot hide them by itself).
 template <int WX, bool ALL>
-__global__ __launch_bounds__(256) void k_down_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][8][64]*/,
+__global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][8][64]*/,
                                                     const float* __restrict__ bias, int Hin, int Win) {
     using C = DnCfg<WX>;
     __shared__ float lds[(ALL ? kFeat : 2) * C::PLANE];

@@ -63,6 +63,17 @@ int main() {
     float *in, *out;
     (void)hipMalloc(&in, 4096); (void)hipMalloc(&out, 256 * 4096 * 4);
     (void)hipMemset(in, 0, 4096);
+    printf("-- operands all zero\n");
+    run<10, 1>("interleaved", in, out, 0);
+    run<16, 1>("interleaved", in, out, 0);
+    run<10, 2>("registers only", in, out, 0);
+    {
+        float h[1024];
+        unsigned x = 12345u;
+        for (int i = 0; i < 1024; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((x >> 8) & 0xffff) / 32768.0f - 1.0f; }
+        (void)hipMemcpy(in, h, 4096, hipMemcpyHostToDevice);
+    }
+    printf("-- operands uniform(-1, 1)\n");
     run<10, 0>("phases", in, out, 0);
     run<10, 1>("interleaved", in, out, 0);
     run<8, 0>("phases", in, out, 0);
