@@ -375,59 +375,79 @@ struct ScCfg {
     static constexpr int NR1 = 9, NR2 = 8;         // rows per wave in conv1 / conv2
     static constexpr int NP2 = PLANE / 2;          // float2 positions per channel
     static constexpr int NL = cdiv_(NP2, 256);
-    static constexpr int LDS_FLOATS = cmax_(4 * PLANE, kFeat * MPLANE) + 8;
+    static constexpr int PLANE_P = PLANE + 128;    // + one dummy float2 per lane: masked lanes commit there, unpredicated
+    static constexpr int LDS_FLOATS = cmax_(4 * PLANE_P, kFeat * MPLANE) + 8;
+    static constexpr bool SCALED = CC > 0;         // only the 3-source input layer carries a staging scale (1e3 * residual)
 };
 
 template <int CA, int CB, int CC, int EPI>
 __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
     using C = ScCfg<CA, CB, CC>;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
     const int n = lane & 15, q = lane >> 4;
     const int strip = wave & 1, half = wave >> 1;
     const int b = blockIdx.z;
     const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
 
-    // ---- staging: float2 positions of this thread (W even: a pair never straddles the image edge) ----
-    int goff[C::NL], loff[C::NL];
-    unsigned okmask = 0, inmask = 0;
+    // ---- staging plan: float2 positions of this thread (W even: a pair never straddles the image edge) ----
+    // Every non-MFMA instruction of the chunk loop is paid in matrix-pipe time, so the
+    // loop carries no predicate, mask or address arithmetic: out-of-image positions are zeroed ONCE here
+    // and the lanes that own them (and the lanes past the end of the plane) load from offset 0 and
+    // commit to a private dummy slot behind the plane.
+    unsigned gofb[C::NL];   // byte offset inside a channel plane
+    int lofw[C::NL];        // LDS float2 index inside a (padded) staged plane
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) {
         const int e = tid + i * 256;
         const int ir = e / (C::PI / 2), ic = 2 * (e - ir * (C::PI / 2));
         const int y = y0 - 2 + ir, x = x0 - 2 + ic;
-        const bool ok = (e < C::NP2) && y >= 0 && y < H && x >= 0 && x < W;
-        goff[i] = ok ? y * W + x : 0;
-        loff[i] = ir * C::PI + ic;
-        okmask |= (ok ? 1u : 0u) << i;
-        inmask |= ((e < C::NP2) ? 1u : 0u) << i;
+        const bool in = e < C::NP2;
+        const bool ok = in && y >= 0 && y < H && x >= 0 && x < W;
+        gofb[i] = ok ? (unsigned)(y * W + x) * 4u : 0u;
+        lofw[i] = (ok ? ir * C::PI + ic : C::PLANE + 2 * lane) >> 1;
+        if (in && !ok) {
+#pragma unroll
+            for (int pl = 0; pl < 4; ++pl) *reinterpret_cast<float2*>(&lds[pl * C::PLANE_P + ir * C::PI + ic]) = make_float2(0.f, 0.f);
+        }
     }
+    const float* const base_a = sa.p + (long)b * sa.sb;
+    const float* const base_b = sb.p + (long)b * sb.sb;
+    const float* const base_c = sc.p + (long)b * sc.sb;
     float2 stage[2][C::NL];
-    float stage_scale[2], afrag_next[6];
-    auto fetch = [&](int g) {
+    float afrag_next[6];
+    auto fetch = [&](int g) {  // g is a compile-time constant after unrolling: the source select folds away
+        // laundering the 32-bit offsets keeps their zero-extension inside this block, which is what lets
+        // the loads use SGPR-base + VGPR-offset addressing (no 64-bit VALU adds)
+        unsigned off[C::NL], aoff = 4u * lane;
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            off[i] = gofb[i];
+            asm volatile("" : "+v"(off[i]));
+        }
+        asm volatile("" : "+v"(aoff));
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int c = 2 * g + j;
-            const float* p0;
-            if (c < CA) { p0 = sa.p + (long)b * sa.sb + (long)c * sa.sc; stage_scale[j] = sa.scale; }
-            else if (c < CA + CB) { p0 = sb.p + (long)b * sb.sb + (long)(c - CA) * sb.sc; stage_scale[j] = sb.scale; }
-            else { p0 = sc.p + (long)b * sc.sb + (long)(c - CA - CB) * sc.sc; stage_scale[j] = sc.scale; }
+            const float* p0 = c < CA ? base_a + (long)c * sa.sc : c < CA + CB ? base_b + (long)(c - CA) * sb.sc : base_c + (long)(c - CA - CB) * sc.sc;
 #pragma unroll
-            for (int i = 0; i < C::NL; ++i) stage[j][i] = *reinterpret_cast<const float2*>(p0 + goff[i]);
+            for (int i = 0; i < C::NL; ++i) stage[j][i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p0) + off[i]);
         }
 #pragma unroll
-        for (int j = 0; j < 6; ++j) afrag_next[j] = w.a1[(g * 6 + j) * 64 + lane];
+        for (int j = 0; j < 6; ++j) afrag_next[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(w.a1 + (g * 6 + j) * 64) + aoff);
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int g) {
+        const int buf = g & 1;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+            const int c = 2 * g + j;
+            const float scale = c < CA ? sa.scale : c < CA + CB ? sb.scale : sc.scale;
 #pragma unroll
             for (int i = 0; i < C::NL; ++i)
-                if (inmask >> i & 1u) {
-                    const bool ok = okmask >> i & 1u;
-                    *reinterpret_cast<float2*>(&lds[(buf * 2 + j) * C::PLANE + loff[i]]) =
-                        ok ? make_float2(stage[j][i].x * stage_scale[j], stage[j][i].y * stage_scale[j]) : make_float2(0.f, 0.f);
-                }
+                reinterpret_cast<float2*>(lds)[(buf * 2 + j) * (C::PLANE_P / 2) + lofw[i]] =
+                    C::SCALED ? make_float2(stage[j][i].x * scale, stage[j][i].y * scale) : stage[j][i];
+        }
     };
 
     // ---- conv1 ----
@@ -445,10 +465,10 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
     STAMP2_DECL
     fetch(0);
     STAMP2(0);  // prologue
-#pragma unroll 1
+#pragma unroll
     for (int g = 0; g < C::NG; ++g) {
         const int buf = g & 1;
-        commit(buf);
+        commit(g);
         float afrag[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) afrag[j] = afrag_next[j];
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
         STAMP2(2);  // chunk barrier
         if (g + 1 < C::NG) fetch(g + 1);
         STAMP2(3);  // fetch issue
-        const float* t = lds + buf * 2 * C::PLANE;
+        const float* t = lds + buf * 2 * C::PLANE_P;
         float br[2][C::NR1 + 2], bvv[2][3];
 #pragma unroll
         for (int j = 0; j < C::NR1 + 2; ++j) br[0][j] = t[bs1 + j * C::PI];
@@ -470,10 +490,10 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
         for (int c = 0; c < 2; ++c) {
             if (c == 0) {  // rows of the second channel are read behind the first channel's MFMAs
 #pragma unroll
-                for (int j = 0; j < C::NR1 + 2; ++j) br[1][j] = t[C::PLANE + bs1 + j * C::PI];
+                for (int j = 0; j < C::NR1 + 2; ++j) br[1][j] = t[C::PLANE_P + bs1 + j * C::PI];
                 if (has_v) {
 #pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) bvv[1][dy] = t[C::PLANE + bsv + dy * C::PI];
+                    for (int dy = 0; dy < 3; ++dy) bvv[1][dy] = t[C::PLANE_P + bsv + dy * C::PI];
                 }
             }
 #pragma unroll
@@ -1193,7 +1213,8 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     static const bool persistent = getenv("HN_DC_PERSISTENT") != nullptr;
     static const bool generic = getenv("HN_DC_GENERIC") != nullptr;
     const bool even = (W & 1) == 0;
-    if (W >= 128 && even && !persistent && !generic) {
+    const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
+    if (W >= 128 && even && !persistent && !generic && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
         static const int dyn_lds = getenv("HN_DC_DYNLDS") ? atoi(getenv("HN_DC_DYNLDS")) : 0;  // experiments: caps blocks per CU
         hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), dyn_lds, s, a, b, c, out, w, e, H, W);
     } else if (W >= 64 && even && persistent) {

@@ -22,3 +22,17 @@ med = np.median(a[:, :, :9].reshape(-1, 9), axis=0)
 print("selector", sel, {k: int(v) for k, v in zip(names, med)}, "sum", int(med.sum()))
 t0 = a[:, 0, 15]; order = np.argsort(t0); life = a[:, :, :9].sum(axis=2).mean(axis=1)
 print("block lifetime median", int(np.median(life)), "kernel span", int(t0.max() - t0.min() + np.median(life)))
+# block timeline (10 ns ticks of s_memrealtime): when do blocks start / end relative to the first start
+end = t0 + a[:, :, :9].sum(axis=2).max(axis=1)
+z = t0.min()
+s_rel, e_rel = np.sort(t0 - z), np.sort(end - z)
+pct = [0, 10, 25, 50, 75, 90, 100]
+print("block start (us) pct", pct, [round(float(np.percentile(s_rel, p)) / 100, 1) for p in pct])
+print("block end   (us) pct", pct, [round(float(np.percentile(e_rel, p)) / 100, 1) for p in pct])
+nb = len(t0)
+first = np.sort(t0 - z)[: nb // 2]
+print("first-round (first half of blocks) start span us", round(float(first.max()) / 100, 1))
+# concurrency over time
+ts = np.arange(0, int(e_rel.max()) + 1, 100)
+conc = [(int(((t0 - z) <= t).sum() - ((end - z) <= t).sum())) for t in ts]
+print("resident blocks every 1 us:", conc)
