@@ -26,6 +26,7 @@ namespace hn {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Diagnostic build only (-DHN_STAMP): per-phase s_memtime stamps of the persistent DoubleConv,
 // written to a buffer nothing else reads.  Never enabled in the shipped library.
@@ -458,9 +459,11 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
     const bool has_v = wave < 2;
     const int vrow0 = wave == 0 ? 0 : 2;
     const int bsv = (vrow0 + n) * C::PI + 64 + q;
-    f32x4 acc1[C::NR1], accv = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // accumulators start at the bias (D rows of a lane: channel 2q for pixels 0/1, channel 2q+1 for pixels 0/1)
+    const float bias0 = w.b1[2 * q], bias1 = w.b1[2 * q + 1];
+    f32x4 acc1[C::NR1], accv = (f32x4){bias0, bias0, bias1, bias1};
 #pragma unroll
-    for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){bias0, bias0, bias1, bias1};
 
     STAMP2_DECL
     fetch(0);
@@ -514,22 +517,40 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
     for (int j = 0; j < kFeat * 3; ++j) a2[j] = w.a2[j * 64 + lane];
     __syncthreads();  // staged input is dead: the mid tensor takes its place
     {
+        // PReLU (architectures.py:32-33) as median(x, s x, +-inf): max(x, s x) for s <= 1, min otherwise --
+        // exactly x or s x -- and the zero padding of the MID tensor outside the image (conv2 pads it)
+        // folded into the two multiplies: m * prelu(x) = median(m x, (m s) x, +-inf) for m in {0, 1}.
         const float slope = w.slope[0];
-        const float bias0 = w.b1[2 * q], bias1 = w.b1[2 * q + 1];
-        auto put = [&](const f32x4& a, int mrow, int pc) {
-            const int y = y0 - 1 + mrow, x = x0 - 1 + 2 * pc;
-            const bool yin = y >= 0 && y < H;
-            const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
-            float v[4] = {a[0] + bias0, a[1] + bias0, a[2] + bias1, a[3] + bias1};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : slope * v[r];  // PReLU (architectures.py:32-33)
-            float* m0 = lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;  // zero outside the image: conv2 pads the MID tensor
-            *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
-            *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
+        const float sel = slope <= 1.f ? __builtin_inff() : -__builtin_inff();
+        auto put = [&](const f32x4& a, int mrow, int pc, f32x2 mk, f32x2 sk) {
+            float2* m = reinterpret_cast<float2*>(lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc);
+            const f32x2 lo = (f32x2){a[0], a[1]}, hi = (f32x2){a[2], a[3]};
+            const f32x2 lm = lo * mk, ls = lo * sk, hm = hi * mk, hs = hi * sk;  // v_pk_mul_f32
+            m[0] = make_float2(__builtin_amdgcn_fmed3f(lm[0], ls[0], sel), __builtin_amdgcn_fmed3f(lm[1], ls[1], sel));
+            m[C::MPLANE / 2] = make_float2(__builtin_amdgcn_fmed3f(hm[0], hs[0], sel), __builtin_amdgcn_fmed3f(hm[1], hs[1], sel));
         };
+        auto put_zero = [&](int mrow, int pc) {
+            float2* m = reinterpret_cast<float2*>(lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc);
+            m[0] = make_float2(0.f, 0.f);
+            m[C::MPLANE / 2] = make_float2(0.f, 0.f);
+        };
+        {   // strip rows: the x mask is a per-lane constant, the row test is wave-uniform
+            const int pc = 16 * strip + n, x = x0 - 1 + 2 * pc;
+            const float mx0 = (x >= 0 && x < W) ? 1.f : 0.f, mx1 = (x + 1 >= 0 && x + 1 < W) ? 1.f : 0.f;
+            const f32x2 mk = (f32x2){mx0, mx1}, sk = (f32x2){mx0 * slope, mx1 * slope};
 #pragma unroll
-        for (int r = 0; r < C::NR1; ++r) put(acc1[r], rb1 + r, 16 * strip + n);
-        if (has_v && (wave == 0 || n >= 14)) put(accv, vrow0 + n, 32);
+            for (int r = 0; r < C::NR1; ++r) {
+                const int y = y0 - 1 + rb1 + r;
+                if (y >= 0 && y < H) put(acc1[r], rb1 + r, pc, mk, sk);
+                else put_zero(rb1 + r, pc);
+            }
+        }
+        if (has_v && (wave == 0 || n >= 14)) {  // pair column 32: x is uniform, the row differs per lane
+            const int y = y0 - 1 + vrow0 + n, x = x0 + 63;
+            const bool yin = y >= 0 && y < H;
+            const float m0 = (yin && x < W) ? 1.f : 0.f, m1 = (yin && x + 1 < W) ? 1.f : 0.f;
+            put(accv, vrow0 + n, 32, (f32x2){m0, m1}, (f32x2){m0 * slope, m1 * slope});
+        }
     }
     STAMP2(5);  // barrier + mid write
     __syncthreads();
@@ -538,11 +559,17 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
     // ---- conv2: output rows 8*half .. +7, pairs 16*strip + n ----
     const int rb2 = C::NR2 * half;
     const int bs2 = rb2 * C::PM + 2 * (16 * strip + n) + q;
+    const float bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
     f32x4 acc2[C::NR2];
 #pragma unroll
-    for (int r = 0; r < C::NR2; ++r) acc2[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
+    for (int r = 0; r < C::NR2; ++r) acc2[r] = (f32x4){bo0, bo0, bo1, bo1};  // start at the bias
     const int ox = x0 + 2 * (16 * strip + n);
+    const int yb = y0 + rb2;                       // first output row of this wave (wave-uniform)
+    const bool xin = ox < W;
+    // all global addresses of the epilogue are (wave-uniform 64-bit base) + (32-bit per-lane byte offset):
+    // rows advance the scalar base, so the row loop carries no vector address arithmetic
+    const long plane = (long)H * W;
+    const unsigned wvoff = xin ? 4u * (unsigned)ox : 0u;
     float aoc0 = 0.f, aoc1 = 0.f, ob_re = 0.f, ob_im = 0.f;
     float2 wf_old[EPI == 1 ? C::NR2 : 1][2];
     if (EPI == 1) {  // out-conv fragments A_j[m][k = q] = ow[2q + j][m] (m < 2); old wavefield values
@@ -554,13 +581,14 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
         ob_re = epi.ob[0];
         ob_im = epi.ob[1];
         if (epi.wf != nullptr && q == 0) {
-            const long plane = (long)H * W;
+            unsigned off = wvoff;
+            asm volatile("" : "+v"(off));
 #pragma unroll
             for (int r = 0; r < C::NR2; ++r) {
-                const int y = y0 + rb2 + r;
-                const long o = (long)b * 2 * plane + (long)(y < H ? y : 0) * W + (ox < W ? ox : 0);
-                wf_old[r][0] = *reinterpret_cast<const float2*>(epi.wf + o);
-                wf_old[r][1] = *reinterpret_cast<const float2*>(epi.wf + o + plane);
+                const int y = yb + r < H ? yb + r : 0;
+                const char* row = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane + (long)y * W);
+                wf_old[r][0] = *reinterpret_cast<const float2*>(row + off);
+                wf_old[r][1] = *reinterpret_cast<const float2*>(row + 4 * plane + off);
             }
         }
     }
@@ -584,33 +612,55 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
         }
     }
     STAMP2(7);  // conv2
+    // acc2[r] = {channel 2q: pixels ox, ox+1; channel 2q+1: pixels ox, ox+1}
+    if (EPI == 0) {
+        if (xin) {
+            unsigned off = 4u * (unsigned)((2 * q) * (int)out.sc + ox);
+            asm volatile("" : "+v"(off));
 #pragma unroll
-    for (int r = 0; r < C::NR2; ++r) {
-        const int y = y0 + rb2 + r;
-        const bool ok = y < H && ox < W;
-        const float o00 = acc2[r][0] + bo0, o01 = acc2[r][1] + bo0;  // channel 2q,   pixels ox, ox+1
-        const float o10 = acc2[r][2] + bo1, o11 = acc2[r][3] + bo1;  // channel 2q+1
-        if (EPI == 0) {
-            if (ok) {
-                float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)y * W + ox;
-                *reinterpret_cast<float2*>(p) = make_float2(o00, o01);
-                *reinterpret_cast<float2*>(p + out.sc) = make_float2(o10, o11);
-            }
-        } else {
-            const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const f32x4 dA = mfma4(aoc1, o10, mfma4(aoc0, o00, z));  // pixel ox
-            const f32x4 dB = mfma4(aoc1, o11, mfma4(aoc0, o01, z));  // pixel ox + 1
-            if (q == 0 && ok) {
-                const long plane = (long)H * W;
-                const long o = (long)b * 2 * plane + (long)y * W + ox;
-                const float re0 = dA[0] + ob_re, re1 = dB[0] + ob_re, im0 = dA[1] + ob_im, im1 = dB[1] + ob_im;
-                if (epi.d_out) {
-                    *reinterpret_cast<float2*>(epi.d_out + o) = make_float2(re0, re1);
-                    *reinterpret_cast<float2*>(epi.d_out + o + plane) = make_float2(im0, im1);
+            for (int r = 0; r < C::NR2; ++r) {
+                if (yb + r < H) {
+                    char* row = reinterpret_cast<char*>(out.p + (long)b * out.sb + (long)(yb + r) * W);
+                    *reinterpret_cast<float2*>(row + off) = make_float2(acc2[r][0], acc2[r][1]);
+                    *reinterpret_cast<float2*>(row + 4 * out.sc + off) = make_float2(acc2[r][2], acc2[r][3]);
                 }
-                if (epi.wf) {  // wf <- d / 1e3 + wf (hybridnet.py:570)
-                    *reinterpret_cast<float2*>(epi.wf + o) = make_float2(div1000(re0) + wf_old[r][0].x, div1000(re1) + wf_old[r][0].y);
-                    *reinterpret_cast<float2*>(epi.wf + o + plane) = make_float2(div1000(im0) + wf_old[r][1].x, div1000(im1) + wf_old[r][1].y);
+            }
+        }
+    } else {
+        // 1x1 out-conv (architectures.py:47-60) as two rounds of independent MFMAs (no back-to-back
+        // dependent pair); C starts at the out-conv bias: D rows 0 / 1 (lanes q = 0) = re / im
+        unsigned off = wvoff;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int h = 0; h < C::NR2; h += 4) {  // four rows at a time: 16 more live registers, not 64
+            f32x4 dA[4], dB[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dA[r] = mfma4(aoc0, acc2[h + r][0], (f32x4){ob_re, ob_im, 0.f, 0.f});  // pixel ox
+                dB[r] = mfma4(aoc0, acc2[h + r][1], (f32x4){ob_re, ob_im, 0.f, 0.f});  // pixel ox + 1
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dA[r] = mfma4(aoc1, acc2[h + r][2], dA[r]);
+                dB[r] = mfma4(aoc1, acc2[h + r][3], dB[r]);
+            }
+            if (q == 0 && xin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (yb + h + r < H) {
+                        const long ro = (long)b * 2 * plane + (long)(yb + h + r) * W;
+                        const float re0 = dA[r][0], im0 = dA[r][1], re1 = dB[r][0], im1 = dB[r][1];
+                        if (epi.d_out) {
+                            char* row = reinterpret_cast<char*>(epi.d_out + ro);
+                            *reinterpret_cast<float2*>(row + off) = make_float2(re0, re1);
+                            *reinterpret_cast<float2*>(row + 4 * plane + off) = make_float2(im0, im1);
+                        }
+                        if (epi.wf) {  // wf <- d / 1e3 + wf (hybridnet.py:570)
+                            char* row = reinterpret_cast<char*>(epi.wf + ro);
+                            *reinterpret_cast<float2*>(row + off) = make_float2(div1000(re0) + wf_old[h + r][0].x, div1000(re1) + wf_old[h + r][0].y);
+                            *reinterpret_cast<float2*>(row + 4 * plane + off) = make_float2(div1000(im0) + wf_old[h + r][1].x, div1000(im1) + wf_old[h + r][1].y);
+                        }
+                    }
                 }
             }
         }
@@ -1214,7 +1264,8 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     static const bool generic = getenv("HN_DC_GENERIC") != nullptr;
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
-    if (W >= 128 && even && !persistent && !generic && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
+    const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
+    if (W >= 128 && even && !persistent && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
         static const int dyn_lds = getenv("HN_DC_DYNLDS") ? atoi(getenv("HN_DC_DYNLDS")) : 0;  // experiments: caps blocks per CU
         hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), dyn_lds, s, a, b, c, out, w, e, H, W);
     } else if (W >= 64 && even && persistent) {
