@@ -57,10 +57,37 @@ struct Twiddles {
 
 // In-LDS Stockham FFT of length N distributed over N/4 threads.  On entry thread j holds
 // x[j + t*N/4] in v[t]; on exit it holds X[j + t*N/4] (natural order).  Element idx of this
-// transform lives at buf[idx * STRIDE].  INV selects the conjugate (unnormalised) transform.
+// transform lives at buf[lds_slot<STRIDE>(idx)].  INV selects the conjugate (unnormalised) transform.
+//
+// STRIDE == 1 (row pass, one transform per LDS row): the radix-4 scatter of the first two stages
+// writes float2 slots 4j (+m) and 4(j-k)+k (+4m) -- 4 lanes of every 16-lane ds_write_b64 group on one
+// bank pair, and with 32 waves per CU sharing the LDS that serialisation was ~75 % of the row kernel's
+// time (SQ_LDS_BANK_CONFLICT).  The XOR swizzle idx ^ ((idx >> 2) & 15) makes every store group and
+// every load group of every stage conflict-free for all N = 16 ... 2048 (checked exhaustively against
+// the bank rule: stores 4 x 16 lanes / 32 dword banks, b64 loads 2 x 32 lanes / 64 dword banks).
+// STRIDE == C (column pass): consecutive lanes own consecutive columns, already conflict-free.
+template <int STRIDE>
+__device__ __forceinline__ int lds_slot(int idx) {
+    return STRIDE == 1 ? (idx ^ ((idx >> 2) & 15)) : idx * STRIDE;
+}
+
+// WAVE = true: the N/4 threads of a transform are exactly one wavefront, whose LDS operations execute
+// in program order -- the exchange needs no workgroup barrier, only that the compiler keeps the order.
+template <bool WAVE>
+__device__ __forceinline__ void exchange_sync() {
+    if (WAVE) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+        __syncthreads();
+    }
+}
+
 template <int N, int STRIDE, bool INV>
 __device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, const Twiddles<N>& tw) {
     constexpr int T = N / 4;
+    constexpr bool WAVE = (STRIDE == 1 && T == 64);
     int s = 0;
 #pragma unroll
     for (int ns = 1; ns * 4 <= N; ns *= 4) {
@@ -80,14 +107,14 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, con
         // multiply a3 by -i (forward) or +i (inverse)
         const float2 r3 = INV ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);
         const int j0 = ((j - k) << 2) + k;
-        __syncthreads();  // everyone finished reading the previous stage
-        buf[(j0) * STRIDE] = make_float2(a0.x + a2.x, a0.y + a2.y);
-        buf[(j0 + ns) * STRIDE] = make_float2(a1.x + r3.x, a1.y + r3.y);
-        buf[(j0 + 2 * ns) * STRIDE] = make_float2(a0.x - a2.x, a0.y - a2.y);
-        buf[(j0 + 3 * ns) * STRIDE] = make_float2(a1.x - r3.x, a1.y - r3.y);
-        __syncthreads();
+        exchange_sync<WAVE>();  // everyone finished reading the previous stage
+        buf[lds_slot<STRIDE>(j0)] = make_float2(a0.x + a2.x, a0.y + a2.y);
+        buf[lds_slot<STRIDE>(j0 + ns)] = make_float2(a1.x + r3.x, a1.y + r3.y);
+        buf[lds_slot<STRIDE>(j0 + 2 * ns)] = make_float2(a0.x - a2.x, a0.y - a2.y);
+        buf[lds_slot<STRIDE>(j0 + 3 * ns)] = make_float2(a1.x - r3.x, a1.y - r3.y);
+        exchange_sync<WAVE>();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = buf[(j + t * T) * STRIDE];
+        for (int t = 0; t < 4; ++t) v[t] = buf[lds_slot<STRIDE>(j + t * T)];
     }
     // N = 2 * 4^m: one radix-2 stage; its operands are already in this thread's registers.
     constexpr bool kOdd = (N == 32 || N == 128 || N == 512 || N == 2048);
