@@ -988,46 +988,62 @@ struct DnCfg {
     static constexpr int IC = 2 * TW + 6;
     static constexpr int PI = IC | 1;                 // odd pitch: the 4 window rows hit distinct banks
     static constexpr int PLANE = IR * PI;
+    static constexpr int PLANE_P = PLANE + 64;        // + one dummy slot per lane (masked lanes commit there)
     static constexpr int NT = 256;
     static constexpr int NL = cdiv_(IR * IC, NT);
 };
 
 // ALL = true (small, latency-bound levels): all 8 input channels are staged at once behind a single
 // barrier instead of one channel per double-buffered chunk.
+// As in k_dc_mfma_s the channel loop carries no predicate or vector address arithmetic (they are paid in
+// matrix-pipe time): out-of-image positions are zeroed once, masked lanes load offset 0 and commit to a
+// dummy slot, the loop is fully unrolled and loads use SGPR-base + 32-bit VGPR-offset addressing.
 // Two blocks per CU (<= 256 registers): the second block's MFMAs fill the first one's staging /
 // barrier gaps (56 -> 49 us at 256^2 x 32; one wavefront per SIMD cannot hide them by itself).
 template <int WX, bool ALL>
 __global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][8][64]*/,
-                                                    const float* __restrict__ bias, int Hin, int Win) {
+                                                       const float* __restrict__ bias, int Hin, int Win) {
     using C = DnCfg<WX>;
-    __shared__ float lds[(ALL ? kFeat : 2) * C::PLANE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float lds[(ALL ? kFeat : 2) * C::PLANE_P];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int wx = wave % WX, wy = wave / WX;
     const int b = blockIdx.z;
     const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
     const int Hout = Hin / 2, Wout = Win / 2;
 
-    int goff[C::NL], loff[C::NL];
-    unsigned okmask = 0, inmask = 0;
+    unsigned gofb[C::NL];
+    int lofw[C::NL];
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) {
         const int e = tid + i * C::NT;
         const int ir = e / C::IC, ic = e - ir * C::IC;
         const int y = 2 * Y0 - 3 + ir, x = 2 * X0 - 3 + ic;
-        const bool ok = (e < C::IR * C::IC) && y >= 0 && y < Hin && x >= 0 && x < Win;
-        goff[i] = ok ? y * Win + x : 0;
-        loff[i] = ir * C::PI + ic;
-        okmask |= (ok ? 1u : 0u) << i;
-        inmask |= ((e < C::IR * C::IC) ? 1u : 0u) << i;
+        const bool inr = e < C::IR * C::IC;
+        const bool ok = inr && y >= 0 && y < Hin && x >= 0 && x < Win;
+        gofb[i] = ok ? 4u * (unsigned)(y * Win + x) : 0u;
+        lofw[i] = ok ? ir * C::PI + ic : C::PLANE + lane;
+        if (inr && !ok) {
+#pragma unroll
+            for (int pl = 0; pl < (ALL ? kFeat : 2); ++pl) lds[pl * C::PLANE_P + ir * C::PI + ic] = 0.f;
+        }
     }
+    const float* const base = in.p + (long)b * in.sb;
     float stage[C::NL], afrag_next[8];
     auto fetch = [&](int ci) {
-        const float* p0 = in.p + (long)b * in.sb + (long)ci * in.sc;
+        unsigned off[C::NL], aoff = 4u * lane;
 #pragma unroll
-        for (int i = 0; i < C::NL; ++i) stage[i] = p0[goff[i]];
+        for (int i = 0; i < C::NL; ++i) {
+            off[i] = gofb[i];
+            asm volatile("" : "+v"(off[i]));
+        }
+        asm volatile("" : "+v"(aoff));
+        const char* p0 = reinterpret_cast<const char*>(base + (long)ci * in.sc);
 #pragma unroll
-        for (int kx = 0; kx < 8; ++kx) afrag_next[kx] = afr[(ci * 8 + kx) * 64 + lane];
+        for (int i = 0; i < C::NL; ++i) stage[i] = *reinterpret_cast<const float*>(p0 + off[i]);
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) afrag_next[kx] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(afr + (ci * 8 + kx) * 64) + aoff);
     };
     // B operand of window row wr, tap kx: staged[(2*(wy*R + wr) + q) * PI + 2*(16*wx + n) + kx]
     const int bbase = (2 * wy * C::R + q) * C::PI + 2 * (16 * wx + n);
@@ -1040,25 +1056,23 @@ __global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const flo
 #pragma unroll
         for (int c = 0; c < kFeat; ++c)
 #pragma unroll
-            for (int i = 0; i < C::NL; ++i) st[c][i] = in.p[(long)b * in.sb + (long)c * in.sc + goff[i]];
+            for (int i = 0; i < C::NL; ++i) st[c][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (long)c * in.sc) + gofb[i]);
 #pragma unroll
         for (int kx = 0; kx < 8; ++kx) afrag_next[kx] = afr[kx * 64 + lane];
 #pragma unroll
         for (int c = 0; c < kFeat; ++c)
 #pragma unroll
-            for (int i = 0; i < C::NL; ++i)
-                if (inmask >> i & 1u) lds[c * C::PLANE + loff[i]] = (okmask >> i & 1u) ? st[c][i] : 0.f;
+            for (int i = 0; i < C::NL; ++i) lds[c * C::PLANE_P + lofw[i]] = st[c][i];
         __syncthreads();
     } else {
         fetch(0);
     }
-#pragma unroll 1
+#pragma unroll
     for (int ci = 0; ci < kFeat; ++ci) {
-        float* t = lds + (ALL ? ci : (ci & 1)) * C::PLANE;
+        float* t = lds + (ALL ? ci : (ci & 1)) * C::PLANE_P;
         if (!ALL) {
 #pragma unroll
-            for (int i = 0; i < C::NL; ++i)
-                if (inmask >> i & 1u) t[loff[i]] = (okmask >> i & 1u) ? stage[i] : 0.f;
+            for (int i = 0; i < C::NL; ++i) t[lofw[i]] = stage[i];
         }
         float afrag[8];
 #pragma unroll
@@ -1073,7 +1087,7 @@ __global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const flo
         float bv[2][C::NWIN];
 #pragma unroll
         for (int wr = 0; wr < C::NWIN; ++wr) bv[0][wr] = t[bbase + 2 * wr * C::PI];
-    __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kx = 0; kx < 8; ++kx) {
             if (kx + 1 < 8) {
@@ -1118,45 +1132,60 @@ struct UpCfg2 {
     static constexpr int IC = TW + 4;                 // input cols X0-2 .. X0+TW+1
     static constexpr int PI = ((IC + 15) / 32) * 32 + 16;  // pitch = 16 (mod 32): rows a, a+1 on disjoint banks
     static constexpr int PLANE = IR * PI;
+    static constexpr int PLANE_P = PLANE + 64;        // + one dummy slot per lane (masked lanes commit there)
     static constexpr int NT = 256;
     static constexpr int NL = cdiv_(IR * IC, NT);
 };
 
+// Staging follows k_down_mfma: zero the out-of-image positions once, no predicates in the (unrolled) loop.
 template <int WX, int R_, bool ALL>
-__global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][2][4][64]*/,
+__global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][2][4][64]*/,
                                                   const float* __restrict__ bias, int Hin, int Win) {
     using C = UpCfg2<WX, R_>;
-    __shared__ float lds[(ALL ? kFeat : 4) * C::PLANE];  // ALL: every channel at once; else 2 buffers x 2 channels
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float lds[(ALL ? kFeat : 4) * C::PLANE_P];  // ALL: every channel at once; else 2 buffers x 2 channels
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int wx = wave % WX, wy = wave / WX;
     const int b = blockIdx.z;
     const int X0 = blockIdx.x * C::TW, Yb = blockIdx.y * C::TH - 1;  // first window row of the block
     const int Hout = 2 * Hin, Wout = 2 * Win;
 
-    int goff[C::NL], loff[C::NL];
-    unsigned okmask = 0, inmask = 0;
+    unsigned gofb[C::NL];
+    int lofw[C::NL];
 #pragma unroll
     for (int i = 0; i < C::NL; ++i) {
         const int e = tid + i * C::NT;
         const int ir = e / C::IC, ic = e - ir * C::IC;
         const int y = Yb - 1 + ir, x = X0 - 2 + ic;
-        const bool ok = (e < C::IR * C::IC) && y >= 0 && y < Hin && x >= 0 && x < Win;
-        goff[i] = ok ? y * Win + x : 0;
-        loff[i] = ir * C::PI + ic;
-        okmask |= (ok ? 1u : 0u) << i;
-        inmask |= ((e < C::IR * C::IC) ? 1u : 0u) << i;
+        const bool inr = e < C::IR * C::IC;
+        const bool ok = inr && y >= 0 && y < Hin && x >= 0 && x < Win;
+        gofb[i] = ok ? 4u * (unsigned)(y * Win + x) : 0u;
+        lofw[i] = ok ? ir * C::PI + ic : C::PLANE + lane;
+        if (inr && !ok) {
+#pragma unroll
+            for (int pl = 0; pl < (ALL ? kFeat : 4); ++pl) lds[pl * C::PLANE_P + ir * C::PI + ic] = 0.f;
+        }
     }
+    const float* const base = in.p + (long)b * in.sb;
     float stage[C::NL][2], afrag_next[16];
     auto fetch = [&](int g) {
-        const float* p0 = in.p + (long)b * in.sb + (long)(2 * g) * in.sc;
+        unsigned off[C::NL], aoff = 4u * lane;
 #pragma unroll
         for (int i = 0; i < C::NL; ++i) {
-            stage[i][0] = p0[goff[i]];
-            stage[i][1] = p0[in.sc + goff[i]];
+            off[i] = gofb[i];
+            asm volatile("" : "+v"(off[i]));
+        }
+        asm volatile("" : "+v"(aoff));
+        const char* p0 = reinterpret_cast<const char*>(base + (long)(2 * g) * in.sc);
+        const char* p1 = reinterpret_cast<const char*>(base + (long)(2 * g + 1) * in.sc);
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            stage[i][0] = *reinterpret_cast<const float*>(p0 + off[i]);
+            stage[i][1] = *reinterpret_cast<const float*>(p1 + off[i]);
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) afrag_next[j] = afr[(g * 16 + j) * 64 + lane];
+        for (int j = 0; j < 16; ++j) afrag_next[j] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(afr + (g * 16 + j) * 64) + aoff);
     };
     // B operand for window row wr, column offset o (= ix - X + 2, 0..4): staged[(wy*R + wr + q) * PI + 16*wx + n + o]
     const int bbase = (wy * C::R + q) * C::PI + 16 * wx + n;
@@ -1169,29 +1198,26 @@ __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* _
 #pragma unroll
         for (int c = 0; c < kFeat; ++c)
 #pragma unroll
-            for (int i = 0; i < C::NL; ++i) st[c][i] = in.p[(long)b * in.sb + (long)c * in.sc + goff[i]];
+            for (int i = 0; i < C::NL; ++i) st[c][i] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (long)c * in.sc) + gofb[i]);
 #pragma unroll
         for (int j = 0; j < 16; ++j) afrag_next[j] = afr[j * 64 + lane];
 #pragma unroll
         for (int c = 0; c < kFeat; ++c)
 #pragma unroll
-            for (int i = 0; i < C::NL; ++i)
-                if (inmask >> i & 1u) lds[c * C::PLANE + loff[i]] = (okmask >> i & 1u) ? st[c][i] : 0.f;
+            for (int i = 0; i < C::NL; ++i) lds[c * C::PLANE_P + lofw[i]] = st[c][i];
         __syncthreads();
     } else {
         fetch(0);
     }
-#pragma unroll 1
+#pragma unroll
     for (int g = 0; g < kFeat / 2; ++g) {
-        float* t = lds + (ALL ? 2 * g : (g & 1) * 2) * C::PLANE;
+        float* t = lds + (ALL ? 2 * g : (g & 1) * 2) * C::PLANE_P;
         if (!ALL) {
 #pragma unroll
-            for (int i = 0; i < C::NL; ++i)
-                if (inmask >> i & 1u) {
-                    const bool ok = okmask >> i & 1u;
-                    t[loff[i]] = ok ? stage[i][0] : 0.f;
-                    t[C::PLANE + loff[i]] = ok ? stage[i][1] : 0.f;
-                }
+            for (int i = 0; i < C::NL; ++i) {
+                t[lofw[i]] = stage[i][0];
+                t[C::PLANE_P + lofw[i]] = stage[i][1];
+            }
         }
         float afrag[16];
 #pragma unroll
@@ -1206,14 +1232,14 @@ __global__ __launch_bounds__(256) void k_up_mfma(Src in, Dst out, const float* _
         float bv[2][C::R];
 #pragma unroll
         for (int wr = 0; wr < C::R; ++wr) bv[0][wr] = t[bbase + wr * C::PI];
-    __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int st = 0; st < 10; ++st) {
             const int c = st / 5, o = st % 5;
             if (st + 1 < 10) {
                 const int c1 = (st + 1) / 5, o1 = (st + 1) % 5;
 #pragma unroll
-                for (int wr = 0; wr < C::R; ++wr) bv[(st + 1) & 1][wr] = t[c1 * C::PLANE + bbase + wr * C::PI + o1];
+                for (int wr = 0; wr < C::R; ++wr) bv[(st + 1) & 1][wr] = t[c1 * C::PLANE_P + bbase + wr * C::PI + o1];
             }
 #pragma unroll
             for (int wr = 0; wr < C::R; ++wr) {
@@ -1353,12 +1379,12 @@ void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin,
     if (Wout > 64) hipLaunchKernelGGL((k_down_mfma<4, false>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     else if (Wout > 32) {
         const dim3 g(cdiv_(Wout, 32), cdiv_(Hout, 16), batch);
-        const unsigned dl = spread_lds(2 * DnCfg<2>::PLANE * sizeof(float), (long)g.x * g.y * g.z);
+        const unsigned dl = spread_lds(2 * DnCfg<2>::PLANE_P * sizeof(float), (long)g.x * g.y * g.z);
         hipLaunchKernelGGL((k_down_mfma<2, false>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
     }
     else {
         const dim3 g(cdiv_(Wout, 16), cdiv_(Hout, 16), batch);
-        const unsigned dl = spread_lds(kFeat * DnCfg<1>::PLANE * sizeof(float), (long)g.x * g.y * g.z);
+        const unsigned dl = spread_lds(kFeat * DnCfg<1>::PLANE_P * sizeof(float), (long)g.x * g.y * g.z);
         hipLaunchKernelGGL((k_down_mfma<1, true>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
     }
 }
@@ -1366,10 +1392,13 @@ void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin,
 void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     // window rows -1 .. Hin-1
     static const int up_small = getenv("HN_UP_SMALL") ? atoi(getenv("HN_UP_SMALL")) : 64;
-    if (Win > up_small) hipLaunchKernelGGL((k_up_mfma<2, 8, false>), dim3(cdiv_(Win, 32), cdiv_(Hin + 1, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    // 22 window rows per block: the Hin + 1 = 129 (257) window rows of a 128^2 (256^2) input split into 6 (12)
+    // row blocks with 2 % padding instead of 9 x 16 with 10 %, and 4 x 6 x 32 = 768 blocks are exactly one
+    // round of 3 resident blocks per CU at 256^2 x 32 (16-row blocks: 1152 = 1.5 rounds)
+    if (Win > up_small) hipLaunchKernelGGL((k_up_mfma<2, 11, false>), dim3(cdiv_(Win, 32), cdiv_(Hin + 1, 22), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     else {
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
-        const unsigned dl = spread_lds(kFeat * UpCfg2<1, 5>::PLANE * sizeof(float), (long)g.x * g.y * g.z);
+        const unsigned dl = spread_lds(kFeat * UpCfg2<1, 5>::PLANE_P * sizeof(float), (long)g.x * g.y * g.z);
         hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
     }
 }
