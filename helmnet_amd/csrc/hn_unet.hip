@@ -455,7 +455,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // state = conv_state(cat[out, state_old])                        (architectures.py:248)
         // Nothing downstream in this iteration reads the new state, so with a side stream the four
         // conv_state kernels are deferred until the main chain is in the small, latency-bound levels
-        // (they start after down(d+1)) and fill the CUs those leave idle.
+        // (see below) and fill the CUs those leave idle.
         if (side == nullptr) {
             ProfScope ps(ctx, KID_STATE0 + 3 * d, s);
             launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
@@ -468,15 +468,16 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                 dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                                 ctx->down[d], m, m);
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
-        if (side != nullptr) {
-            // after down(d): release conv_state(d-1) (and, at the last level, conv_state(d) as well)
-            HN_HIP(ctx, hipEventRecord(side_lane->ev[d], s));
-            const int e_lo = d > 0 ? d - 1 : depth, e_hi = d == depth - 1 ? d : d - 1;
-            for (int e = e_lo; e <= e_hi && e < depth; ++e) {
+        if (side != nullptr && d == depth - 1) {
+            // One release for all four conv_state kernels, after the last down: every skip tensor exists, and
+            // the main chain is entering its small, latency-bound levels, whose idle CUs the side stream
+            // fills.  (An event record costs the main stream a ~6 us bubble, so there is exactly one.)
+            HN_HIP(ctx, hipEventRecord(side_lane->ev[0], s));
+            HN_HIP(ctx, hipStreamWaitEvent(side, side_lane->ev[0], 0));
+            for (int e = 0; e < depth; ++e) {
                 const int me = n >> e;
                 const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
                 const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
-                HN_HIP(ctx, hipStreamWaitEvent(side, side_lane->ev[d], 0));
                 ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
                 launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
             }
