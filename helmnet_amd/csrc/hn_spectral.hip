@@ -130,41 +130,48 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, con
     }
 }
 
+// Everything one thread needs from the 1-D tables of an axis, fetched once per kernel (one memory round
+// trip together with the caller's first data loads).
+template <int N>
+struct AxisTab {
+    Twiddles<N> tw;
+    float k1[4], k2[4];
+    float2 ca[4], cb[4];
+    __device__ __forceinline__ void load(int j, const SpecPtrs& t) {
+        constexpr int T = N / 4;
+        tw.load(j, t.tw);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            k1[q] = t.k1[j + q * T];
+            k2[q] = t.k2[j + q * T];
+            ca[q] = t.a[j + q * T];
+            cb[q] = t.b[j + q * T];
+        }
+    }
+};
+
 // forward transform, two derivative multipliers, two inverse transforms, PML coefficients.
 // in: v[t] = u[j + t*T] along the axis;  out: acc[t] = (a*du + b*ddu)[j + t*T]
 template <int N, int STRIDE>
-__device__ __forceinline__ void axis_operator(float2 (&v)[4], float2 (&acc)[4], float2* buf, int j, const SpecPtrs& t) {
-    constexpr int T = N / 4;
-    // all table reads up front (one memory round trip together with the caller's loads)
-    Twiddles<N> tw;
-    tw.load(j, t.tw);
-    float k1[4], k2[4];
-    float2 ca[4], cb[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        k1[q] = t.k1[j + q * T];
-        k2[q] = t.k2[j + q * T];
-        ca[q] = t.a[j + q * T];
-        cb[q] = t.b[j + q * T];
-    }
-    fft_pass<N, STRIDE, false>(v, buf, j, tw);
+__device__ __forceinline__ void axis_operator(float2 (&v)[4], float2 (&acc)[4], float2* buf, int j, const AxisTab<N>& t) {
+    fft_pass<N, STRIDE, false>(v, buf, j, t.tw);
     float2 U[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         U[q] = v[q];
-        v[q] = make_float2(-U[q].y * k1[q], U[q].x * k1[q]);  // (0, k) * U   (spectral.py:50, 281)
+        v[q] = make_float2(-U[q].y * t.k1[q], U[q].x * t.k1[q]);  // (0, k) * U   (spectral.py:50, 281)
     }
-    fft_pass<N, STRIDE, true>(v, buf, j, tw);
+    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        acc[q] = cmul(ca[q], v[q]);
-        v[q] = make_float2(k2[q] * U[q].x, k2[q] * U[q].y);  // (-k^2, 0) * U (spectral.py:52, 283)
+        acc[q] = cmul(t.ca[q], v[q]);
+        v[q] = make_float2(t.k2[q] * U[q].x, t.k2[q] * U[q].y);  // (-k^2, 0) * U (spectral.py:52, 283)
     }
-    fft_pass<N, STRIDE, true>(v, buf, j, tw);
+    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
     constexpr float inv_n = 1.0f / N;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float2 d = cmul(cb[q], v[q]);
+        const float2 d = cmul(t.cb[q], v[q]);
         acc[q] = make_float2((acc[q].x + d.x) * inv_n, (acc[q].y + d.y) * inv_n);
     }
 }
@@ -173,7 +180,11 @@ template <int N>
 struct RowCfg {
     static constexpr int T = N / 4;
     static constexpr int R0 = (256 / T) > 0 ? (256 / T) : 1;
-    static constexpr int R = R0 < N ? R0 : N;  // rows per block
+    static constexpr int R = R0 < N ? R0 : N;  // rows per block and pass
+    // rows a thread group handles one after the other, the next row's HBM operands in flight behind the
+    // current row's transforms (the pass is latency-bound: without this every wave of the launch loads,
+    // then computes, then stores in lock step)
+    static constexpr int RPW = (N % (2 * R) == 0) ? 2 : 1;
 };
 
 // Column pass: out = ay*dy + by*ddy.  Block = C columns x N/4 butterfly threads; consecutive
@@ -193,7 +204,9 @@ __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict
         const long o = (long)(j + q * T) * N;
         v[q] = make_float2(pre[o], pre[o + plane]);
     }
-    axis_operator<N, C>(v, acc, buf + c, j, t);
+    AxisTab<N> tab;
+    tab.load(j, t);
+    axis_operator<N, C>(v, acc, buf + c, j, tab);
     float* po = out + (long)blockIdx.y * 2 * plane + col;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -206,54 +219,69 @@ __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict
 // Row pass: out = [out +] ax*dx + bx*ddx [+ k_sq*u - src]; optional per-sample sum of squares.
 // FLAGS: 1 = add the partial result already in `out` (column pass), 2 = residual terms.
 template <int N>
+struct RowOperands {  // everything one row still needs from HBM, requested in one go
+    float2 u[4], part[4], sv[4];
+    float kq[4];
+    __device__ __forceinline__ void load(const float* __restrict__ wf, const float* __restrict__ out, const float* __restrict__ ksq,
+                                         const float* __restrict__ src, long src_sb, int b, int row, int j, int flags) {
+        constexpr int T = N / 4;
+        const long plane = (long)N * N, ro = (long)row * N;
+        const float* pre = wf + (long)b * 2 * plane + ro;
+        const float* po = out + (long)b * 2 * plane + ro;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = j + q * T;
+            u[q] = make_float2(pre[x], pre[plane + x]);
+            part[q] = make_float2(0.f, 0.f);
+            sv[q] = make_float2(0.f, 0.f);
+            kq[q] = 0.f;
+            if (flags & 1) part[q] = make_float2(po[x], po[plane + x]);
+            if (flags & 2) {
+                kq[q] = ksq[(long)b * plane + ro + x];
+                const float* ps = src + (long)b * src_sb + ro + x;
+                sv[q] = make_float2(ps[0], ps[plane]);
+            }
+        }
+    }
+};
+
+template <int N>
 __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
     const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
     const float* __restrict__ src, long src_sb, SpecPtrs t, int flags, float* __restrict__ sumsq) {
-    constexpr int T = RowCfg<N>::T, R = RowCfg<N>::R;
+    constexpr int T = RowCfg<N>::T, R = RowCfg<N>::R, RPW = RowCfg<N>::RPW;
     __shared__ float2 buf[N * R];
     __shared__ float red[(T * R + 63) / 64];
     const int j = threadIdx.x, ry = threadIdx.y;
-    const int row = blockIdx.x * R + ry, b = blockIdx.y;
+    const int row0 = blockIdx.x * (R * RPW) + ry, b = blockIdx.y;
     const long plane = (long)N * N;
-    const long ro = (long)row * N;
-    const float* pre = wf + (long)b * 2 * plane + ro;
-    float2 u[4], v[4], acc[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        u[q] = make_float2(pre[j + q * T], pre[plane + j + q * T]);
-        v[q] = u[q];
-    }
-    // everything this row still needs from HBM is requested NOW, so that there is one memory round trip
-    // per wave instead of two (the kernel is latency-bound: waves spend 80 % of their life in s_waitcnt)
-    float* po = out + (long)b * 2 * plane + ro;
-    float2 part[4], sv[4];
-    float kq[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int x = j + q * T;
-        part[q] = make_float2(0.f, 0.f);
-        sv[q] = make_float2(0.f, 0.f);
-        kq[q] = 0.f;
-        if (flags & 1) part[q] = make_float2(po[x], po[plane + x]);
-        if (flags & 2) {
-            kq[q] = ksq[(long)b * plane + ro + x];
-            const float* ps = src + (long)b * src_sb + ro + x;
-            sv[q] = make_float2(ps[0], ps[plane]);
-        }
-    }
-    axis_operator<N, 1>(v, acc, buf + ry * N, j, t);
+    RowOperands<N> cur, nxt;
+    cur.load(wf, out, ksq, src, src_sb, b, row0, j, flags);
+    AxisTab<N> tab;
+    tab.load(j, t);
     float ss = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int x = j + q * T;
-        float re = acc[q].x + part[q].x, im = acc[q].y + part[q].y;
-        if (flags & 2) {
-            re = re + kq[q] * u[q].x - sv[q].x;
-            im = im + kq[q] * u[q].y - sv[q].y;
+    for (int i = 0; i < RPW; ++i) {
+        const int row = row0 + i * R;
+        if (i + 1 < RPW) nxt.load(wf, out, ksq, src, src_sb, b, row + R, j, flags);
+        float2 v[4], acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = cur.u[q];
+        axis_operator<N, 1>(v, acc, buf + ry * N, j, tab);
+        float* po = out + (long)b * 2 * plane + (long)row * N;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int x = j + q * T;
+            float re = acc[q].x + cur.part[q].x, im = acc[q].y + cur.part[q].y;
+            if (flags & 2) {
+                re = re + cur.kq[q] * cur.u[q].x - cur.sv[q].x;
+                im = im + cur.kq[q] * cur.u[q].y - cur.sv[q].y;
+            }
+            po[x] = re;
+            po[plane + x] = im;
+            ss += re * re + im * im;
         }
-        po[x] = re;
-        po[plane + x] = im;
-        ss += re * re + im * im;
+        if (i + 1 < RPW) cur = nxt;
     }
     if (sumsq != nullptr) {
 #pragma unroll
@@ -317,7 +345,7 @@ void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, con
     }
     constexpr int R = RowCfg<N>::R;
     ProfScope ps(ctx, KID_SPEC_ROWS, s);
-    hipLaunchKernelGGL((k_spec_rows<N>), dim3(N / R, batch), dim3(T, R), 0, s, wf, out, ksq, src, src_sb, p,
+    hipLaunchKernelGGL((k_spec_rows<N>), dim3(N / (R * RowCfg<N>::RPW), batch), dim3(T, R), 0, s, wf, out, ksq, src, src_sb, p,
                        1 | (resid ? 2 : 0), sumsq);
 }
 
