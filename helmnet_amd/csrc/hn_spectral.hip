@@ -184,35 +184,60 @@ struct RowCfg {
     // rows a thread group handles one after the other, the next row's HBM operands in flight behind the
     // current row's transforms (the pass is latency-bound: without this every wave of the launch loads,
     // then computes, then stores in lock step)
-    static constexpr int RPW = (N % (2 * R) == 0) ? 2 : 1;
+    // measured at 256^2 x 32: 33.6 us (1 row) -> 22.5 (2) -> 20.5 (4) -> 25.2 (8)
+    static constexpr int RPW = (N >= 256 && N % (4 * R) == 0) ? 4 : (N % (2 * R) == 0) ? 2 : 1;
 };
 
 // Column pass: out = ay*dy + by*ddy.  Block = C columns x N/4 butterfly threads; consecutive
-// threads own consecutive columns so each global access is a C*4-byte row segment.
+// threads own consecutive columns so each global access is a C*4-byte row segment.  A block walks
+// CPW groups of C columns, the next group's loads in flight behind the current group's transforms.
+template <int N, int C>
+struct ColCfg {
+    // measured at 256^2 x 32: 20.8 us (1 group) -> 18.8 (2) -> 28.8 (4: only 128 blocks left)
+    static constexpr int CPW = (N >= 256 && N % (2 * C) == 0) ? 2 : 1;
+};
+
 template <int N, int C>
 __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict__ wf, float* __restrict__ out,
                                                           SpecPtrs t) {
-    constexpr int T = N / 4;
+    constexpr int T = N / 4, CPW = ColCfg<N, C>::CPW;
     __shared__ float2 buf[N * C];
     const int c = threadIdx.x, j = threadIdx.y;
-    const int col = blockIdx.x * C + c;
+    const int col0 = blockIdx.x * (C * CPW) + c;
     const long plane = (long)N * N;
-    const float* pre = wf + (long)blockIdx.y * 2 * plane + col;
-    float2 v[4], acc[4];
+    const float* pre = wf + (long)blockIdx.y * 2 * plane + col0;
+    float* po = out + (long)blockIdx.y * 2 * plane + col0;
+    float2 cur[4], nxt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const long o = (long)(j + q * T) * N;
-        v[q] = make_float2(pre[o], pre[o + plane]);
+        cur[q] = make_float2(pre[o], pre[o + plane]);
     }
     AxisTab<N> tab;
     tab.load(j, t);
-    axis_operator<N, C>(v, acc, buf + c, j, tab);
-    float* po = out + (long)blockIdx.y * 2 * plane + col;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const long o = (long)(j + q * T) * N;
-        po[o] = acc[q].x;
-        po[o + plane] = acc[q].y;
+    for (int i = 0; i < CPW; ++i) {
+        if (i + 1 < CPW) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long o = (long)(j + q * T) * N + (i + 1) * C;
+                nxt[q] = make_float2(pre[o], pre[o + plane]);
+            }
+        }
+        float2 v[4], acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = cur[q];
+        axis_operator<N, C>(v, acc, buf + c, j, tab);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long o = (long)(j + q * T) * N + i * C;
+            po[o] = acc[q].x;
+            po[o + plane] = acc[q].y;
+        }
+        if (i + 1 < CPW) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+        }
     }
 }
 
@@ -341,7 +366,7 @@ void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, con
     constexpr int C = (1024 / T) < 16 ? (1024 / T) : 16;
     {
         ProfScope ps(ctx, KID_SPEC_COLS, s);
-        hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / C, batch), dim3(C, T), 0, s, wf, out, p);
+        hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / (C * ColCfg<N, C>::CPW), batch), dim3(C, T), 0, s, wf, out, p);
     }
     constexpr int R = RowCfg<N>::R;
     ProfScope ps(ctx, KID_SPEC_ROWS, s);
