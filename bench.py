@@ -204,7 +204,7 @@ def main():
                         "traffic_source": traffic_src,
                         "avg_launch_us": round(avg_s * 1e6, 2), "launches": dom_cnt, "bytes_per_launch": byts}
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # rank 0 at N = 1 only (torchrun pins OMP threads to 1 per rank)
             its, cnt, secs = cpu_baseline(torch.from_numpy(sos_np), n, loc)
             cpu = {"value": round(its, 4), "unit": "iterations/s", "cores": torch.get_num_threads(), "kind": "port",
                    "sample": f"{cnt} single_step iterations of the same {B}x{n}x{n} batch ({secs:.1f} s), "

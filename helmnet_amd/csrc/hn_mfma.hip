@@ -1291,7 +1291,8 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
-    if (W >= 128 && even && !persistent && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
+    static const int strip_min = getenv("HN_STRIP_MIN") ? atoi(getenv("HN_STRIP_MIN")) : 128;
+    if (W >= strip_min && even && !persistent && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
         static const int dyn_lds = getenv("HN_DC_DYNLDS") ? atoi(getenv("HN_DC_DYNLDS")) : 0;  // experiments: caps blocks per CU
         hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), dyn_lds, s, a, b, c, out, w, e, H, W);
     } else if (W >= 64 && even && persistent) {
