@@ -21,6 +21,8 @@
 #include <cstdlib>
 
 #include "hn_internal.h"
+#include <cstring>
+#include <cstdint>
 
 namespace hn {
 namespace {
@@ -122,6 +124,8 @@ struct McW {
     const float* slope;
     const float* a2;  // conv2 A fragments [8][3][64]
     const float* b2;  // [8]
+    const void* a1s;  // split-bf16 conv1 fragments [groups of 8 ci][3 dy][3 parts][64 lanes] x 8 bf16 (k_dc_bf3), may be null
+    const void* a2s;  // split-bf16 conv2 fragments [1][3][3][64] x 8 bf16
 };
 struct McEpi {
     const float* ow;  // outc weight [8][2]
@@ -667,6 +671,334 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
     }
     STAMP2(8);  // epilogue
     STAMP2_FLUSH();
+}
+
+// ------------------------------------------------------------------------------------------
+// EXPERIMENT (HN_UNET_IMPL=bf16x3, never the default): the strip DoubleConv on the bf16 matrix core with
+// fp32-accurate split products.  A normal fp32 x is exactly h + m + l with three bf16 terms; the
+// product block keeps 6 of the 9 cross terms (hh, hm, mh, hl, lh, mm -- the dropped ones are below
+// 2^-24 relative) and accumulates in fp32 inside v_mfma_f32_16x16x32_bf16.  tools/ubench_bf16x3.hip:
+// error 9.3e-8 of sum|a b| on K = 160 dot products (a plain fp32 FMA chain: 1.2e-7), and 1.6 - 2.1 x the
+// fp32-MFMA rate for the same convolution.  Results differ from the fp32-MFMA path in the last bits, so
+// it has its own parity run (tests under HN_UNET_IMPL=bf16x3) and is reported separately.
+//   K = 32 = 4 window positions (q) x 8 input channels, M = (co, dxo) as in the fp32 kernels.
+//   B operand: one ds_read_b128 = 8 channels of one pixel of one part; LDS holds [part][row][x][8 ch]
+//   bf16 (single buffer of 8 channels = 64 KB; the next group's loads are in flight in registers).
+// ------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+template <int CA, int CB, int CC>
+struct B3Cfg {
+    static constexpr int TH = 16, TW = 64;
+    static constexpr int CIN = CA + CB + CC, NG = (CIN + 7) / 8;
+    static constexpr int IR = TH + 4, PI = TW + 4;          // staged rows / pixels per row
+    static constexpr int ROWB = PI * 16, PARTB = IR * ROWB; // bytes: one pixel = 8 bf16
+    static constexpr int MR = TH + 2, MPARTB = MR * ROWB;
+    static constexpr int NR1 = 9, NR2 = 8;
+    static constexpr int NP2 = IR * PI / 2, NL = cdiv_(NP2, 256);
+    static constexpr int LDS_BYTES = 3 * PARTB;             // 65280; the mid tensor (3 * MPARTB = 58752) reuses it
+    static constexpr bool SCALED = CC > 0;
+};
+
+// 18 MFMAs of one staged row against up to three output rows (dy = 0, 1, 2); consecutive MFMAs hit different accumulators
+template <int NR>
+__device__ __forceinline__ void bf3_row(f32x4 (&acc)[NR], int j, const bf16x8 (&a)[3][3], const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
+    constexpr int AP[6] = {2, 0, 1, 1, 0, 0};  // A part of term t (0 = h, 1 = m, 2 = l), small terms first
+    constexpr int BP[6] = {0, 2, 1, 0, 1, 0};  // B part
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int r = j - dy;
+            if (r >= 0 && r < NR) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dy][AP[t]], BP[t] == 0 ? bh : BP[t] == 1 ? bm : bl, acc[r], 0, 0, 0);
+        }
+}
+
+template <int CA, int CB, int CC, int EPI>
+__global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
+    using C = B3Cfg<CA, CB, CC>;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int strip = wave & 1, half = wave >> 1;
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+
+    // ---- staging plan: pixel pairs (W even) ----
+    unsigned gofb[C::NL];
+    int lofb[C::NL];
+    bool okm[C::NL];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * 256;
+        const int ir = e / (C::PI / 2), ic = 2 * (e - ir * (C::PI / 2));
+        const int y = y0 - 2 + ir, x = x0 - 2 + ic;
+        const bool in = e < C::NP2;
+        okm[i] = in && y >= 0 && y < H && x >= 0 && x < W;
+        gofb[i] = okm[i] ? (unsigned)(y * W + x) * 4u : 0u;
+        lofb[i] = (ir * C::PI + ic) * 16;
+        if (in && !okm[i]) {  // zero padding, written once: commits skip these positions
+            bf16x8 z;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<bf16x8*>(lds + pl * C::PARTB + lofb[i]) = z;
+                *reinterpret_cast<bf16x8*>(lds + pl * C::PARTB + lofb[i] + 16) = z;
+            }
+        }
+    }
+    const float* const base_a = sa.p + (long)b * sa.sb;
+    const float* const base_b = sb.p + (long)b * sb.sb;
+    const float* const base_c = sc.p + (long)b * sc.sb;
+    float2 stage[8][C::NL];
+    auto fetch = [&](int g) {
+        unsigned off[C::NL];
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            off[i] = gofb[i];
+            asm volatile("" : "+v"(off[i]));
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 8 * g + j;
+            if (c < C::CIN) {
+                const float* p0 = c < CA ? base_a + (long)c * sa.sc : c < CA + CB ? base_b + (long)(c - CA) * sb.sc : base_c + (long)(c - CA - CB) * sc.sc;
+#pragma unroll
+                for (int i = 0; i < C::NL; ++i) stage[j][i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p0) + off[i]);
+            }
+        }
+    };
+    auto commit = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            if (okm[i]) {
+#pragma unroll
+                for (int px = 0; px < 2; ++px) {
+                    bf16x8 vh, vm, vl;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int c = 8 * g + j;
+                        float v = 0.f;
+                        if (c < C::CIN) {
+                            v = px ? stage[j][i].y : stage[j][i].x;
+                            if (C::SCALED) v *= (c < CA ? sa.scale : c < CA + CB ? sb.scale : sc.scale);
+                        }
+                        __bf16 h, m, l;
+                        split3(v, h, m, l);
+                        vh[j] = h; vm[j] = m; vl[j] = l;
+                    }
+                    *reinterpret_cast<bf16x8*>(lds + 0 * C::PARTB + lofb[i] + 16 * px) = vh;
+                    *reinterpret_cast<bf16x8*>(lds + 1 * C::PARTB + lofb[i] + 16 * px) = vm;
+                    *reinterpret_cast<bf16x8*>(lds + 2 * C::PARTB + lofb[i] + 16 * px) = vl;
+                }
+            }
+        }
+    };
+
+    // ---- conv1 ----
+    const int rb1 = C::NR1 * half;
+    const int bs1 = (rb1 * C::PI + 2 * (16 * strip + n) + q) * 16;
+    const bool has_v = wave < 2;
+    const int vrow0 = wave == 0 ? 0 : 2;
+    const int bsv = ((vrow0 + n) * C::PI + 64 + q) * 16;
+    const float bias0 = w.b1[2 * q], bias1 = w.b1[2 * q + 1];
+    f32x4 acc1[C::NR1], accv[1];
+    accv[0] = (f32x4){bias0, bias0, bias1, bias1};
+#pragma unroll
+    for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){bias0, bias0, bias1, bias1};
+    const bf16x8* a1s = reinterpret_cast<const bf16x8*>(w.a1s) + lane;
+
+    fetch(0);
+#pragma unroll
+    for (int g = 0; g < C::NG; ++g) {
+        if (g > 0) __syncthreads();  // every wave is done reading the previous group
+        commit(g);
+        bf16x8 a[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt) a[dy][pt] = a1s[((g * 3 + dy) * 3 + pt) * 64];
+        __syncthreads();
+        if (g + 1 < C::NG) fetch(g + 1);
+        bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + bs1), bm = *reinterpret_cast<const bf16x8*>(lds + C::PARTB + bs1),
+               bl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::PARTB + bs1);
+#pragma unroll
+        for (int j = 0; j < C::NR1 + 2; ++j) {
+            bf16x8 nh = bh, nm = bm, nl = bl;
+            if (j + 1 < C::NR1 + 2) {
+                nh = *reinterpret_cast<const bf16x8*>(lds + bs1 + (j + 1) * C::ROWB);
+                nm = *reinterpret_cast<const bf16x8*>(lds + C::PARTB + bs1 + (j + 1) * C::ROWB);
+                nl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::PARTB + bs1 + (j + 1) * C::ROWB);
+            }
+            bf3_row<C::NR1>(acc1, j, a, bh, bm, bl);
+            bh = nh; bm = nm; bl = nl;
+        }
+        if (has_v) {  // pair column 32 (mid columns 64, 65): n indexes the mid row
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(lds + bsv + dy * C::ROWB), vm = *reinterpret_cast<const bf16x8*>(lds + C::PARTB + bsv + dy * C::ROWB),
+                             vl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::PARTB + bsv + dy * C::ROWB);
+                bf3_row<1>(accv, dy, a, vh, vm, vl);  // j = dy: only the term r = 0 survives
+            }
+        }
+    }
+    bf16x8 a2[3][3];
+    {
+        const bf16x8* a2s = reinterpret_cast<const bf16x8*>(w.a2s) + lane;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int pt = 0; pt < 3; ++pt) a2[dy][pt] = a2s[(dy * 3 + pt) * 64];
+    }
+    __syncthreads();  // staged input is dead: the mid tensor takes its place
+    {
+        const float slope = w.slope[0];
+        const float sel = slope <= 1.f ? __builtin_inff() : -__builtin_inff();
+        auto put = [&](const f32x4& a, int mrow, int pc, f32x2 mk, f32x2 sk) {
+            const f32x2 lo = (f32x2){a[0], a[1]}, hi = (f32x2){a[2], a[3]};
+            const f32x2 lm = lo * mk, ls = lo * sk, hm = hi * mk, hs = hi * sk;
+            const float v00 = __builtin_amdgcn_fmed3f(lm[0], ls[0], sel), v01 = __builtin_amdgcn_fmed3f(lm[1], ls[1], sel);  // channel 2q, pixels 0 / 1
+            const float v10 = __builtin_amdgcn_fmed3f(hm[0], hs[0], sel), v11 = __builtin_amdgcn_fmed3f(hm[1], hs[1], sel);  // channel 2q + 1
+            __bf16 h00, m00, l00, h01, m01, l01, h10, m10, l10, h11, m11, l11;
+            split3(v00, h00, m00, l00); split3(v01, h01, m01, l01); split3(v10, h10, m10, l10); split3(v11, h11, m11, l11);
+            unsigned char* m = lds + (mrow * C::PI + 2 * pc) * 16 + 4 * q;  // [pixel][8 ch] bf16: channels 2q, 2q + 1
+            *reinterpret_cast<bf16x2*>(m) = (bf16x2){h00, h10};
+            *reinterpret_cast<bf16x2*>(m + 16) = (bf16x2){h01, h11};
+            *reinterpret_cast<bf16x2*>(m + C::MPARTB) = (bf16x2){m00, m10};
+            *reinterpret_cast<bf16x2*>(m + C::MPARTB + 16) = (bf16x2){m01, m11};
+            *reinterpret_cast<bf16x2*>(m + 2 * C::MPARTB) = (bf16x2){l00, l10};
+            *reinterpret_cast<bf16x2*>(m + 2 * C::MPARTB + 16) = (bf16x2){l01, l11};
+        };
+        {
+            const int pc = 16 * strip + n, x = x0 - 1 + 2 * pc;
+            const float mx0 = (x >= 0 && x < W) ? 1.f : 0.f, mx1 = (x + 1 >= 0 && x + 1 < W) ? 1.f : 0.f;
+            const f32x2 mk = (f32x2){mx0, mx1}, sk = (f32x2){mx0 * slope, mx1 * slope};
+            const f32x2 zz = (f32x2){0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < C::NR1; ++r) {
+                const int y = y0 - 1 + rb1 + r;
+                const bool yin = y >= 0 && y < H;
+                put(acc1[r], rb1 + r, pc, yin ? mk : zz, yin ? sk : zz);
+            }
+        }
+        if (has_v && (wave == 0 || n >= 14)) {
+            const int y = y0 - 1 + vrow0 + n, x = x0 + 63;
+            const bool yin = y >= 0 && y < H;
+            const float m0 = (yin && x < W) ? 1.f : 0.f, m1 = (yin && x + 1 < W) ? 1.f : 0.f;
+            put(accv[0], vrow0 + n, 32, (f32x2){m0, m1}, (f32x2){m0 * slope, m1 * slope});
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 ----
+    const int rb2 = C::NR2 * half;
+    const int bs2 = (rb2 * C::PI + 2 * (16 * strip + n) + q) * 16;
+    const float bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
+    f32x4 acc2[C::NR2];
+#pragma unroll
+    for (int r = 0; r < C::NR2; ++r) acc2[r] = (f32x4){bo0, bo0, bo1, bo1};
+    const int ox = x0 + 2 * (16 * strip + n);
+    const int yb = y0 + rb2;
+    const bool xin = ox < W;
+    const long plane = (long)H * W;
+    const unsigned wvoff = xin ? 4u * (unsigned)ox : 0u;
+    float aoc0 = 0.f, aoc1 = 0.f, ob_re = 0.f, ob_im = 0.f;
+    float2 wf_old[EPI == 1 ? C::NR2 : 1][2];
+    if (EPI == 1) {
+        const int m = lane & 15;
+        if (m < 2) {
+            aoc0 = epi.ow[(2 * q) * 2 + m];
+            aoc1 = epi.ow[(2 * q + 1) * 2 + m];
+        }
+        ob_re = epi.ob[0];
+        ob_im = epi.ob[1];
+        if (epi.wf != nullptr && q == 0) {
+            unsigned off = wvoff;
+            asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int r = 0; r < C::NR2; ++r) {
+                const int y = yb + r < H ? yb + r : 0;
+                const char* row = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane + (long)y * W);
+                wf_old[r][0] = *reinterpret_cast<const float2*>(row + off);
+                wf_old[r][1] = *reinterpret_cast<const float2*>(row + 4 * plane + off);
+            }
+        }
+    }
+    {
+        bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + bs2), bm = *reinterpret_cast<const bf16x8*>(lds + C::MPARTB + bs2),
+               bl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::MPARTB + bs2);
+#pragma unroll
+        for (int j = 0; j < C::NR2 + 2; ++j) {
+            bf16x8 nh = bh, nm = bm, nl = bl;
+            if (j + 1 < C::NR2 + 2) {
+                nh = *reinterpret_cast<const bf16x8*>(lds + bs2 + (j + 1) * C::ROWB);
+                nm = *reinterpret_cast<const bf16x8*>(lds + C::MPARTB + bs2 + (j + 1) * C::ROWB);
+                nl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::MPARTB + bs2 + (j + 1) * C::ROWB);
+            }
+            bf3_row<C::NR2>(acc2, j, a2, bh, bm, bl);
+            bh = nh; bm = nm; bl = nl;
+        }
+    }
+    if (EPI == 0) {
+        if (xin) {
+            unsigned off = 4u * (unsigned)((2 * q) * (int)out.sc + ox);
+            asm volatile("" : "+v"(off));
+#pragma unroll
+            for (int r = 0; r < C::NR2; ++r) {
+                if (yb + r < H) {
+                    char* row = reinterpret_cast<char*>(out.p + (long)b * out.sb + (long)(yb + r) * W);
+                    *reinterpret_cast<float2*>(row + off) = make_float2(acc2[r][0], acc2[r][1]);
+                    *reinterpret_cast<float2*>(row + 4 * out.sc + off) = make_float2(acc2[r][2], acc2[r][3]);
+                }
+            }
+        }
+    } else {
+        unsigned off = wvoff;
+        asm volatile("" : "+v"(off));
+#pragma unroll
+        for (int h = 0; h < C::NR2; h += 4) {
+            f32x4 dA[4], dB[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dA[r] = mfma4(aoc0, acc2[h + r][0], (f32x4){ob_re, ob_im, 0.f, 0.f});
+                dB[r] = mfma4(aoc0, acc2[h + r][1], (f32x4){ob_re, ob_im, 0.f, 0.f});
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dA[r] = mfma4(aoc1, acc2[h + r][2], dA[r]);
+                dB[r] = mfma4(aoc1, acc2[h + r][3], dB[r]);
+            }
+            if (q == 0 && xin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (yb + h + r < H) {
+                        const long ro = (long)b * 2 * plane + (long)(yb + h + r) * W;
+                        const float re0 = dA[r][0], im0 = dA[r][1], re1 = dB[r][0], im1 = dB[r][1];
+                        if (epi.d_out) {
+                            char* row = reinterpret_cast<char*>(epi.d_out + ro);
+                            *reinterpret_cast<float2*>(row + off) = make_float2(re0, re1);
+                            *reinterpret_cast<float2*>(row + 4 * plane + off) = make_float2(im0, im1);
+                        }
+                        if (epi.wf) {
+                            char* row = reinterpret_cast<char*>(epi.wf + ro);
+                            *reinterpret_cast<float2*>(row + off) = make_float2(div1000(re0) + wf_old[h + r][0].x, div1000(re1) + wf_old[h + r][0].y);
+                            *reinterpret_cast<float2*>(row + 4 * plane + off) = make_float2(div1000(im0) + wf_old[h + r][1].x, div1000(im1) + wf_old[h + r][1].y);
+                        }
+                    }
+                }
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1291,6 +1623,11 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
+    static const bool bf3 = getenv("HN_UNET_IMPL") != nullptr && std::strcmp(getenv("HN_UNET_IMPL"), "bf16x3") == 0;
+    if (bf3 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC>::SCALED)) {
+        hipLaunchKernelGGL((k_dc_bf3<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        return;
+    }
     static const int strip_min = getenv("HN_STRIP_MIN") ? atoi(getenv("HN_STRIP_MIN")) : 128;
     if (W >= strip_min && even && !persistent && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
         static const int dyn_lds = getenv("HN_DC_DYNLDS") ? atoi(getenv("HN_DC_DYNLDS")) : 0;  // experiments: caps blocks per CU
@@ -1335,6 +1672,37 @@ void pack_frag_3x3(const float* w, int cin, float* dst) {
                 dst[(ci * 3 + dy) * 64 + l] = (dx >= 0 && dx <= 2) ? w[((co * cin + ci) * 3 + dy) * 3 + dx] : 0.f;
             }
 }
+// split-bf16 fragments of a 3x3 conv (k_dc_bf3): [group of 8 ci][dy][part][64 lanes][8 bf16]; lane l -> (co, dxo) as
+// above, window position q = l >> 4, element e = channel 8 g + e; part 0 / 1 / 2 = h / m / l of w = h + m + l.
+static inline uint16_t bf16_rne(float x) {
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static inline float bf16_f(uint16_t h) {
+    const uint32_t u = (uint32_t)h << 16;
+    float f;
+    std::memcpy(&f, &u, 4);
+    return f;
+}
+size_t frag_3x3_split_floats(int cin) { return (size_t)((cin + 7) / 8) * 3 * 3 * 64 * 4; }  // 8 bf16 = 4 floats of storage
+void pack_frag_3x3_split(const float* w, int cin, float* dst_as_float) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dst_as_float);
+    const int ng = (cin + 7) / 8;
+    for (int g = 0; g < ng; ++g)
+        for (int dy = 0; dy < 3; ++dy)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = (l & 15) >> 1, dxo = l & 1, qq = l >> 4, dx = qq - dxo, ci = 8 * g + e;
+                    const float v = (dx >= 0 && dx <= 2 && ci < cin) ? w[((co * cin + ci) * 3 + dy) * 3 + dx] : 0.f;
+                    const uint16_t h = bf16_rne(v);
+                    const float r1 = v - bf16_f(h);
+                    const uint16_t m = bf16_rne(r1);
+                    const uint16_t lo = bf16_rne(r1 - bf16_f(m));
+                    const uint16_t part[3] = {h, m, lo};
+                    for (int pt = 0; pt < 3; ++pt) dst[((((size_t)g * 3 + dy) * 3 + pt) * 64 + l) * 8 + e] = part[pt];
+                }
+}
 // down conv, weight [8][8][8][8] (co, ci, ky, kx) -> [ci][kx][64]: lane -> (co, h = l&1, k = l>>4): w[co][ci][4h+k][kx]
 void pack_frag_down(const float* w, float* dst) {
     for (int ci = 0; ci < kFeat; ++ci)
@@ -1358,7 +1726,9 @@ void pack_frag_up(const float* w, float* dst) {
 
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s) {
-    const McW mw{frag1, w.b1, w.slope, frag2, w.b2};
+    const int cin = kind == 0 ? kInCh : kind == 1 ? kFeat + kState : kind == 2 ? kFeat : 2 * kFeat;
+    // hn_load_weights stores the split-bf16 fragments right behind the fp32 ones
+    const McW mw{frag1, w.b1, w.slope, frag2, w.b2, frag1 + (size_t)cin * 3 * 64, frag2 + (size_t)kFeat * 3 * 64};
     const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf};
     switch (kind) {
         case 0: launch_dc_mfma<2, 2, 2, 0>(a, b, c, out, mw, e, H, W, batch, s); break;          // inc
