@@ -102,11 +102,16 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=1, help="hn_step pipeline lanes (sub-batches on parallel streams); "
                     "2 gives about +5 %% it/s but kernels of the two lanes overlap, so per-kernel timings (roofline) blur")
+    ap.add_argument("--unet-impl", default=None, choices=["valu", "bf16x3"],
+                    help="experiments only (sets HN_UNET_IMPL): 'bf16x3' = split-bf16 DoubleConv kernels with fp32-accurate "
+                         "products; the default and the reported metric is the fp32 matrix-core path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel time table (stderr)")
     args = ap.parse_args()
 
     os.environ["HN_STREAMS"] = str(args.lanes)   # read by libhelmnet_hip.so when its first hn_step runs
+    if args.unet_impl:
+        os.environ["HN_UNET_IMPL"] = args.unet_impl
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -220,7 +225,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{n}x{n} ring-phantom SoS maps, batch={B} per GPU, point source {loc}, "
                                    "shipped jcp checkpoint weights, fp32 (BASELINE configs[1])",
-                       "batch_per_gpu": B, "domain": n, "lanes": args.lanes, "parallelism": f"dp{world} (batch shards, no data-path collective)"},
+                       "batch_per_gpu": B, "domain": n, "lanes": args.lanes, "unet_impl": args.unet_impl or "fp32-mfma", "parallelism": f"dp{world} (batch shards, no data-path collective)"},
             "sample_iterations_per_s": round(world * B * K / dt, 1),
             "unet_tflops": round(total_flops * K / dt / 1e12, 2),
             "residual_rmse_after_timed_steps": {"median": float(np.median(final_rmse)), "max": float(worst.max().item())},

@@ -246,6 +246,23 @@ def test_multiple_sources_and_variable_source(solver, weights):
     assert out["residual_norms"].shape == (25, 2)
 
 
+def test_split_bf16_experiment_keeps_the_parity_bar():
+    """HN_UNET_IMPL=bf16x3 (opt-in experiment: DoubleConvs on the bf16 matrix core with 3-term split operands and
+    fp32 accumulation) must meet the same bars as the default fp32 path; the library reads the switch at
+    first use, so it runs in a process of its own."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HN_UNET_IMPL="bf16x3")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_unet_impl.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["impl"] == "bf16x3"
+    for n in (256, 128):
+        assert out[f"single_step_{n}"]["wf"] <= 1e-5 and out[f"single_step_{n}"]["res"] <= 1e-5, out
+        assert out[f"unet_output_{n}"] <= 1e-5, out
+    assert out["cfg1_wf_linf_vs_reference"] <= 1e-4 and out["cfg1_rmse_rel"] <= 2e-2, out
+
+
 def test_error_behaviour(solver):
     from helmnet_amd import HybridNet, IterativeSolver
     with pytest.raises(NotImplementedError):

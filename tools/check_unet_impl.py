@@ -1,0 +1,53 @@
+"""Parity of an alternative UNet implementation (HN_UNET_IMPL, read by the library at first use, hence a
+process of its own): single_step against the CPU oracle on seeded inputs, and a 100-iteration free run
+against the default fp32 matrix-core path's committed golden trace.  Prints one JSON line.
+
+    HN_UNET_IMPL=bf16x3 python tools/check_unet_impl.py
+"""
+import json, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from golden_inputs import teacher_inputs
+from helmnet_amd import IterativeSolver
+from oracle import helmnet_oracle as O
+
+dev = torch.device("cuda:0")
+s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(dev)
+with np.load(os.path.join(ROOT, "tests", "golden", "jcp_weights.npz")) as z:
+    weights = {k: torch.from_numpy(z[k]) for k in z.files}
+out = {"impl": os.environ.get("HN_UNET_IMPL", "fp32-mfma")}
+for n, b in ((256, 2), (128, 2)):
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=77 + n).items()}
+    loc = [n // 4, n // 2]
+    s.set_domain_size(n, source_location=loc)
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    src = O.point_source_map(n, loc, 10.0)
+    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+    st = O.unflatten_states(ti["states"], n, 4)
+    want_wf, want_res, want_st = O.single_step(ti["wf"], k_sq_o, ti["res"], st, weights, src, t)
+    g = {k: v.to(dev) for k, v in ti.items()}
+    k_sq, _ = s.get_initials(g["sos"])
+    s.f.set_states(g["states"], flatten=True)
+    wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
+    out[f"single_step_{n}"] = {
+        "wf": ((wf2.cpu() - want_wf).abs().max() / want_wf.abs().max()).item(),
+        "res": ((res2.cpu() - want_res).abs().max() / want_res.abs().max()).item(),
+    }
+# the network output itself (single_step's wavefield error is dominated by the rounding of wf + d/1e3)
+from helmnet_amd import HybridNet
+for n in (256, 128):
+    net = HybridNet("prelu", 4, n, 8, 6, 2, 4)
+    net.load_state_dict(weights)
+    net.to(dev)
+    x = torch.randn(2, 6, n, n, generator=torch.Generator().manual_seed(11 + n))
+    net.clear_states(x.to(dev))
+    d = net(x.to(dev)).cpu()
+    want, _ = O.unet_forward(x, [torch.zeros(2, 2, m, m) for m in O.state_dims(n, 4)], weights)
+    out[f"unet_output_{n}"] = ((d - want).abs().max() / want.abs().max()).item()
+with np.load(os.path.join(ROOT, "tests", "golden", "free_run.npz")) as z:
+    s.set_domain_size(256, source_location=[30, 128])
+    o = s.forward(torch.ones(1, 1, 256, 256, device=dev), num_iterations=100)
+    out["cfg1_wf_linf_vs_reference"] = float(np.abs(o["wavefields"][0].cpu().numpy() - z["cfg1_wf_it100"]).max())
+    out["cfg1_rmse_rel"] = float(np.abs(o["residual_norms"].cpu().numpy() / z["cfg1_rmse"] - 1).max())
+print(json.dumps(out))

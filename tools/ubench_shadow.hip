@@ -1,9 +1,11 @@
+// (-DBF16: the same with v_mfma_f32_16x16x32_bf16)
 // Micro-benchmark: how many VALU instructions of the SAME wave fit in the shadow of an fp32 MFMA
 // (16x16x4, 32 matrix-pipe cycles)?  One wave per SIMD, 10 accumulators, K VALU ops per MFMA pinned
 // between the MFMAs with sched_group_barrier.  Reported as wall cycles per MFMA at 2.4 GHz.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 template <int K, int KIND, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k(const float* __restrict__ in, float* __restrict__ out, int steps) {
     const int lane = threadIdx.x & 63;
@@ -11,6 +13,11 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float* __restrict__ in, fl
 #pragma unroll
     for (int g = 0; g < 10; ++g) acc[g] = (f32x4){0, 0, 0, 0};
     const float a = in[lane], b = in[64 + lane];
+#ifdef BF16
+    bf16x8 a8, b8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a8[e] = (__bf16)in[(lane + e) & 255]; b8[e] = (__bf16)in[(lane + 3 * e + 7) & 255]; }
+#endif
     float v[8];
     int iv[8];
 #pragma unroll
@@ -18,7 +25,11 @@ __global__ __launch_bounds__(64 * WAVES) void k(const float* __restrict__ in, fl
     for (int st = 0; st < steps; ++st) {
 #pragma unroll
         for (int g = 0; g < 10; ++g) {
+#ifdef BF16
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a8, b8, acc[g], 0, 0, 0);
+#else
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[g], 0, 0, 0);
+#endif
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 if (KIND == 0) v[j & 7] = __builtin_fmaf(v[j & 7], 0.999f, 0.001f);
