@@ -224,11 +224,13 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             const float* w1 = blob + pos; pos += (size_t)cm * cin * 9 + cm + 1;
             const float* w2 = blob + pos; pos += (size_t)co * cm * 9 + co;
             if (cm != kFeat || co != kFeat) { off.push_back((size_t)-1); off.push_back((size_t)-1); return; }
-            // each fp32 fragment block is followed by its split-bf16 twin (launch_dc8 relies on this order)
+            // each fp32 fragment block is followed by its split-bf16 and fp16 twins (launch_dc8 relies on this order)
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3(w1, cin, fr.data() + off.back());
             { const size_t o = fr.size(); fr.resize(o + frag_3x3_split_floats(cin)); pack_frag_3x3_split(w1, cin, fr.data() + o); }
+            { const size_t o = fr.size(); fr.resize(o + frag_3x3_half_floats(cin)); pack_frag_3x3_half(w1, cin, fr.data() + o); }
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * 3 * 64); pack_frag_3x3(w2, kFeat, fr.data() + off.back());
             { const size_t o = fr.size(); fr.resize(o + frag_3x3_split_floats(kFeat)); pack_frag_3x3_split(w2, kFeat, fr.data() + o); }
+            { const size_t o = fr.size(); fr.resize(o + frag_3x3_half_floats(kFeat)); pack_frag_3x3_half(w2, kFeat, fr.data() + o); }
         };
         auto k8 = [&](bool up) {
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * kFeat * 64);

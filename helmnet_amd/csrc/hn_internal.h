@@ -154,6 +154,8 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
 void pack_frag_3x3(const float* w_oihw, int cin, float* dst);  // -> [cin][3][64]
 size_t frag_3x3_split_floats(int cin);                          // storage of the split-bf16 twin, in floats
 void pack_frag_3x3_split(const float* w_oihw, int cin, float* dst);  // -> [ceil(cin/8)][3 dy][3 parts][64][8 bf16]
+size_t frag_3x3_half_floats(int cin);
+void pack_frag_3x3_half(const float* w_oihw, int cin, float* dst);   // -> [ceil(cin/8)][3 dy][64][8 half]
 void pack_frag_down(const float* w_oihw, float* dst);          // -> [8][8][64]
 void pack_frag_up(const float* w_iohw, float* dst);            // -> [8][2][4][64]
 // kind: 0 inc (2+2+2 ch), 1 conv_signal (8+2), 2 bottleneck (8), 3 decoder (8+8; final_epi adds outc + wf update)

@@ -126,6 +126,8 @@ struct McW {
     const float* b2;  // [8]
     const void* a1s;  // split-bf16 conv1 fragments [groups of 8 ci][3 dy][3 parts][64 lanes] x 8 bf16 (k_dc_bf3), may be null
     const void* a2s;  // split-bf16 conv2 fragments [1][3][3][64] x 8 bf16
+    const void* a1h;  // fp16 conv1 fragments [groups][3 dy][64 lanes] x 8 half (mixed-precision mode)
+    const void* a2h;
 };
 struct McEpi {
     const float* ow;  // outc weight [8][2]
@@ -687,15 +689,40 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
 // ------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void split3(float x, __bf16& h, __bf16& m, __bf16& l) {
-    h = (__bf16)x;
-    const float r1 = x - (float)h;
-    m = (__bf16)r1;
-    l = (__bf16)(r1 - (float)m);
-}
+// Operand formats of the 16-bit matrix-core DoubleConv (k_dc_x16):
+//   SplitBf16: 3 parts, 6 product terms, fp32-accurate (HN_UNET_IMPL=bf16x3)
+//   HalfF16  : 1 part, 1 term: the mixed-precision configuration of BASELINE.json configs[4] ("fp16 UNet /
+//              fp32 spectral residual"; the reference converges identically in fp16) (HN_UNET_IMPL=fp16)
+struct SplitBf16 {
+    typedef __bf16 T;
+    typedef bf16x8 V8;
+    typedef bf16x2 V2;
+    static constexpr int NP = 3, NT = 6;
+    __device__ static constexpr int ap(int t) { return t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0; }  // A part of term t, small terms first:
+    __device__ static constexpr int bp(int t) { return t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0; }  // lh, hl, mm, mh, hm, hh
+    __device__ static __forceinline__ void split(float x, T (&p)[3]) {
+        p[0] = (T)x;
+        const float r1 = x - (float)p[0];
+        p[1] = (T)r1;
+        p[2] = (T)(r1 - (float)p[1]);
+    }
+    __device__ static __forceinline__ f32x4 mma(const V8& a, const V8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+struct HalfF16 {
+    typedef _Float16 T;
+    typedef f16x8 V8;
+    typedef f16x2 V2;
+    static constexpr int NP = 1, NT = 1;
+    __device__ static constexpr int ap(int) { return 0; }
+    __device__ static constexpr int bp(int) { return 0; }
+    __device__ static __forceinline__ void split(float x, T (&p)[1]) { p[0] = (T)x; }
+    __device__ static __forceinline__ f32x4 mma(const V8& a, const V8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
 
-template <int CA, int CB, int CC>
+template <int CA, int CB, int CC, int NP>
 struct B3Cfg {
     static constexpr int TH = 16, TW = 64;
     static constexpr int CIN = CA + CB + CC, NG = (CIN + 7) / 8;
@@ -704,27 +731,48 @@ struct B3Cfg {
     static constexpr int MR = TH + 2, MPARTB = MR * ROWB;
     static constexpr int NR1 = 9, NR2 = 8;
     static constexpr int NP2 = IR * PI / 2, NL = cdiv_(NP2, 256);
-    static constexpr int LDS_BYTES = 3 * PARTB;             // 65280; the mid tensor (3 * MPARTB = 58752) reuses it
+    static constexpr int LDS_BYTES = NP * PARTB;            // 65280 for 3 parts; the mid tensor (NP * MPARTB) reuses it
     static constexpr bool SCALED = CC > 0;
 };
 
-// 18 MFMAs of one staged row against up to three output rows (dy = 0, 1, 2); consecutive MFMAs hit different accumulators
-template <int NR>
-__device__ __forceinline__ void bf3_row(f32x4 (&acc)[NR], int j, const bf16x8 (&a)[3][3], const bf16x8& bh, const bf16x8& bm, const bf16x8& bl) {
-    constexpr int AP[6] = {2, 0, 1, 1, 0, 0};  // A part of term t (0 = h, 1 = m, 2 = l), small terms first
-    constexpr int BP[6] = {0, 2, 1, 0, 1, 0};  // B part
+// NT x 3 MFMAs of one staged row against up to three output rows (dy = 0, 1, 2); consecutive MFMAs hit different accumulators
+template <typename M, int NR>
+__device__ __forceinline__ void x16_row(f32x4 (&acc)[NR], int j, const typename M::V8 (&a)[3][M::NP], const typename M::V8 (&bv)[M::NP]) {
 #pragma unroll
-    for (int t = 0; t < 6; ++t)
+    for (int t = 0; t < M::NT; ++t)
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy) {
             const int r = j - dy;
-            if (r >= 0 && r < NR) acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[dy][AP[t]], BP[t] == 0 ? bh : BP[t] == 1 ? bm : bl, acc[r], 0, 0, 0);
+            if (r >= 0 && r < NR) acc[r] = M::mma(a[dy][M::ap(t)], bv[M::bp(t)], acc[r]);
         }
 }
 
-template <int CA, int CB, int CC, int EPI>
-__global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
-    using C = B3Cfg<CA, CB, CC>;
+// NR output rows of one strip from NR + 2 staged rows, read one row ahead; part stride PB, row stride RB bytes
+template <typename M, int NR, int PB, int RB>
+__device__ __forceinline__ void x16_rows(f32x4 (&acc)[NR], const typename M::V8 (&a)[3][M::NP], const unsigned char* base) {
+    typename M::V8 cur[M::NP], nxt[M::NP];
+#pragma unroll
+    for (int pt = 0; pt < M::NP; ++pt) cur[pt] = *reinterpret_cast<const typename M::V8*>(base + pt * PB);
+#pragma unroll
+    for (int j = 0; j < NR + 2; ++j) {
+        if (j + 1 < NR + 2) {
+#pragma unroll
+            for (int pt = 0; pt < M::NP; ++pt) nxt[pt] = *reinterpret_cast<const typename M::V8*>(base + pt * PB + (j + 1) * RB);
+        }
+        x16_row<M, NR>(acc, j, a, cur);
+        if (j + 1 < NR + 2) {
+#pragma unroll
+            for (int pt = 0; pt < M::NP; ++pt) cur[pt] = nxt[pt];
+        }
+    }
+}
+
+template <typename M, int CA, int CB, int CC, int EPI>
+__global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
+    using C = B3Cfg<CA, CB, CC, M::NP>;
+    typedef typename M::V8 V8;
+    typedef typename M::V2 V2;
+    typedef typename M::T T;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -747,13 +795,13 @@ __global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst o
         gofb[i] = okm[i] ? (unsigned)(y * W + x) * 4u : 0u;
         lofb[i] = (ir * C::PI + ic) * 16;
         if (in && !okm[i]) {  // zero padding, written once: commits skip these positions
-            bf16x8 z;
+            V8 z;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) z[k] = (__bf16)0.f;
+            for (int k = 0; k < 8; ++k) z[k] = (T)0.f;
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                *reinterpret_cast<bf16x8*>(lds + pl * C::PARTB + lofb[i]) = z;
-                *reinterpret_cast<bf16x8*>(lds + pl * C::PARTB + lofb[i] + 16) = z;
+            for (int pl = 0; pl < M::NP; ++pl) {
+                *reinterpret_cast<V8*>(lds + pl * C::PARTB + lofb[i]) = z;
+                *reinterpret_cast<V8*>(lds + pl * C::PARTB + lofb[i] + 16) = z;
             }
         }
     }
@@ -784,7 +832,7 @@ __global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst o
             if (okm[i]) {
 #pragma unroll
                 for (int px = 0; px < 2; ++px) {
-                    bf16x8 vh, vm, vl;
+                    V8 vp[M::NP];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int c = 8 * g + j;
@@ -793,13 +841,13 @@ __global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst o
                             v = px ? stage[j][i].y : stage[j][i].x;
                             if (C::SCALED) v *= (c < CA ? sa.scale : c < CA + CB ? sb.scale : sc.scale);
                         }
-                        __bf16 h, m, l;
-                        split3(v, h, m, l);
-                        vh[j] = h; vm[j] = m; vl[j] = l;
+                        T pr[M::NP];
+                        M::split(v, pr);
+#pragma unroll
+                        for (int pt = 0; pt < M::NP; ++pt) vp[pt][j] = pr[pt];
                     }
-                    *reinterpret_cast<bf16x8*>(lds + 0 * C::PARTB + lofb[i] + 16 * px) = vh;
-                    *reinterpret_cast<bf16x8*>(lds + 1 * C::PARTB + lofb[i] + 16 * px) = vm;
-                    *reinterpret_cast<bf16x8*>(lds + 2 * C::PARTB + lofb[i] + 16 * px) = vl;
+#pragma unroll
+                    for (int pt = 0; pt < M::NP; ++pt) *reinterpret_cast<V8*>(lds + pt * C::PARTB + lofb[i] + 16 * px) = vp[pt];
                 }
             }
         }
@@ -816,49 +864,38 @@ __global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst o
     accv[0] = (f32x4){bias0, bias0, bias1, bias1};
 #pragma unroll
     for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){bias0, bias0, bias1, bias1};
-    const bf16x8* a1s = reinterpret_cast<const bf16x8*>(w.a1s) + lane;
+    const V8* a1s = reinterpret_cast<const V8*>(M::NP == 3 ? w.a1s : w.a1h) + lane;
 
     fetch(0);
 #pragma unroll
     for (int g = 0; g < C::NG; ++g) {
         if (g > 0) __syncthreads();  // every wave is done reading the previous group
         commit(g);
-        bf16x8 a[3][3];
+        V8 a[3][M::NP];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int pt = 0; pt < 3; ++pt) a[dy][pt] = a1s[((g * 3 + dy) * 3 + pt) * 64];
+            for (int pt = 0; pt < M::NP; ++pt) a[dy][pt] = a1s[((g * 3 + dy) * M::NP + pt) * 64];
         __syncthreads();
         if (g + 1 < C::NG) fetch(g + 1);
-        bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + bs1), bm = *reinterpret_cast<const bf16x8*>(lds + C::PARTB + bs1),
-               bl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::PARTB + bs1);
-#pragma unroll
-        for (int j = 0; j < C::NR1 + 2; ++j) {
-            bf16x8 nh = bh, nm = bm, nl = bl;
-            if (j + 1 < C::NR1 + 2) {
-                nh = *reinterpret_cast<const bf16x8*>(lds + bs1 + (j + 1) * C::ROWB);
-                nm = *reinterpret_cast<const bf16x8*>(lds + C::PARTB + bs1 + (j + 1) * C::ROWB);
-                nl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::PARTB + bs1 + (j + 1) * C::ROWB);
-            }
-            bf3_row<C::NR1>(acc1, j, a, bh, bm, bl);
-            bh = nh; bm = nm; bl = nl;
-        }
+        x16_rows<M, C::NR1, C::PARTB, C::ROWB>(acc1, a, lds + bs1);
         if (has_v) {  // pair column 32 (mid columns 64, 65): n indexes the mid row
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const bf16x8 vh = *reinterpret_cast<const bf16x8*>(lds + bsv + dy * C::ROWB), vm = *reinterpret_cast<const bf16x8*>(lds + C::PARTB + bsv + dy * C::ROWB),
-                             vl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::PARTB + bsv + dy * C::ROWB);
-                bf3_row<1>(accv, dy, a, vh, vm, vl);  // j = dy: only the term r = 0 survives
+                V8 vv[M::NP];
+#pragma unroll
+                for (int pt = 0; pt < M::NP; ++pt) vv[pt] = *reinterpret_cast<const V8*>(lds + pt * C::PARTB + bsv + dy * C::ROWB);
+                x16_row<M, 1>(accv, dy, a, vv);  // j = dy: only the term r = 0 survives
             }
         }
     }
-    bf16x8 a2[3][3];
+    V8 a2[3][M::NP];
     {
-        const bf16x8* a2s = reinterpret_cast<const bf16x8*>(w.a2s) + lane;
+        const V8* a2s = reinterpret_cast<const V8*>(M::NP == 3 ? w.a2s : w.a2h) + lane;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int pt = 0; pt < 3; ++pt) a2[dy][pt] = a2s[(dy * 3 + pt) * 64];
+            for (int pt = 0; pt < M::NP; ++pt) a2[dy][pt] = a2s[(dy * M::NP + pt) * 64];
     }
     __syncthreads();  // staged input is dead: the mid tensor takes its place
     {
@@ -869,15 +906,14 @@ __global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst o
             const f32x2 lm = lo * mk, ls = lo * sk, hm = hi * mk, hs = hi * sk;
             const float v00 = __builtin_amdgcn_fmed3f(lm[0], ls[0], sel), v01 = __builtin_amdgcn_fmed3f(lm[1], ls[1], sel);  // channel 2q, pixels 0 / 1
             const float v10 = __builtin_amdgcn_fmed3f(hm[0], hs[0], sel), v11 = __builtin_amdgcn_fmed3f(hm[1], hs[1], sel);  // channel 2q + 1
-            __bf16 h00, m00, l00, h01, m01, l01, h10, m10, l10, h11, m11, l11;
-            split3(v00, h00, m00, l00); split3(v01, h01, m01, l01); split3(v10, h10, m10, l10); split3(v11, h11, m11, l11);
-            unsigned char* m = lds + (mrow * C::PI + 2 * pc) * 16 + 4 * q;  // [pixel][8 ch] bf16: channels 2q, 2q + 1
-            *reinterpret_cast<bf16x2*>(m) = (bf16x2){h00, h10};
-            *reinterpret_cast<bf16x2*>(m + 16) = (bf16x2){h01, h11};
-            *reinterpret_cast<bf16x2*>(m + C::MPARTB) = (bf16x2){m00, m10};
-            *reinterpret_cast<bf16x2*>(m + C::MPARTB + 16) = (bf16x2){m01, m11};
-            *reinterpret_cast<bf16x2*>(m + 2 * C::MPARTB) = (bf16x2){l00, l10};
-            *reinterpret_cast<bf16x2*>(m + 2 * C::MPARTB + 16) = (bf16x2){l01, l11};
+            T p00[M::NP], p01[M::NP], p10[M::NP], p11[M::NP];
+            M::split(v00, p00); M::split(v01, p01); M::split(v10, p10); M::split(v11, p11);
+            unsigned char* m = lds + (mrow * C::PI + 2 * pc) * 16 + 4 * q;  // [pixel][8 ch] 16-bit: channels 2q, 2q + 1
+#pragma unroll
+            for (int pt = 0; pt < M::NP; ++pt) {
+                *reinterpret_cast<V2*>(m + pt * C::MPARTB) = (V2){p00[pt], p10[pt]};
+                *reinterpret_cast<V2*>(m + pt * C::MPARTB + 16) = (V2){p01[pt], p11[pt]};
+            }
         };
         {
             const int pc = 16 * strip + n, x = x0 - 1 + 2 * pc;
@@ -934,21 +970,7 @@ __global__ __launch_bounds__(256, 2) void k_dc_bf3(Src sa, Src sb, Src sc, Dst o
             }
         }
     }
-    {
-        bf16x8 bh = *reinterpret_cast<const bf16x8*>(lds + bs2), bm = *reinterpret_cast<const bf16x8*>(lds + C::MPARTB + bs2),
-               bl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::MPARTB + bs2);
-#pragma unroll
-        for (int j = 0; j < C::NR2 + 2; ++j) {
-            bf16x8 nh = bh, nm = bm, nl = bl;
-            if (j + 1 < C::NR2 + 2) {
-                nh = *reinterpret_cast<const bf16x8*>(lds + bs2 + (j + 1) * C::ROWB);
-                nm = *reinterpret_cast<const bf16x8*>(lds + C::MPARTB + bs2 + (j + 1) * C::ROWB);
-                nl = *reinterpret_cast<const bf16x8*>(lds + 2 * C::MPARTB + bs2 + (j + 1) * C::ROWB);
-            }
-            bf3_row<C::NR2>(acc2, j, a2, bh, bm, bl);
-            bh = nh; bm = nm; bl = nl;
-        }
-    }
+    x16_rows<M, C::NR2, C::MPARTB, C::ROWB>(acc2, a2, lds + bs2);
     if (EPI == 0) {
         if (xin) {
             unsigned off = 4u * (unsigned)((2 * q) * (int)out.sc + ox);
@@ -1623,9 +1645,11 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
-    static const bool bf3 = getenv("HN_UNET_IMPL") != nullptr && std::strcmp(getenv("HN_UNET_IMPL"), "bf16x3") == 0;
-    if (bf3 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC>::SCALED)) {
-        hipLaunchKernelGGL((k_dc_bf3<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+    static const int x16 = getenv("HN_UNET_IMPL") == nullptr ? 0 : std::strcmp(getenv("HN_UNET_IMPL"), "bf16x3") == 0 ? 1 : std::strcmp(getenv("HN_UNET_IMPL"), "fp16") == 0 ? 2 : 0;
+    if (x16 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC, 3>::SCALED)) {
+        const dim3 g(cdiv_(W, 64), cdiv_(H, 16), batch);
+        if (x16 == 1) hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        else hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
         return;
     }
     static const int strip_min = getenv("HN_STRIP_MIN") ? atoi(getenv("HN_STRIP_MIN")) : 128;
@@ -1703,6 +1727,42 @@ void pack_frag_3x3_split(const float* w, int cin, float* dst_as_float) {
                     for (int pt = 0; pt < 3; ++pt) dst[((((size_t)g * 3 + dy) * 3 + pt) * 64 + l) * 8 + e] = part[pt];
                 }
 }
+// fp16 fragments (mixed-precision mode): [group][dy][64 lanes][8 half], same lane / element meaning
+static inline uint16_t f16_rne(float x) {  // fp32 -> IEEE binary16, round to nearest even, saturating to +-inf
+    uint32_t u;
+    std::memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t e = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t man = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0u));
+    if (e >= 31) return (uint16_t)(sign | 0x7c00u);
+    if (e <= 0) {
+        if (e < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - e;
+        uint32_t h = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (h & 1u))) ++h;
+        return (uint16_t)(sign | h);
+    }
+    uint32_t h = ((uint32_t)e << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1u))) ++h;
+    return (uint16_t)(sign | h);
+}
+size_t frag_3x3_half_floats(int cin) { return (size_t)((cin + 7) / 8) * 3 * 64 * 4; }
+void pack_frag_3x3_half(const float* w, int cin, float* dst_as_float) {
+    uint16_t* dst = reinterpret_cast<uint16_t*>(dst_as_float);
+    const int ng = (cin + 7) / 8;
+    for (int g = 0; g < ng; ++g)
+        for (int dy = 0; dy < 3; ++dy)
+            for (int l = 0; l < 64; ++l)
+                for (int e = 0; e < 8; ++e) {
+                    const int co = (l & 15) >> 1, dxo = l & 1, qq = l >> 4, dx = qq - dxo, ci = 8 * g + e;
+                    const float v = (dx >= 0 && dx <= 2 && ci < cin) ? w[((co * cin + ci) * 3 + dy) * 3 + dx] : 0.f;
+                    dst[((((size_t)g * 3 + dy)) * 64 + l) * 8 + e] = f16_rne(v);
+                }
+}
 // down conv, weight [8][8][8][8] (co, ci, ky, kx) -> [ci][kx][64]: lane -> (co, h = l&1, k = l>>4): w[co][ci][4h+k][kx]
 void pack_frag_down(const float* w, float* dst) {
     for (int ci = 0; ci < kFeat; ++ci)
@@ -1728,7 +1788,9 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s) {
     const int cin = kind == 0 ? kInCh : kind == 1 ? kFeat + kState : kind == 2 ? kFeat : 2 * kFeat;
     // hn_load_weights stores the split-bf16 fragments right behind the fp32 ones
-    const McW mw{frag1, w.b1, w.slope, frag2, w.b2, frag1 + (size_t)cin * 3 * 64, frag2 + (size_t)kFeat * 3 * 64};
+    const float* s1 = frag1 + (size_t)cin * 3 * 64;      // split-bf16 twin, then the fp16 twin
+    const float* s2 = frag2 + (size_t)kFeat * 3 * 64;
+    const McW mw{frag1, w.b1, w.slope, frag2, w.b2, s1, s2, s1 + frag_3x3_split_floats(cin), s2 + frag_3x3_split_floats(kFeat)};
     const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf};
     switch (kind) {
         case 0: launch_dc_mfma<2, 2, 2, 0>(a, b, c, out, mw, e, H, W, batch, s); break;          // inc

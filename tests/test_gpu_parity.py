@@ -246,21 +246,43 @@ def test_multiple_sources_and_variable_source(solver, weights):
     assert out["residual_norms"].shape == (25, 2)
 
 
-def test_split_bf16_experiment_keeps_the_parity_bar():
-    """HN_UNET_IMPL=bf16x3 (opt-in experiment: DoubleConvs on the bf16 matrix core with 3-term split operands and
-    fp32 accumulation) must meet the same bars as the default fp32 path; the library reads the switch at
-    first use, so it runs in a process of its own."""
+def _run_unet_impl_check(impl):
+    """The library reads HN_UNET_IMPL at first use, so alternative implementations run in a process of their own."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HN_UNET_IMPL="bf16x3")
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_unet_impl.py")], env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, HN_UNET_IMPL=impl)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_unet_impl.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
-    assert out["impl"] == "bf16x3"
+    assert out["impl"] == impl
+    return out
+
+
+def test_split_bf16_experiment_keeps_the_parity_bar():
+    """HN_UNET_IMPL=bf16x3 (opt-in experiment: DoubleConvs on the bf16 matrix core with 3-term split operands and
+    fp32 accumulation) must meet the same bars as the default fp32 path."""
+    out = _run_unet_impl_check("bf16x3")
     for n in (256, 128):
         assert out[f"single_step_{n}"]["wf"] <= 1e-5 and out[f"single_step_{n}"]["res"] <= 1e-5, out
         assert out[f"unet_output_{n}"] <= 1e-5, out
     assert out["cfg1_wf_linf_vs_reference"] <= 1e-4 and out["cfg1_rmse_rel"] <= 2e-2, out
+    assert out["readme300_wf_linf_vs_reference"] <= 1e-4 and out["readme300_rmse_rel"] <= 2e-2, out
+
+
+def test_mixed_fp16_unet_configuration():
+    """BASELINE.json configs[4]: fp16 UNet (DoubleConv operands in fp16, fp32 accumulation; every tensor in HBM,
+    the hidden state, the wavefield update and the spectral residual stay fp32).  Not bit-comparable with the
+    fp32 path: the network output carries fp16 rounding (bar 5e-3 of max), but the iteration converges to the
+    same answer (SURVEY 0.1 measured 1.77e-5 vs 1.76e-5 final RMSE for the reference with an fp16 network, which
+    is what this path reproduces): wavefield within 1e-3 of the reference's fp32 run ([measured] 3.3e-5 after 100
+    iterations, 2.2e-4 after 300), residual trace within 5 %."""
+    out = _run_unet_impl_check("fp16")
+    for n in (256, 128):
+        assert out[f"unet_output_{n}"] <= 5e-3, out
+        assert out[f"single_step_{n}"]["wf"] <= 1e-4 and out[f"single_step_{n}"]["res"] <= 1e-4, out
+    assert out["cfg1_wf_linf_vs_reference"] <= 1e-3 and out["cfg1_rmse_rel"] <= 5e-2, out
+    assert out["readme300_wf_linf_vs_reference"] <= 1e-3 and out["readme300_rmse_rel"] <= 5e-2, out
+    assert abs(out["readme300_final_rmse"] / out["readme300_final_rmse_reference"] - 1) <= 5e-2, out
 
 
 def test_error_behaviour(solver):

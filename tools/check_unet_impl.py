@@ -50,4 +50,12 @@ with np.load(os.path.join(ROOT, "tests", "golden", "free_run.npz")) as z:
     o = s.forward(torch.ones(1, 1, 256, 256, device=dev), num_iterations=100)
     out["cfg1_wf_linf_vs_reference"] = float(np.abs(o["wavefields"][0].cpu().numpy() - z["cfg1_wf_it100"]).max())
     out["cfg1_rmse_rel"] = float(np.abs(o["residual_norms"].cpu().numpy() / z["cfg1_rmse"] - 1).max())
+    # README problem, 300 iterations: converged residual and wavefield against the reference's own run
+    from helmnet_amd.phantoms import readme_sos
+    o = s.forward(torch.from_numpy(readme_sos()).to(dev), num_iterations=300, residuals="norms")
+    rm = o["residual_norms"].cpu().numpy()
+    out["readme300_final_rmse"] = float(rm[-1].max())
+    out["readme300_final_rmse_reference"] = float(z["readme_rmse"][-1].max())
+    out["readme300_rmse_rel"] = float(np.abs(rm / z["readme_rmse"] - 1).max())
+    out["readme300_wf_linf_vs_reference"] = float(np.abs(o["wavefields"][0].cpu().numpy() - z["readme_wf_it300"]).max())
 print(json.dumps(out))
