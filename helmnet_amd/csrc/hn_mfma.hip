@@ -718,7 +718,8 @@ struct HalfF16 {
     static constexpr int NP = 1, NT = 1;
     __device__ static constexpr int ap(int) { return 0; }
     __device__ static constexpr int bp(int) { return 0; }
-    __device__ static __forceinline__ void split(float x, T (&p)[1]) { p[0] = (T)x; }
+    // saturating: a sample whose residual blows up must not poison the batch with inf - inf = NaN
+    __device__ static __forceinline__ void split(float x, T (&p)[1]) { p[0] = (T)__builtin_amdgcn_fmed3f(x, -65504.f, 65504.f); }
     __device__ static __forceinline__ f32x4 mma(const V8& a, const V8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 

@@ -64,3 +64,33 @@ def smooth_random_sos(n: int, batch: int, seed: int = 1) -> np.ndarray:
     c = np.cumsum(np.cumsum(np.pad(u, ((0, 0), (1, 0), (1, 0))), axis=1), axis=2)
     box = (c[:, 8:, 8:] - c[:, :-8, 8:] - c[:, 8:, :-8] + c[:, :-8, :-8]) / 64.0
     return (1.0 + box[:, None, :n, :n]).astype(np.float32)
+
+
+def skull_sos(n: int = 512, batch: int = 1, seed: int = 0, boost: float = 0.87, brain: float = 0.0) -> np.ndarray:
+    """[batch, 1, n, n] synthetic transcranial phantoms for BASELINE.json configs[4] (the CQ500-derived maps of
+    the paper are not redistributable): water 1.0 and an elliptical skull shell of relative sound speed
+    1 + boost (0.87: 2800 / 1500 m/s) with smooth tables and a slower diploe.  ``brain`` > 0 adds soft-tissue
+    heterogeneity inside (out of the network's training distribution, dataloaders.py:115-156, which is a
+    homogeneous interior behind a constant-boost ring).  Values stay in [1, 2]; the PML margin stays water."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(n, dtype=np.float32), np.arange(n, dtype=np.float32), indexing="ij")
+    out = np.empty((batch, 1, n, n), np.float32)
+    for b in range(batch):
+        cy, cx = n * (0.52 + 0.03 * rng.standard_normal()), n * (0.5 + 0.03 * rng.standard_normal())
+        ay, ax = n * (0.30 + 0.02 * rng.random()), n * (0.24 + 0.02 * rng.random())
+        th = rng.uniform(-0.2, 0.2)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        ang = np.arctan2(v, u)
+        wobble = 1.0 + 0.03 * np.sin(3 * ang + rng.uniform(0, 6.28)) + 0.02 * np.sin(5 * ang + rng.uniform(0, 6.28))
+        r = np.sqrt((u / ax) ** 2 + (v / ay) ** 2) / wobble          # 1 on the outer table
+        thick = 0.10 + 0.03 * np.sin(2 * ang + rng.uniform(0, 6.28))  # shell thickness in units of r
+        edge = 0.012
+        outer = 1.0 / (1.0 + np.exp((r - 1.0) / edge))
+        inner = 1.0 / (1.0 + np.exp((r - (1.0 - thick)) / edge))
+        shell = outer - inner                                         # 1 inside the bone
+        mid = np.exp(-(((r - (1.0 - 0.5 * thick)) / (0.25 * thick)) ** 2))
+        bone = boost * (1.0 - 0.29 * mid)                             # cortical tables faster than the diploe
+        soft = brain * (0.5 + 0.5 * np.sin(6.28 * (2.0 * u / n + 0.3)) * np.sin(6.28 * (1.5 * v / n + 0.1)))
+        out[b, 0] = 1.0 + shell * bone + inner * soft
+    return np.clip(out, 1.0, 2.0).astype(np.float32)

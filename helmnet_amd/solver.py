@@ -301,6 +301,33 @@ class IterativeSolver(nn.Module):
         st = self.f.get_states(flatten=True).float().contiguous().clone()
         return self._run(wf, res, st, k_sq.float().contiguous(), num_iterations, return_wavefields, return_states, residuals)
 
+    def solve_to_tolerance(self, sos_maps, tol: float, max_iterations: int = None, check_every: int = 50,
+                           norm_reduce=None) -> dict:
+        """Extension (BASELINE.json configs[4], "convergence-to-tolerance"): iterate in chunks of
+        ``check_every`` until the WORST per-sample residual RMSE (hybridnet.py:295-297) is below ``tol`` or
+        ``max_iterations`` is reached.  One device-to-host read of a single float per chunk; with
+        ``norm_reduce`` (e.g. helmnet_amd.distributed.allreduce_residual_norms) the test is global over ranks.
+        Returns wavefield, last residual, per-iteration RMSE trace [K, B], iterations run and whether it converged."""
+        if max_iterations is None:
+            max_iterations = self.hparams.max_iterations
+        sos_maps = sos_maps.float().contiguous()
+        k_sq, wf = self.get_initials(sos_maps)
+        self.f.clear_states(wf)
+        res = self.get_residual(wf, k_sq)
+        k_sq = k_sq.contiguous()
+        done, traces, converged = 0, [], False
+        while done < max_iterations:
+            chunk = min(int(check_every), max_iterations - done)
+            out = self.n_steps(wf, k_sq, res, chunk, residuals="norms")
+            wf, res = out["wavefields"][0], out["last_residual"]
+            traces.append(out["residual_norms"])
+            done += chunk
+            worst = out["residual_norms"][-1].max() if norm_reduce is None else norm_reduce(out["residual_norms"][-1], "max")
+            if float(worst) < tol:
+                converged = True
+                break
+        return {"wavefield": wf, "residual": res, "residual_norms": torch.cat(traces, 0), "iterations": done, "converged": converged}
+
     def forward_variable_src(self, sos_maps, src_time_pairs, return_wavefields=False, return_states=False,
                              num_iterations=None, stop_if_diverge=False, residuals: str = "all"):
         """hybridnet.py:699-754: swap the source map at given iterations (the residual is recomputed

@@ -64,3 +64,27 @@ def test_gmres_on_hip_operator_agrees_with_learned_solver():
     a, b = out["wavefield"], learned["wavefields"][0]
     rel = (a - b).abs().amax(dim=(1, 2, 3)) / b.abs().amax(dim=(1, 2, 3))
     assert float(rel.max()) < 0.05, rel
+
+
+@pytest.mark.gpu
+def test_convergence_to_tolerance_on_a_transcranial_phantom():
+    """BASELINE.json configs[4] shape (512^2, set_domain_size, run until the worst residual RMSE is below a
+    tolerance): the chunked loop stops at the first check below tol and equals one uninterrupted forward()."""
+    import torch
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import skull_sos
+    dev = torch.device("cuda:0")
+    s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(dev)
+    s.set_domain_size(512, source_location=[51, 256])
+    sos_np = skull_sos(512, 2, seed=0, boost=0.4)
+    assert sos_np.min() == 1.0 and 1.3 < sos_np.max() <= 2.0 and (sos_np[:, :, :40] == 1.0).all()   # PML margin stays water
+    sos = torch.from_numpy(sos_np).to(dev)
+    out = s.solve_to_tolerance(sos, tol=1e-4, max_iterations=1000, check_every=50)
+    assert out["converged"] and out["iterations"] <= 400 and out["iterations"] % 50 == 0
+    rm = out["residual_norms"]
+    assert rm.shape == (out["iterations"], 2) and float(rm[-1].max()) < 1e-4 <= float(rm[-51].max())
+    ref = s.forward(sos, num_iterations=out["iterations"], residuals="norms")
+    assert torch.equal(ref["wavefields"][0], out["wavefield"])                       # same arithmetic, chunked or not
+    assert torch.allclose(ref["residual_norms"], rm, rtol=1e-5, atol=0)              # per-sample sums are float atomics
+    slow = s.solve_to_tolerance(sos, tol=1e-12, max_iterations=100, check_every=30)
+    assert not slow["converged"] and slow["iterations"] == 100 and slow["residual_norms"].shape[0] == 100
