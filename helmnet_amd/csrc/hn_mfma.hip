@@ -1025,12 +1025,12 @@ __global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst o
 }
 
 // ------------------------------------------------------------------------------------------
-// Persistent full-tile DoubleConv for the big levels (W even, tile 16 x 64, one block per CU).
-// All input channels of a tile (with halo 2) are resident in LDS (up to 87 KB) next to the mid
-// tensor (39 KB), so conv1 runs its cin*3 MFMA steps back to back with no barrier; the NEXT
-// tile's input is already in flight into registers (float2 loads issued before conv1) and is
-// committed to LDS after conv1.  Two barriers per tile; one wavefront per SIMD owns its matrix
-// pipe.  A-operand fragments of both convolutions stay in registers for the whole launch.
+// Full-tile DoubleConv for the small levels (W <= 64; tiles 8 x 32 and 8 x 16, one tile per block).
+// All input channels of a tile (with halo 2) are staged at once next to the mid tensor, so conv1 runs
+// its cin*3 MFMA steps back to back behind one barrier; two barriers per tile; A-operand fragments of
+// both convolutions go through LDS.  (The tile loop and the next-tile prefetch date from a persistent
+// 16 x 64 one-block-per-CU variant for the big levels, which measured 25 % slower than the chunked
+// kernels -- nothing covers staging / mid / epilogue at one wavefront per SIMD -- and is no longer launched.)
 // ------------------------------------------------------------------------------------------
 template <int CA, int CB, int CC, int TH_ = 16, int TW_ = 64>
 struct PcCfg {
@@ -1625,24 +1625,9 @@ __global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float
     }
 }
 
-// Experiment knob (HN_SPREAD=1): extra dynamic LDS that caps the blocks per CU of a small launch at
-// ceil(nblocks / 256).  Measured 2 % SLOWER on the small levels (co-located blocks were not the
-// problem), so it is off by default.
-inline unsigned spread_lds(size_t static_bytes, long nblocks) {
-    static const bool off = getenv("HN_SPREAD") == nullptr;
-    const long per_cu = (nblocks + 255) / 256;
-    if (off || per_cu >= 8) return 0;
-    const size_t want = (160 * 1024) / (size_t)per_cu;          // LDS share that admits exactly per_cu blocks
-    const size_t need = want > 512 ? want - 512 : 0;            // a little slack below the exact share
-    return need > static_bytes ? (unsigned)(need - static_bytes) & ~15u : 0;
-}
-
 template <int CA, int CB, int CC, int EPI>
 void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
-    // the persistent full-tile variant measured slower than the chunked one (1 wave per SIMD leaves
-    // staging / epilogue phases uncovered); kept opt-in for experiments
-    static const bool persistent = getenv("HN_DC_PERSISTENT") != nullptr;
-    static const bool generic = getenv("HN_DC_GENERIC") != nullptr;
+    static const bool generic = getenv("HN_DC_GENERIC") != nullptr;  // A/B: force the generic chunked kernel
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
@@ -1653,26 +1638,16 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
         else hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
         return;
     }
-    static const int strip_min = getenv("HN_STRIP_MIN") ? atoi(getenv("HN_STRIP_MIN")) : 128;
-    if (W >= strip_min && even && !persistent && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
-        static const int dyn_lds = getenv("HN_DC_DYNLDS") ? atoi(getenv("HN_DC_DYNLDS")) : 0;  // experiments: caps blocks per CU
-        hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), dyn_lds, s, a, b, c, out, w, e, H, W);
-    } else if (W >= 64 && even && persistent) {
-        using C = PcCfg<CA, CB, CC>;
-        const int tx = cdiv_(W, 64), ty = cdiv_(H, 16), nt = tx * ty * batch;
-        const int per_cu = (160 * 1024) / (int)(C::LDS_FLOATS * sizeof(float));
-        const int grid = nt < 256 * per_cu ? nt : 256 * per_cu;
-        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 16, 64>), dim3(grid), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+    if (W >= 128 && even && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
+        hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
     } else if (even && !generic && W > 16) {
         // small levels are latency-bound: whole input tile staged at once (one barrier), small 8 x 32
         // tiles so that even a 32^2 image spreads over many CUs
         const int tx = cdiv_(W, 32), ty = cdiv_(H, 8), nt = tx * ty * batch;
-        const unsigned dl = spread_lds(PcCfg<CA, CB, CC, 8, 32>::LDS_FLOATS * sizeof(float), nt);
-        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 32>), dim3(nt), dim3(256), dl, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 32>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
     } else if (even && !generic) {
         const int tx = cdiv_(W, 16), ty = cdiv_(H, 8), nt = tx * ty * batch;
-        const unsigned dl = spread_lds(PcCfg<CA, CB, CC, 8, 16>::LDS_FLOATS * sizeof(float), nt);
-        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 16>), dim3(nt), dim3(256), dl, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+        hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 16>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
     } else if (W > 32) {
         hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 64, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
     } else if (W > 16) {
@@ -1813,27 +1788,24 @@ void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin,
     if (Wout > 64) hipLaunchKernelGGL((k_down_mfma<4, false>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     else if (Wout > 32) {
         const dim3 g(cdiv_(Wout, 32), cdiv_(Hout, 16), batch);
-        const unsigned dl = spread_lds(2 * DnCfg<2>::PLANE_P * sizeof(float), (long)g.x * g.y * g.z);
-        hipLaunchKernelGGL((k_down_mfma<2, false>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
+        hipLaunchKernelGGL((k_down_mfma<2, false>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     }
     else {
         const dim3 g(cdiv_(Wout, 16), cdiv_(Hout, 16), batch);
-        const unsigned dl = spread_lds(kFeat * DnCfg<1>::PLANE_P * sizeof(float), (long)g.x * g.y * g.z);
-        hipLaunchKernelGGL((k_down_mfma<1, true>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
+        hipLaunchKernelGGL((k_down_mfma<1, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     }
 }
 
 void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     // window rows -1 .. Hin-1
-    static const int up_small = getenv("HN_UP_SMALL") ? atoi(getenv("HN_UP_SMALL")) : 64;
+    constexpr int up_small = 64;  // at and below: the all-channels-at-once kernel (few tiles, latency-bound)
     // 22 window rows per block: the Hin + 1 = 129 (257) window rows of a 128^2 (256^2) input split into 6 (12)
     // row blocks with 2 % padding instead of 9 x 16 with 10 %, and 4 x 6 x 32 = 768 blocks are exactly one
     // round of 3 resident blocks per CU at 256^2 x 32 (16-row blocks: 1152 = 1.5 rounds)
     if (Win > up_small) hipLaunchKernelGGL((k_up_mfma<2, 11, false>), dim3(cdiv_(Win, 32), cdiv_(Hin + 1, 22), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     else {
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
-        const unsigned dl = spread_lds(kFeat * UpCfg2<1, 5>::PLANE_P * sizeof(float), (long)g.x * g.y * g.z);
-        hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), dl, s, in, out, frag, bias, Hin, Win);
+        hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     }
 }
 
