@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--lanes", type=int, default=1, help="hn_step pipeline lanes (sub-batches on parallel streams); "
                     "2 gives about +5 %% it/s but kernels of the two lanes overlap, so per-kernel timings (roofline) blur")
-    ap.add_argument("--unet-impl", default=None, choices=["valu", "bf16x3", "fp16"],
+    ap.add_argument("--unet-impl", default=None, choices=["valu", "bf16x3", "bf16x2", "fp16"],
                     help="experiments only (sets HN_UNET_IMPL): 'bf16x3' = split-bf16 DoubleConv kernels with fp32-accurate "
                          "products; the default and the reported metric is the fp32 matrix-core path")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -700,7 +700,7 @@ struct SplitBf16 {
     typedef __bf16 T;
     typedef bf16x8 V8;
     typedef bf16x2 V2;
-    static constexpr int NP = 3, NT = 6;
+    static constexpr int NP = 3, NT = 6, NPF = 3;  // NPF: parts per (group, dy) in the host-packed fragment buffer
     __device__ static constexpr int ap(int t) { return t == 0 ? 2 : (t == 2 || t == 3) ? 1 : 0; }  // A part of term t, small terms first:
     __device__ static constexpr int bp(int t) { return t == 1 ? 2 : (t == 2 || t == 4) ? 1 : 0; }  // lh, hl, mm, mh, hm, hh
     __device__ static __forceinline__ void split(float x, T (&p)[3]) {
@@ -711,11 +711,26 @@ struct SplitBf16 {
     }
     __device__ static __forceinline__ f32x4 mma(const V8& a, const V8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
+// 2-term bf16 split: 3 products (mh, hm, hh), ~2^-16 relative, full fp32 exponent range -- the range-safe mixed mode
+// (HN_UNET_IMPL=bf16x2); shares the fragment buffers of SplitBf16 (parts 0 and 1 of 3).
+struct SplitBf16x2 {
+    typedef __bf16 T;
+    typedef bf16x8 V8;
+    typedef bf16x2 V2;
+    static constexpr int NP = 2, NT = 3, NPF = 3;
+    __device__ static constexpr int ap(int t) { return t == 0 ? 1 : 0; }
+    __device__ static constexpr int bp(int t) { return t == 1 ? 1 : 0; }
+    __device__ static __forceinline__ void split(float x, T (&p)[2]) {
+        p[0] = (T)x;
+        p[1] = (T)(x - (float)p[0]);
+    }
+    __device__ static __forceinline__ f32x4 mma(const V8& a, const V8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
 struct HalfF16 {
     typedef _Float16 T;
     typedef f16x8 V8;
     typedef f16x2 V2;
-    static constexpr int NP = 1, NT = 1;
+    static constexpr int NP = 1, NT = 1, NPF = 1;
     __device__ static constexpr int ap(int) { return 0; }
     __device__ static constexpr int bp(int) { return 0; }
     // saturating: a sample whose residual blows up must not poison the batch with inf - inf = NaN
@@ -865,7 +880,7 @@ __global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst o
     accv[0] = (f32x4){bias0, bias0, bias1, bias1};
 #pragma unroll
     for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){bias0, bias0, bias1, bias1};
-    const V8* a1s = reinterpret_cast<const V8*>(M::NP == 3 ? w.a1s : w.a1h) + lane;
+    const V8* a1s = reinterpret_cast<const V8*>(M::NPF == 3 ? w.a1s : w.a1h) + lane;
 
     fetch(0);
 #pragma unroll
@@ -876,7 +891,7 @@ __global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst o
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int pt = 0; pt < M::NP; ++pt) a[dy][pt] = a1s[((g * 3 + dy) * M::NP + pt) * 64];
+            for (int pt = 0; pt < M::NP; ++pt) a[dy][pt] = a1s[((g * 3 + dy) * M::NPF + pt) * 64];
         __syncthreads();
         if (g + 1 < C::NG) fetch(g + 1);
         x16_rows<M, C::NR1, C::PARTB, C::ROWB>(acc1, a, lds + bs1);
@@ -892,11 +907,11 @@ __global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst o
     }
     V8 a2[3][M::NP];
     {
-        const V8* a2s = reinterpret_cast<const V8*>(M::NP == 3 ? w.a2s : w.a2h) + lane;
+        const V8* a2s = reinterpret_cast<const V8*>(M::NPF == 3 ? w.a2s : w.a2h) + lane;
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int pt = 0; pt < M::NP; ++pt) a2[dy][pt] = a2s[(dy * M::NP + pt) * 64];
+            for (int pt = 0; pt < M::NP; ++pt) a2[dy][pt] = a2s[(dy * M::NPF + pt) * 64];
     }
     __syncthreads();  // staged input is dead: the mid tensor takes its place
     {
@@ -1631,11 +1646,15 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
-    static const int x16 = getenv("HN_UNET_IMPL") == nullptr ? 0 : std::strcmp(getenv("HN_UNET_IMPL"), "bf16x3") == 0 ? 1 : std::strcmp(getenv("HN_UNET_IMPL"), "fp16") == 0 ? 2 : 0;
+    static const int x16 = [] {
+        const char* e = getenv("HN_UNET_IMPL");
+        return e == nullptr ? 0 : std::strcmp(e, "bf16x3") == 0 ? 1 : std::strcmp(e, "fp16") == 0 ? 2 : std::strcmp(e, "bf16x2") == 0 ? 3 : 0;
+    }();
     if (x16 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC, 3>::SCALED)) {
         const dim3 g(cdiv_(W, 64), cdiv_(H, 16), batch);
         if (x16 == 1) hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
-        else hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        else if (x16 == 2) hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        else hipLaunchKernelGGL((k_dc_x16<SplitBf16x2, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
         return;
     }
     if (W >= 128 && even && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {

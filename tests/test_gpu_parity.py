@@ -269,6 +269,18 @@ def test_split_bf16_experiment_keeps_the_parity_bar():
     assert out["readme300_wf_linf_vs_reference"] <= 1e-4 and out["readme300_rmse_rel"] <= 2e-2, out
 
 
+def test_two_term_bf16_split_mode():
+    """HN_UNET_IMPL=bf16x2: 2-term bf16 split (3 products, ~2^-16 relative, full fp32 exponent range) -- the
+    range-safe mixed-precision mode.  Network output within 1e-4 of max; free runs still meet the fp32
+    wavefield bar of 1e-4 against the reference's fp32 runs."""
+    out = _run_unet_impl_check("bf16x2")
+    for n in (256, 128):
+        assert out[f"unet_output_{n}"] <= 1e-4, out
+        assert out[f"single_step_{n}"]["wf"] <= 1e-5 and out[f"single_step_{n}"]["res"] <= 1e-5, out
+    assert out["cfg1_wf_linf_vs_reference"] <= 1e-4 and out["cfg1_rmse_rel"] <= 2e-2, out
+    assert out["readme300_wf_linf_vs_reference"] <= 1e-4 and out["readme300_rmse_rel"] <= 2e-2, out
+
+
 def test_mixed_fp16_unet_configuration():
     """BASELINE.json configs[4]: fp16 UNet (DoubleConv operands in fp16, fp32 accumulation; every tensor in HBM,
     the hidden state, the wavefield update and the spectral residual stay fp32).  Not bit-comparable with the
