@@ -235,6 +235,12 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         auto k8 = [&](bool up) {
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * kFeat * 64);
             if (up) pack_frag_up(blob + pos, fr.data() + off.back()); else pack_frag_down(blob + pos, fr.data() + off.back());
+            {   // 16-bit twins (mixed-precision modes), right behind the fp32 block: 3-part bf16, then fp16
+                const size_t o = fr.size();
+                fr.resize(o + k8_split_floats() + k8_half_floats());
+                if (up) pack_frag_up_x16(blob + pos, fr.data() + o, fr.data() + o + k8_split_floats());
+                else pack_frag_down_x16(blob + pos, fr.data() + o, fr.data() + o + k8_split_floats());
+            }
             pos += k8_count();
         };
         dc(kInCh, kFeat, kFeat);

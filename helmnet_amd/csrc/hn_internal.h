@@ -158,6 +158,10 @@ size_t frag_3x3_half_floats(int cin);
 void pack_frag_3x3_half(const float* w_oihw, int cin, float* dst);   // -> [ceil(cin/8)][3 dy][64][8 half]
 void pack_frag_down(const float* w_oihw, float* dst);          // -> [8][8][64]
 void pack_frag_up(const float* w_iohw, float* dst);            // -> [8][2][4][64]
+size_t k8_split_floats();
+size_t k8_half_floats();
+void pack_frag_down_x16(const float* w_oihw, float* dst_split, float* dst_half);
+void pack_frag_up_x16(const float* w_iohw, float* dst_split, float* dst_half);
 // kind: 0 inc (2+2+2 ch), 1 conv_signal (8+2), 2 bottleneck (8), 3 decoder (8+8; final_epi adds outc + wf update)
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);

@@ -1640,16 +1640,222 @@ __global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// 16-bit matrix-core versions of the 8x8 stride-2 convolutions (mixed-precision modes only, see k_dc_x16):
+// K = 32 = 4 window rows (q) x 8 input channels, so one MFMA per (kx, window row) and product term covers
+// all input channels; the input tile is converted once and staged channel-last [part][row][x][8 ch].
+// ------------------------------------------------------------------------------------------
+template <typename M>
+struct DnX {
+    static constexpr int TH = 16, TW = 16, R = 4, NWIN = R + 2;
+    static constexpr int IR = 2 * TH + 6, IC = 2 * TW + 6;
+    static constexpr int PI = IC | 1;                       // odd pixel pitch: the 4 window rows of a read land on disjoint banks
+    static constexpr int ROWB = PI * 16, PARTB = IR * ROWB;
+    static constexpr int NL = cdiv_(IR * IC, 256);
+    static constexpr int LDS_BYTES = M::NP * PARTB;
+};
+
+template <typename M>
+__global__ __launch_bounds__(256, 2) void k_down_x16(Src in, Dst out, const void* __restrict__ afr /*[8 kx][NPF][64] x 8*/,
+                                                      const float* __restrict__ bias, int Hin, int Win) {
+    using C = DnX<M>;
+    typedef typename M::V8 V8;
+    typedef typename M::T T;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z;
+    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const int Hout = Hin / 2, Wout = Win / 2;
+    const float* const base = in.p + (long)b * in.sb;
+    // ---- stage the whole 38 x 38 x 8 input window: one pixel (8 channel loads) per thread and step ----
+    float v[C::NL][kFeat];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * 256;
+        const int ir = e / C::IC, ic = e - ir * C::IC;
+        const int y = 2 * Y0 - 3 + ir, x = 2 * X0 - 3 + ic;
+        const bool ok = e < C::IR * C::IC && y >= 0 && y < Hin && x >= 0 && x < Win;
+        const unsigned off = ok ? 4u * (unsigned)(y * Win + x) : 0u;
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c) {
+            const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (long)c * in.sc) + off);
+            v[i][c] = ok ? t : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * 256;
+        const int ir = e / C::IC, ic = e - ir * C::IC;
+        if (e < C::IR * C::IC) {
+            V8 vp[M::NP];
+#pragma unroll
+            for (int c = 0; c < kFeat; ++c) {
+                T pr[M::NP];
+                M::split(v[i][c], pr);
+#pragma unroll
+                for (int pt = 0; pt < M::NP; ++pt) vp[pt][c] = pr[pt];
+            }
+#pragma unroll
+            for (int pt = 0; pt < M::NP; ++pt) *reinterpret_cast<V8*>(lds + pt * C::PARTB + (ir * C::PI + ic) * 16) = vp[pt];
+        }
+    }
+    __syncthreads();
+    // B operand of window row wr, tap kx, lane (n, q): pixel (2 (wy R + wr) + q, 2 n + kx)
+    const unsigned char* const bbase = lds + ((2 * wy * C::R + q) * C::PI + 2 * n) * 16;
+    const V8* const af = reinterpret_cast<const V8*>(afr) + lane;
+    f32x4 acc[C::NWIN];
+#pragma unroll
+    for (int i = 0; i < C::NWIN; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kx = 0; kx < 8; ++kx) {
+        V8 a[M::NP];
+#pragma unroll
+        for (int pt = 0; pt < M::NP; ++pt) a[pt] = af[(kx * M::NPF + pt) * 64];
+#pragma unroll
+        for (int wr = 0; wr < C::NWIN; ++wr) {
+            V8 bv[M::NP];
+#pragma unroll
+            for (int pt = 0; pt < M::NP; ++pt) bv[pt] = *reinterpret_cast<const V8*>(bbase + pt * C::PARTB + (2 * wr * C::PI + kx) * 16);
+#pragma unroll
+            for (int t = 0; t < M::NT; ++t) acc[wr] = M::mma(a[M::ap(t)], bv[M::bp(t)], acc[wr]);
+        }
+    }
+    // D rows of lane (n, q): (co = 2q, h = 0), (2q, 1), (2q+1, 0), (2q+1, 1); out[Y] = P0[Y] + P1[Y + 2]
+    const int X = X0 + n;
+    const float b0 = bias[2 * q], b1 = bias[2 * q + 1];
+    if (X < Wout) {
+#pragma unroll
+        for (int r = 0; r < C::R; ++r) {
+            const int Y = Y0 + wy * C::R + r;
+            if (Y < Hout) {
+                float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)Y * Wout + X;
+                p[0] = acc[r][0] + acc[r + 2][1] + b0;
+                p[out.sc] = acc[r][2] + acc[r + 2][3] + b1;
+            }
+        }
+    }
+}
+
+template <typename M>
+struct UpX {
+    static constexpr int R = 5, TH = 4 * R, TW = 16;        // window rows / input columns per block
+    static constexpr int IR = TH + 3, IC = TW + 4;
+    static constexpr int PI = 32;                           // pixel pitch = 0 (mod 16): window rows a, a + 1 on disjoint banks
+    static constexpr int ROWB = PI * 16, PARTB = IR * ROWB;
+    static constexpr int NL = cdiv_(IR * IC, 256);
+    static constexpr int LDS_BYTES = M::NP * PARTB;
+};
+
+template <typename M>
+__global__ __launch_bounds__(256, 2) void k_up_x16(Src in, Dst out, const void* __restrict__ afr /*[2 px][4 bb][NPF][64] x 8*/,
+                                                    const float* __restrict__ bias, int Hin, int Win) {
+    using C = UpX<M>;
+    typedef typename M::V8 V8;
+    typedef typename M::T T;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wy = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, q = lane >> 4;
+    const int b = blockIdx.z;
+    const int X0 = blockIdx.x * C::TW, Yb = blockIdx.y * C::TH - 1;  // first window row of the block
+    const int Hout = 2 * Hin, Wout = 2 * Win;
+    const float* const base = in.p + (long)b * in.sb;
+    float v[C::NL][kFeat];
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * 256;
+        const int ir = e / C::IC, ic = e - ir * C::IC;
+        const int y = Yb - 1 + ir, x = X0 - 2 + ic;
+        const bool ok = e < C::IR * C::IC && y >= 0 && y < Hin && x >= 0 && x < Win;
+        const unsigned off = ok ? 4u * (unsigned)(y * Win + x) : 0u;
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c) {
+            const float t = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base + (long)c * in.sc) + off);
+            v[i][c] = ok ? t : 0.f;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < C::NL; ++i) {
+        const int e = tid + i * 256;
+        const int ir = e / C::IC, ic = e - ir * C::IC;
+        if (e < C::IR * C::IC) {
+            V8 vp[M::NP];
+#pragma unroll
+            for (int c = 0; c < kFeat; ++c) {
+                T pr[M::NP];
+                M::split(v[i][c], pr);
+#pragma unroll
+                for (int pt = 0; pt < M::NP; ++pt) vp[pt][c] = pr[pt];
+            }
+#pragma unroll
+            for (int pt = 0; pt < M::NP; ++pt) *reinterpret_cast<V8*>(lds + pt * C::PARTB + (ir * C::PI + ic) * 16) = vp[pt];
+        }
+    }
+    __syncthreads();
+    // B operand of window row wr, column offset o (= ix - X + 2, 0..4), lane (n, a = q): pixel (wy R + wr + a, n + o)
+    const unsigned char* const bbase = lds + ((wy * C::R + q) * C::PI + n) * 16;
+    const V8* const af = reinterpret_cast<const V8*>(afr) + lane;
+    f32x4 acc[C::R][2];
+#pragma unroll
+    for (int i = 0; i < C::R; ++i) acc[i][0] = acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 5; ++o) {
+        V8 a0[M::NP], a1[M::NP];  // px = 0: bb = o (o < 4);  px = 1: bb = o - 1 (o > 0)
+#pragma unroll
+        for (int pt = 0; pt < M::NP; ++pt) {
+            if (o < 4) a0[pt] = af[((0 * 4 + o) * M::NPF + pt) * 64];
+            if (o > 0) a1[pt] = af[((1 * 4 + o - 1) * M::NPF + pt) * 64];
+        }
+#pragma unroll
+        for (int wr = 0; wr < C::R; ++wr) {
+            V8 bv[M::NP];
+#pragma unroll
+            for (int pt = 0; pt < M::NP; ++pt) bv[pt] = *reinterpret_cast<const V8*>(bbase + pt * C::PARTB + (wr * C::PI + o) * 16);
+#pragma unroll
+            for (int t = 0; t < M::NT; ++t) {
+                if (o < 4) acc[wr][0] = M::mma(a0[M::ap(t)], bv[M::bp(t)], acc[wr][0]);
+                if (o > 0) acc[wr][1] = M::mma(a1[M::ap(t)], bv[M::bp(t)], acc[wr][1]);
+            }
+        }
+    }
+    // D rows of lane (n, q): (co = 2q, py = 0), (2q, 1), (2q+1, 0), (2q+1, 1); acc[.][px]
+    const int X = X0 + n;
+    const float b0 = bias[2 * q], b1 = bias[2 * q + 1];
+    if (X < Win) {
+#pragma unroll
+        for (int wr = 0; wr < C::R; ++wr) {
+            const int Y = Yb + wy * C::R + wr;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int y = 2 * Y + 1 + py;
+                if (y >= 0 && y < Hout) {
+                    float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)y * Wout + 2 * X;
+                    *reinterpret_cast<float2*>(p) = make_float2(acc[wr][0][py] + b0, acc[wr][1][py] + b0);
+                    *reinterpret_cast<float2*>(p + out.sc) = make_float2(acc[wr][0][2 + py] + b1, acc[wr][1][2 + py] + b1);
+                }
+            }
+        }
+    }
+}
+
+// 0 = fp32 matrix core (default), 1 = bf16x3, 2 = fp16, 3 = bf16x2 (HN_UNET_IMPL, read once)
+inline int x16_mode() {
+    static const int mode = [] {
+        const char* e = getenv("HN_UNET_IMPL");
+        return e == nullptr ? 0 : std::strcmp(e, "bf16x3") == 0 ? 1 : std::strcmp(e, "fp16") == 0 ? 2 : std::strcmp(e, "bf16x2") == 0 ? 3 : 0;
+    }();
+    return mode;
+}
+
 template <int CA, int CB, int CC, int EPI>
 void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
     static const bool generic = getenv("HN_DC_GENERIC") != nullptr;  // A/B: force the generic chunked kernel
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
-    static const int x16 = [] {
-        const char* e = getenv("HN_UNET_IMPL");
-        return e == nullptr ? 0 : std::strcmp(e, "bf16x3") == 0 ? 1 : std::strcmp(e, "fp16") == 0 ? 2 : std::strcmp(e, "bf16x2") == 0 ? 3 : 0;
-    }();
+    const int x16 = x16_mode();
     if (x16 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC, 3>::SCALED)) {
         const dim3 g(cdiv_(W, 64), cdiv_(H, 16), batch);
         if (x16 == 1) hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
@@ -1767,6 +1973,34 @@ void pack_frag_down(const float* w, float* dst) {
                 dst[(ci * 8 + kx) * 64 + l] = w[((co * kFeat + ci) * 8 + 4 * h + k) * 8 + kx];
             }
 }
+// 16-bit fragments of the 8x8 convs (k_down_x16 / k_up_x16): [8 blocks][parts][64 lanes][8 ci]; block = kx (down) or
+// px * 4 + bb (up); lane -> (co, h | py = l & 1, q | a = l >> 4) as in the fp32 packers; the 3-part bf16 buffer
+// (k8_split_floats) is followed by the fp16 one (k8_half_floats).
+size_t k8_split_floats() { return (size_t)8 * 3 * 64 * 4; }
+size_t k8_half_floats() { return (size_t)8 * 64 * 4; }
+static void pack_k8_x16(const float* w, bool up, float* dst_split, float* dst_half) {
+    uint16_t* ds = reinterpret_cast<uint16_t*>(dst_split);
+    uint16_t* dh = reinterpret_cast<uint16_t*>(dst_half);
+    for (int blk = 0; blk < 8; ++blk)
+        for (int l = 0; l < 64; ++l)
+            for (int ci = 0; ci < kFeat; ++ci) {
+                const int co = (l & 15) >> 1, j = l & 1, k = l >> 4;
+                float v;
+                if (!up) v = w[((co * kFeat + ci) * 8 + 4 * j + k) * 8 + blk];                       // down: w[co][ci][4h + q][kx]
+                else {
+                    const int px = blk >> 2, bb = blk & 3;
+                    v = w[((ci * kFeat + co) * 8 + (6 + j - 2 * k)) * 8 + (7 - px - 2 * bb)];        // up: w[ci][co][6 + py - 2a][7 - px - 2bb]
+                }
+                const uint16_t h = bf16_rne(v);
+                const float r1 = v - bf16_f(h);
+                const uint16_t m = bf16_rne(r1);
+                const uint16_t part[3] = {h, m, bf16_rne(r1 - bf16_f(m))};
+                for (int pt = 0; pt < 3; ++pt) ds[(((size_t)blk * 3 + pt) * 64 + l) * 8 + ci] = part[pt];
+                dh[((size_t)blk * 64 + l) * 8 + ci] = f16_rne(v);
+            }
+}
+void pack_frag_down_x16(const float* w, float* dst_split, float* dst_half) { pack_k8_x16(w, false, dst_split, dst_half); }
+void pack_frag_up_x16(const float* w, float* dst_split, float* dst_half) { pack_k8_x16(w, true, dst_split, dst_half); }
 // transposed conv, weight [8][8][8][8] (ci, co, ky, kx) -> [ci][px][bb][64]:
 // lane -> (co, py = l&1, a = l>>4): w[ci][co][6 + py - 2a][7 - px - 2bb]
 void pack_frag_up(const float* w, float* dst) {
@@ -1802,6 +2036,15 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
 
 void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     const int Wout = Win / 2, Hout = Hin / 2;
+    if (const int mode = x16_mode(); mode != 0 && Wout >= 64) {  // mixed-precision modes: levels 0 and 1 on the 16-bit matrix core
+        const dim3 g(cdiv_(Wout, 16), cdiv_(Hout, 16), batch);
+        const float* split = frag + (size_t)kFeat * kFeat * 64;   // hn_load_weights stores the 16-bit twins behind the fp32 block
+        const float* half = split + k8_split_floats();
+        if (mode == 1) hipLaunchKernelGGL((k_down_x16<SplitBf16>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
+        else if (mode == 3) hipLaunchKernelGGL((k_down_x16<SplitBf16x2>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
+        else hipLaunchKernelGGL((k_down_x16<HalfF16>), g, dim3(256), 0, s, in, out, half, bias, Hin, Win);
+        return;
+    }
     // tile shape by level size: 64x16 outputs per block for the big levels, 32x16 at 64 < Wout... (more, shorter blocks
     // when there are few tiles: 17 us instead of 26 us at Wout = 64), all channels at once for the small ones
     if (Wout > 64) hipLaunchKernelGGL((k_down_mfma<4, false>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
@@ -1817,6 +2060,15 @@ void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin,
 
 void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     // window rows -1 .. Hin-1
+    if (const int mode = x16_mode(); mode != 0 && Win >= 64) {
+        const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
+        const float* split = frag + (size_t)kFeat * kFeat * 64;
+        const float* half = split + k8_split_floats();
+        if (mode == 1) hipLaunchKernelGGL((k_up_x16<SplitBf16>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
+        else if (mode == 3) hipLaunchKernelGGL((k_up_x16<SplitBf16x2>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
+        else hipLaunchKernelGGL((k_up_x16<HalfF16>), g, dim3(256), 0, s, in, out, half, bias, Hin, Win);
+        return;
+    }
     constexpr int up_small = 64;  // at and below: the all-channels-at-once kernel (few tiles, latency-bound)
     // 22 window rows per block: the Hin + 1 = 129 (257) window rows of a 128^2 (256^2) input split into 6 (12)
     // row blocks with 2 % padding instead of 9 x 16 with 10 %, and 4 x 6 x 32 = 768 blocks are exactly one
