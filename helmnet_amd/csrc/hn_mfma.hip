@@ -2036,12 +2036,13 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
 
 void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     const int Wout = Win / 2, Hout = Hin / 2;
-    if (const int mode = x16_mode(); mode != 0 && Wout >= 64) {  // mixed-precision modes: levels 0 and 1 on the 16-bit matrix core
+    // mixed-precision modes: levels 0 and 1 on the 16-bit matrix core; the 3-part split stays on the fp32 kernel
+    // here (its 71 KB window and 288 MFMAs per wave measured 55 us against 48 us)
+    if (const int mode = x16_mode(); mode >= 2 && Wout >= 64) {
         const dim3 g(cdiv_(Wout, 16), cdiv_(Hout, 16), batch);
         const float* split = frag + (size_t)kFeat * kFeat * 64;   // hn_load_weights stores the 16-bit twins behind the fp32 block
         const float* half = split + k8_split_floats();
-        if (mode == 1) hipLaunchKernelGGL((k_down_x16<SplitBf16>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
-        else if (mode == 3) hipLaunchKernelGGL((k_down_x16<SplitBf16x2>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
+        if (mode == 3) hipLaunchKernelGGL((k_down_x16<SplitBf16x2>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
         else hipLaunchKernelGGL((k_down_x16<HalfF16>), g, dim3(256), 0, s, in, out, half, bias, Hin, Win);
         return;
     }
