@@ -84,49 +84,64 @@ __device__ __forceinline__ void exchange_sync() {
     }
 }
 
-template <int N, int STRIDE, bool INV>
-__device__ __forceinline__ void fft_pass(float2 (&v)[4], float2* buf, int j, const Twiddles<N>& tw) {
+// NB independent transforms of the same direction run in lock step and share the exchange points (transform nb
+// lives at buf + nb * bstride): the passes are latency-bound, so two transforms cost little more than one.
+template <int N, int STRIDE, bool INV, int NB>
+__device__ __forceinline__ void fft_pass(float2 (&v)[NB][4], float2* buf, int bstride, int j, const Twiddles<N>& tw) {
     constexpr int T = N / 4;
     constexpr bool WAVE = (STRIDE == 1 && T == 64);
     int s = 0;
 #pragma unroll
     for (int ns = 1; ns * 4 <= N; ns *= 4) {
         const int k = j & (ns - 1);
-        if (ns > 1) {
-            float2 w1 = tw.w[s][0], w2 = tw.w[s][1], w3 = tw.w[s][2];
-            ++s;
-            if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
-            v[1] = cmul(v[1], w1);
-            v[2] = cmul(v[2], w2);
-            v[3] = cmul(v[3], w3);
-        }
-        const float2 a0 = make_float2(v[0].x + v[2].x, v[0].y + v[2].y);
-        const float2 a1 = make_float2(v[0].x - v[2].x, v[0].y - v[2].y);
-        const float2 a2 = make_float2(v[1].x + v[3].x, v[1].y + v[3].y);
-        const float2 a3 = make_float2(v[1].x - v[3].x, v[1].y - v[3].y);
-        // multiply a3 by -i (forward) or +i (inverse)
-        const float2 r3 = INV ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);
         const int j0 = ((j - k) << 2) + k;
+        float2 o[NB][4];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (ns > 1) {
+                float2 w1 = tw.w[s][0], w2 = tw.w[s][1], w3 = tw.w[s][2];
+                if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+                v[nb][1] = cmul(v[nb][1], w1);
+                v[nb][2] = cmul(v[nb][2], w2);
+                v[nb][3] = cmul(v[nb][3], w3);
+            }
+            const float2 a0 = make_float2(v[nb][0].x + v[nb][2].x, v[nb][0].y + v[nb][2].y);
+            const float2 a1 = make_float2(v[nb][0].x - v[nb][2].x, v[nb][0].y - v[nb][2].y);
+            const float2 a2 = make_float2(v[nb][1].x + v[nb][3].x, v[nb][1].y + v[nb][3].y);
+            const float2 a3 = make_float2(v[nb][1].x - v[nb][3].x, v[nb][1].y - v[nb][3].y);
+            // multiply a3 by -i (forward) or +i (inverse)
+            const float2 r3 = INV ? make_float2(-a3.y, a3.x) : make_float2(a3.y, -a3.x);
+            o[nb][0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+            o[nb][1] = make_float2(a1.x + r3.x, a1.y + r3.y);
+            o[nb][2] = make_float2(a0.x - a2.x, a0.y - a2.y);
+            o[nb][3] = make_float2(a1.x - r3.x, a1.y - r3.y);
+        }
+        if (ns > 1) ++s;
         exchange_sync<WAVE>();  // everyone finished reading the previous stage
-        buf[lds_slot<STRIDE>(j0)] = make_float2(a0.x + a2.x, a0.y + a2.y);
-        buf[lds_slot<STRIDE>(j0 + ns)] = make_float2(a1.x + r3.x, a1.y + r3.y);
-        buf[lds_slot<STRIDE>(j0 + 2 * ns)] = make_float2(a0.x - a2.x, a0.y - a2.y);
-        buf[lds_slot<STRIDE>(j0 + 3 * ns)] = make_float2(a1.x - r3.x, a1.y - r3.y);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) buf[nb * bstride + lds_slot<STRIDE>(j0 + t * ns)] = o[nb][t];
         exchange_sync<WAVE>();
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = buf[lds_slot<STRIDE>(j + t * T)];
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[nb][t] = buf[nb * bstride + lds_slot<STRIDE>(j + t * T)];
     }
     // N = 2 * 4^m: one radix-2 stage; its operands are already in this thread's registers.
     constexpr bool kOdd = (N == 32 || N == 128 || N == 512 || N == 2048);
     if (kOdd) {
         float2 wa = tw.wa, wb = tw.wb;
         if (INV) { wa.y = -wa.y; wb.y = -wb.y; }
-        const float2 p = cmul(v[2], wa), q = cmul(v[3], wb);
-        const float2 x0 = v[0], x1 = v[1];
-        v[0] = make_float2(x0.x + p.x, x0.y + p.y);
-        v[2] = make_float2(x0.x - p.x, x0.y - p.y);
-        v[1] = make_float2(x1.x + q.x, x1.y + q.y);
-        v[3] = make_float2(x1.x - q.x, x1.y - q.y);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const float2 p = cmul(v[nb][2], wa), q = cmul(v[nb][3], wb);
+            const float2 x0 = v[nb][0], x1 = v[nb][1];
+            v[nb][0] = make_float2(x0.x + p.x, x0.y + p.y);
+            v[nb][2] = make_float2(x0.x - p.x, x0.y - p.y);
+            v[nb][1] = make_float2(x1.x + q.x, x1.y + q.y);
+            v[nb][3] = make_float2(x1.x - q.x, x1.y - q.y);
+        }
     }
 }
 
@@ -150,29 +165,29 @@ struct AxisTab {
     }
 };
 
-// forward transform, two derivative multipliers, two inverse transforms, PML coefficients.
+// forward transform, two derivative multipliers, two inverse transforms (in lock step: 8 exchange passes per
+// line instead of 12), PML coefficients.
 // in: v[t] = u[j + t*T] along the axis;  out: acc[t] = (a*du + b*ddu)[j + t*T]
+// buf: this line's slot of the first LDS buffer; buf + bstride: the same slot of the second one.
 template <int N, int STRIDE>
-__device__ __forceinline__ void axis_operator(float2 (&v)[4], float2 (&acc)[4], float2* buf, int j, const AxisTab<N>& t) {
-    fft_pass<N, STRIDE, false>(v, buf, j, t.tw);
-    float2 U[4];
+__device__ __forceinline__ void axis_operator(float2 (&v)[4], float2 (&acc)[4], float2* buf, int bstride, int j, const AxisTab<N>& t) {
+    float2 f[1][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[0][q] = v[q];
+    fft_pass<N, STRIDE, false, 1>(f, buf, bstride, j, t.tw);
+    float2 d[2][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        U[q] = v[q];
-        v[q] = make_float2(-U[q].y * t.k1[q], U[q].x * t.k1[q]);  // (0, k) * U   (spectral.py:50, 281)
+        const float2 U = f[0][q];
+        d[0][q] = make_float2(-U.y * t.k1[q], U.x * t.k1[q]);  // (0, k) * U     (spectral.py:50, 281)
+        d[1][q] = make_float2(t.k2[q] * U.x, t.k2[q] * U.y);   // (-k^2, 0) * U  (spectral.py:52, 283)
     }
-    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        acc[q] = cmul(t.ca[q], v[q]);
-        v[q] = make_float2(t.k2[q] * U[q].x, t.k2[q] * U[q].y);  // (-k^2, 0) * U (spectral.py:52, 283)
-    }
-    fft_pass<N, STRIDE, true>(v, buf, j, t.tw);
+    fft_pass<N, STRIDE, true, 2>(d, buf, bstride, j, t.tw);
     constexpr float inv_n = 1.0f / N;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float2 d = cmul(t.cb[q], v[q]);
-        acc[q] = make_float2((acc[q].x + d.x) * inv_n, (acc[q].y + d.y) * inv_n);
+        const float2 p = cmul(t.ca[q], d[0][q]), r = cmul(t.cb[q], d[1][q]);
+        acc[q] = make_float2((p.x + r.x) * inv_n, (p.y + r.y) * inv_n);
     }
 }
 
@@ -201,7 +216,7 @@ template <int N, int C>
 __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict__ wf, float* __restrict__ out,
                                                           SpecPtrs t) {
     constexpr int T = N / 4, CPW = ColCfg<N, C>::CPW;
-    __shared__ float2 buf[N * C];
+    __shared__ float2 buf[2 * N * C];
     const int c = threadIdx.x, j = threadIdx.y;
     const int col0 = blockIdx.x * (C * CPW) + c;
     const long plane = (long)N * N;
@@ -227,7 +242,7 @@ __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict
         float2 v[4], acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = cur[q];
-        axis_operator<N, C>(v, acc, buf + c, j, tab);
+        axis_operator<N, C>(v, acc, buf + c, N * C, j, tab);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long o = (long)(j + q * T) * N + i * C;
@@ -275,7 +290,7 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
     const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
     const float* __restrict__ src, long src_sb, SpecPtrs t, int flags, float* __restrict__ sumsq) {
     constexpr int T = RowCfg<N>::T, R = RowCfg<N>::R, RPW = RowCfg<N>::RPW;
-    __shared__ float2 buf[N * R];
+    __shared__ float2 buf[2 * N * R];
     __shared__ float red[(T * R + 63) / 64];
     const int j = threadIdx.x, ry = threadIdx.y;
     const int row0 = blockIdx.x * (R * RPW) + ry, b = blockIdx.y;
@@ -292,7 +307,7 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
         float2 v[4], acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = cur.u[q];
-        axis_operator<N, 1>(v, acc, buf + ry * N, j, tab);
+        axis_operator<N, 1>(v, acc, buf + ry * N, N * R, j, tab);
         float* po = out + (long)b * 2 * plane + (long)row * N;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
