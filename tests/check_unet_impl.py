@@ -2,12 +2,12 @@
 process of its own): single_step against the CPU oracle on seeded inputs, and a 100-iteration free run
 against the default fp32 matrix-core path's committed golden trace.  Prints one JSON line.
 
-    HN_UNET_IMPL=bf16x3 python tools/check_unet_impl.py
+    HN_UNET_IMPL=bf16x3 python tests/check_unet_impl.py
 """
 import json, os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))  # test infrastructure: may use the oracle
 from golden_inputs import teacher_inputs
 from helmnet_amd import IterativeSolver
 from oracle import helmnet_oracle as O

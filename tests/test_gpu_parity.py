@@ -251,7 +251,7 @@ def _run_unet_impl_check(impl):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, HN_UNET_IMPL=impl)
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_unet_impl.py")], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "check_unet_impl.py")], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["impl"] == impl
