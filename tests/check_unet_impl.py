@@ -45,6 +45,13 @@ for n in (256, 128):
     d = net(x.to(dev)).cpu()
     want, _ = O.unet_forward(x, [torch.zeros(2, 2, m, m) for m in O.state_dims(n, 4)], weights)
     out[f"unet_output_{n}"] = ((d - want).abs().max() / want.abs().max()).item()
+    # against a float64 evaluation of the same network: how far each implementation (and the fp32 CPU oracle
+    # itself) is from the exact answer
+    w64 = {k: v.double() for k, v in weights.items()}
+    truth, _ = O.unet_forward(x.double(), [torch.zeros(2, 2, m, m, dtype=torch.float64) for m in O.state_dims(n, 4)], w64)
+    out[f"unet_output_{n}_vs_fp64"] = ((d.double() - truth).abs().max() / truth.abs().max()).item()
+    out[f"unet_output_{n}_vs_fp64_rms"] = ((d.double() - truth).pow(2).mean().sqrt() / truth.pow(2).mean().sqrt()).item()
+    out[f"oracle_fp32_{n}_vs_fp64"] = ((want.double() - truth).abs().max() / truth.abs().max()).item()
 with np.load(os.path.join(ROOT, "tests", "golden", "free_run.npz")) as z:
     s.set_domain_size(256, source_location=[30, 128])
     o = s.forward(torch.ones(1, 1, 256, 256, device=dev), num_iterations=100)

@@ -267,6 +267,9 @@ def test_split_bf16_experiment_keeps_the_parity_bar():
         assert out[f"unet_output_{n}"] <= 1e-5, out
     assert out["cfg1_wf_linf_vs_reference"] <= 1e-4 and out["cfg1_rmse_rel"] <= 2e-2, out
     assert out["readme300_wf_linf_vs_reference"] <= 1e-4 and out["readme300_rmse_rel"] <= 2e-2, out
+    # not a reduced-precision path: against a float64 evaluation it is at least as close as the fp32 CPU oracle
+    for n in (256, 128):
+        assert out[f"unet_output_{n}_vs_fp64"] <= 1.25 * out[f"oracle_fp32_{n}_vs_fp64"], out
 
 
 def test_two_term_bf16_split_mode():
