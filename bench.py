@@ -232,6 +232,15 @@ def main():
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        # secondary line for the HBM-bound part of the path (north_star: "achieved HBM GB/s for the FFT path"):
+        # compulsory bytes of get_residual (5 planes per sample) over the shortest bracketed launches of the two
+        # spectral kernels in the fully bracketed warm-up pass
+        sp_us = (pmin.get("spectral_cols", 0.0) + pmin.get("spectral_rows", 0.0)) * 1e3
+        if sp_us > 0:
+            sp_bytes = spectral_bytes(n) * B
+            line["hbm_path"] = {"kernels": ["spectral_cols", "spectral_rows"], "bound": "hbm", "bytes_per_step": sp_bytes,
+                                "us_per_step": round(sp_us, 2), "achieved": round(sp_bytes / (sp_us * 1e-6) / 1e9, 1),
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(sp_bytes / (sp_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         if args.breakdown:
             # event brackets around EVERY kernel stall the stream (the host cannot issue ~70 API calls per
             # step fast enough), so the average over-states a kernel that follows a host gap; the shortest
