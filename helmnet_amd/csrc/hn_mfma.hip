@@ -738,16 +738,17 @@ struct HalfF16 {
     __device__ static __forceinline__ f32x4 mma(const V8& a, const V8& b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 
-template <int CA, int CB, int CC, int NP>
+template <int CA, int CB, int CC, int NP, int TH_ = 16>
 struct B3Cfg {
-    static constexpr int TH = 16, TW = 64;
+    static constexpr int TH = TH_, TW = 64;
     static constexpr int CIN = CA + CB + CC, NG = (CIN + 7) / 8;
     static constexpr int IR = TH + 4, PI = TW + 4;          // staged rows / pixels per row
     static constexpr int ROWB = PI * 16, PARTB = IR * ROWB; // bytes: one pixel = 8 bf16
     static constexpr int MR = TH + 2, MPARTB = MR * ROWB;
-    static constexpr int NR1 = 9, NR2 = 8;
+    static constexpr int NR1 = MR / 2, NR2 = TH / 2;        // rows per wave: two halves of a 32-pixel strip (9 / 8, or 5 / 4 for 8-row tiles)
+    static constexpr int NV = MR > 16 ? 2 : 1;              // 16-row MFMA groups of the extra pair column
     static constexpr int NP2 = IR * PI / 2, NL = cdiv_(NP2, 256);
-    static constexpr int LDS_BYTES = NP * PARTB;            // 65280 for 3 parts; the mid tensor (NP * MPARTB) reuses it
+    static constexpr int LDS_BYTES = NP * PARTB;            // 65280 for 3 parts x 16-row tiles; the mid tensor (NP * MPARTB) reuses it
     static constexpr bool SCALED = CC > 0;
 };
 
@@ -783,9 +784,9 @@ __device__ __forceinline__ void x16_rows(f32x4 (&acc)[NR], const typename M::V8 
     }
 }
 
-template <typename M, int CA, int CB, int CC, int EPI>
-__global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
-    using C = B3Cfg<CA, CB, CC, M::NP>;
+template <typename M, int CA, int CB, int CC, int EPI, int TH = 16>
+__global__ __launch_bounds__(256, TH == 16 ? 2 : 3) void k_dc_x16(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
+    using C = B3Cfg<CA, CB, CC, M::NP, TH>;
     typedef typename M::V8 V8;
     typedef typename M::V2 V2;
     typedef typename M::T T;
@@ -872,8 +873,8 @@ __global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst o
     // ---- conv1 ----
     const int rb1 = C::NR1 * half;
     const int bs1 = (rb1 * C::PI + 2 * (16 * strip + n) + q) * 16;
-    const bool has_v = wave < 2;
-    const int vrow0 = wave == 0 ? 0 : 2;
+    const bool has_v = wave < C::NV;                    // 18 mid rows: two groups (rows 0-15, 2-17); 10 mid rows: one
+    const int vrow0 = wave == 0 ? 0 : C::MR - 16;
     const int bsv = ((vrow0 + n) * C::PI + 64 + q) * 16;
     const float bias0 = w.b1[2 * q], bias1 = w.b1[2 * q + 1];
     f32x4 acc1[C::NR1], accv[1];
@@ -943,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void k_dc_x16(Src sa, Src sb, Src sc, Dst o
                 put(acc1[r], rb1 + r, pc, yin ? mk : zz, yin ? sk : zz);
             }
         }
-        if (has_v && (wave == 0 || n >= 14)) {
+        if (has_v && (wave == 0 ? n < C::MR : n >= 14)) {
             const int y = y0 - 1 + vrow0 + n, x = x0 + 63;
             const bool yin = y >= 0 && y < H;
             const float m0 = (yin && x < W) ? 1.f : 0.f, m1 = (yin && x + 1 < W) ? 1.f : 0.f;
@@ -1857,6 +1858,14 @@ void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, 
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
     const int x16 = x16_mode();
     if (x16 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC, 3>::SCALED)) {
+        static const int th8 = getenv("HN_X16_TH8") ? atoi(getenv("HN_X16_TH8")) : -1;   // experiment: 8-row tiles (more, smaller blocks per CU)
+        if (th8 > 0 || (th8 < 0 && x16 == 1)) {   // default: the 3-part split (65 KB per 16-row tile -> 39 KB, 3 blocks per CU: +4 % it/s)
+            const dim3 g8(cdiv_(W, 64), cdiv_(H, 8), batch);
+            if (x16 == 1) hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI, 8>), g8, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+            else if (x16 == 2) hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI, 8>), g8, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+            else hipLaunchKernelGGL((k_dc_x16<SplitBf16x2, CA, CB, CC, EPI, 8>), g8, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+            return;
+        }
         const dim3 g(cdiv_(W, 64), cdiv_(H, 16), batch);
         if (x16 == 1) hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
         else if (x16 == 2) hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
