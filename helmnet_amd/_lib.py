@@ -18,6 +18,11 @@ _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhelmnet
 _lib = None
 
 HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2}
+# enum hn_precision / hn_option / hn_counter of include/helmnet_hip.h
+HN_PRECISION = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16x2": 3, "valu": 4}
+HN_OPTION = {"lanes": 0, "side_stream": 1, "graph": 2}
+HN_COUNTER = {"graph_replays": 0, "eager_iterations": 1, "graphs_captured": 2}
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); every symbol include/helmnet_hip.h declares
 SYMBOLS = {
@@ -25,6 +30,10 @@ SYMBOLS = {
     "hn_create": (c_int, [POINTER(c_void_p), c_int]),
     "hn_destroy": (None, [c_void_p]),
     "hn_last_error": (c_char_p, [c_void_p]),
+    "hn_set_unet_precision": (c_int, [c_void_p, c_int]),
+    "hn_get_unet_precision": (c_int, [c_void_p]),
+    "hn_set_option": (c_int, [c_void_p, c_int, c_int]),
+    "hn_get_counter": (c_int64, [c_void_p, c_int]),
     "hn_weight_count": (c_size_t, [c_int, c_int, c_int]),
     "hn_load_weights": (c_int, [c_void_p, POINTER(c_float), c_size_t, c_int, c_int, c_int, c_int]),
     "hn_set_domain": (c_int, [c_void_p, c_int, c_int, c_float, c_float]),
@@ -67,8 +76,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library does not export the symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.hn_abi_version() != 1:
-        raise HelmnetHipError(f"ABI version mismatch: library reports {lib.hn_abi_version()}, binding expects 1")
+    if lib.hn_abi_version() != ABI_VERSION:
+        raise HelmnetHipError(f"ABI version mismatch: library reports {lib.hn_abi_version()}, binding expects {ABI_VERSION}")
     _lib = lib
     return lib
 

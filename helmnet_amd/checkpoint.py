@@ -42,8 +42,9 @@ def read_lightning_checkpoint(path: str, map_location="cpu") -> Tuple[Dict, Dict
 
 
 def read_exported_weights(npz_path: str, hparams_json: str) -> Tuple[Dict, Dict[str, torch.Tensor]]:
-    """The `f.*` tensors + hparams exported from the shipped checkpoint (tests/golden/jcp_*);
-    used where the reference checkout (and so the .ckpt) is not available, e.g. the GPU box."""
+    """The `f.*` tensors + hparams exported from the shipped (MIT-licensed) checkpoint, carried as package
+    data (helmnet_amd/data/jcp_*); used where the reference checkout (and so the .ckpt) is not available,
+    e.g. the GPU box."""
     with open(hparams_json) as f:
         hp = json.load(f)
     with np.load(npz_path) as z:
@@ -52,5 +53,5 @@ def read_exported_weights(npz_path: str, hparams_json: str) -> Tuple[Dict, Dict[
 
 
 def default_exported_weights() -> Tuple[str, str]:
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
     return os.path.join(root, "jcp_weights.npz"), os.path.join(root, "jcp_hparams.json")

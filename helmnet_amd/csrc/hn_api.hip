@@ -145,17 +145,68 @@ int hn_create(hn_ctx** out, int device_id) {
         return fail(nullptr, HN_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, HN_ERR_UNSUPPORTED, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(nullptr, HN_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    if (prev >= 0 && prev != device_id) (void)hipSetDevice(prev);
     hn_ctx* c = new (std::nothrow) hn_ctx();
     if (!c) return fail(nullptr, HN_ERR_NOMEM, "out of host memory");
     c->device = device_id;
+    // environment variables are defaults only, read here and nowhere else
+    if (const char* v = getenv("HN_UNET_IMPL")) {
+        c->precision = std::strcmp(v, "bf16x3") == 0 ? HN_PREC_BF16X3 : std::strcmp(v, "fp16") == 0 ? HN_PREC_FP16
+                     : std::strcmp(v, "bf16x2") == 0 ? HN_PREC_BF16X2 : std::strcmp(v, "valu") == 0 ? HN_PREC_FP32_VALU : HN_PREC_FP32;
+    }
+    if (const char* v = getenv("HN_STREAMS")) { const int n = atoi(v); c->opt_lanes = n < 1 ? 1 : n > 8 ? 8 : n; }
+    if (const char* v = getenv("HN_SIDE_STREAM")) c->opt_side_stream = atoi(v) != 0;
+    if (const char* v = getenv("HN_GRAPH")) c->opt_graph = atoi(v) != 0;
     *out = c;
     return HN_OK;
 }
 
+int hn_set_unet_precision(hn_ctx* ctx, int precision) {
+    if (!ctx) return HN_ERR_ARG;
+    if (precision < HN_PREC_FP32 || precision > HN_PREC_FP32_VALU)
+        return fail(ctx, HN_ERR_ARG, "hn_set_unet_precision: unknown mode %d", precision);
+    if (precision != ctx->precision) clear_step_graphs(ctx);
+    ctx->precision = precision;
+    return HN_OK;
+}
+
+int hn_get_unet_precision(const hn_ctx* ctx) { return ctx ? ctx->precision : HN_ERR_ARG; }
+
+int hn_set_option(hn_ctx* ctx, int option, int value) {
+    if (!ctx) return HN_ERR_ARG;
+    switch (option) {
+        case HN_OPT_LANES:
+            if (value < 1 || value > 8) return fail(ctx, HN_ERR_ARG, "HN_OPT_LANES must be in [1, 8] (got %d)", value);
+            ctx->opt_lanes = value;
+            break;
+        case HN_OPT_SIDE_STREAM: ctx->opt_side_stream = value != 0; break;
+        case HN_OPT_GRAPH: ctx->opt_graph = value != 0; break;
+        default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
+    }
+    clear_step_graphs(ctx);
+    return HN_OK;
+}
+
+int64_t hn_get_counter(const hn_ctx* ctx, int counter) {
+    if (!ctx) return -1;
+    switch (counter) {
+        case HN_CNT_GRAPH_REPLAYS: return ctx->graph_replays;
+        case HN_CNT_EAGER_ITERATIONS: return ctx->eager_iterations;
+        case HN_CNT_GRAPHS_CAPTURED: return ctx->graphs_captured;
+        default: return -1;
+    }
+}
+
 void hn_destroy(hn_ctx* ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
+    DeviceGuard guard(ctx);   // runs from Engine.__del__ at arbitrary times: must not leave another device current
+    (void)hipDeviceSynchronize();
+    clear_step_graphs(ctx);
+    if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
+    (void)hipFree(ctx->it_counter);
     free_workspace(ctx);
     spec_free(ctx->tab);
     (void)hipFree(ctx->wdev);
@@ -196,7 +247,9 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         return fail(ctx, HN_ERR_UNSUPPORTED, "activation kind %d is not implemented (prelu / relu / leakyrelu only)", act_kind);
     const size_t want = hn_weight_count(features, depth, state_ch);
     if (n_floats != want) return fail(ctx, HN_ERR_ARG, "weight blob has %zu floats, expected %zu", n_floats, want);
-    HN_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx);
+    HN_HIP(ctx, hipDeviceSynchronize());  // nothing may still read the old weights
+    clear_step_graphs(ctx);
     (void)hipFree(ctx->wdev);
     ctx->wdev = nullptr;
     HN_HIP(ctx, hipMalloc((void**)&ctx->wdev, want * sizeof(float)));
@@ -257,8 +310,6 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         for (int d = 0; d < depth; ++d) { ctx->f_sig[d][0] = nxt(); ctx->f_sig[d][1] = nxt(); ctx->f_down[d] = nxt(); nxt(); nxt(); }
         for (int d = 0; d <= depth; ++d) { ctx->f_dec[d][0] = nxt(); ctx->f_dec[d][1] = nxt(); }
         for (int d = 0; d < depth; ++d) ctx->f_up[d] = nxt();
-        const char* impl = getenv("HN_UNET_IMPL");
-        ctx->use_valu = impl && std::strcmp(impl, "valu") == 0;
     }
     if (ctx->have_weights && ctx->depth != depth) free_workspace(ctx);
     ctx->depth = depth;
@@ -272,7 +323,9 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
 
 int hn_set_domain(hn_ctx* ctx, int n, int pml, float sigma_max, float k) {
     if (!ctx) return HN_ERR_ARG;
-    HN_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx);
+    HN_HIP(ctx, hipDeviceSynchronize());
+    clear_step_graphs(ctx);
     if (n % 16 != 0) return fail(ctx, HN_ERR_ARG, "domain size %d must be divisible by 16", n);
     if (!(k > 0.f) || !(sigma_max >= 0.f)) return fail(ctx, HN_ERR_ARG, "k must be > 0 and sigma_max >= 0");
     if (n != ctx->tab.n) free_workspace(ctx);
@@ -287,6 +340,7 @@ int hn_set_domain(hn_ctx* ctx, int n, int pml, float sigma_max, float k) {
 int hn_get_sigmas(hn_ctx* ctx, float* out, void* stream) {
     if (!ctx || !out) return fail(ctx, HN_ERR_ARG, "hn_get_sigmas: NULL argument");
     if (ctx->tab.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
+    DeviceGuard guard(ctx);
     HN_HIP(ctx, hipMemcpyAsync(out, ctx->tab.sigmas, sizeof(float) * 2 * ctx->tab.n * ctx->tab.n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return HN_OK;
 }
@@ -297,8 +351,9 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
     int rc = check_ready(ctx, max_batch);
     if (rc != HN_OK) return rc;
     if (max_batch <= ctx->cap_batch) return HN_OK;
-    HN_HIP(ctx, hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx);
     HN_HIP(ctx, hipDeviceSynchronize());  // nothing may still be using the old workspace
+    clear_step_graphs(ctx);
     free_workspace(ctx);
     const int n = ctx->tab.n, depth = ctx->depth;
     for (int d = 0; d <= depth; ++d) {
@@ -333,6 +388,7 @@ int hn_profile_stride(hn_ctx* ctx, int every_nth) {
 
 int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids) {
     if (!ctx || !total_ms || !count) return fail(ctx, HN_ERR_ARG, "hn_profile_collect: NULL argument");
+    DeviceGuard guard(ctx);
     for (auto& r : ctx->prof_recs) {
         HN_HIP(ctx, hipEventSynchronize(r.b));
         float ms = 0.f;
@@ -357,6 +413,7 @@ int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids)
 int hn_laplacian(hn_ctx* ctx, const float* wf, float* out, int batch, void* stream) {
     if (!ctx || !wf || !out) return fail(ctx, HN_ERR_ARG, "hn_laplacian: NULL argument");
     if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
+    DeviceGuard guard(ctx);
     return spec_apply(ctx, wf, out, nullptr, nullptr, 1, batch, nullptr, (hipStream_t)stream);
 }
 
@@ -365,6 +422,7 @@ int hn_residual(hn_ctx* ctx, const float* wf, const float* k_sq, const float* sr
     if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
     if (src_batch != 1 && src_batch != batch)
         return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
+    DeviceGuard guard(ctx);
     return spec_apply(ctx, wf, res, k_sq, src, src_batch, batch, nullptr, (hipStream_t)stream);
 }
 
@@ -372,6 +430,7 @@ int hn_rmse(hn_ctx* ctx, const float* res, float* rmse, int batch, void* stream)
     if (!ctx || !res || !rmse) return fail(ctx, HN_ERR_ARG, "hn_rmse: NULL argument");
     if (ctx->tab.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
     if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
+    DeviceGuard guard(ctx);
     hipStream_t s = (hipStream_t)stream;
     const long per = 2L * ctx->tab.n * ctx->tab.n;
     HN_HIP(ctx, hipMemsetAsync(rmse, 0, sizeof(float) * batch, s));
@@ -386,6 +445,7 @@ int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states
     if (states_in == states_out) return fail(ctx, HN_ERR_ARG, "hn_unet: states_in must not alias states_out");
     int rc = check_ready(ctx, batch);
     if (rc != HN_OK) return rc;
+    DeviceGuard guard(ctx);
     if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
     const long plane = (long)ctx->tab.n * ctx->tab.n;
     const Src wf{in6, kInCh * plane, plane, 1.f};
@@ -394,36 +454,28 @@ int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states
     return unet_forward(ctx, wf, res, sig, states_in, states_out, d_out, nullptr, batch, (hipStream_t)stream);
 }
 
-int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq, const float* src, int src_batch, int batch,
-            int n_iter, float* res_hist, float* wf_hist, float* st_hist, float* rmse_hist, void* stream) {
-    if (!ctx || !wf || !res || !states || !k_sq || !src) return fail(ctx, HN_ERR_ARG, "hn_step: NULL argument");
-    if (n_iter < 0) return fail(ctx, HN_ERR_ARG, "n_iter must be >= 0");
-    if (src_batch != 1 && src_batch != batch)
-        return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
-    int rc = check_ready(ctx, batch);
-    if (rc != HN_OK) return rc;
-    if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
-    hipStream_t s = (hipStream_t)stream;
-    const long plane = (long)ctx->tab.n * ctx->tab.n;
-    const long L = ctx->state_len;
-    if (rmse_hist && n_iter > 0) HN_HIP(ctx, hipMemsetAsync(rmse_hist, 0, sizeof(float) * (size_t)n_iter * batch, s));
-    // ---- sub-batch pipelining over internal streams ----
-    if (ctx->n_streams == 0) {
-        const char* e = getenv("HN_STREAMS");
-        int ns = e ? atoi(e) : 1;  // HN_STREAMS=2: two staggered sub-batches, one fills the CUs while the other walks the small
-                                  // levels; with block counts tuned to the full batch it measures 4 % slower, so it is off
-        ns = ns < 1 ? 1 : (ns > 8 ? 8 : ns);
-        for (int j = 0; j < ns; ++j) {
-            HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));
-            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming));
-            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[j], hipEventDisableTiming));
-        }
-        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-        ctx->n_streams = ns;
+}  // extern "C" (continued below)
+
+namespace hn {
+namespace {
+
+struct StepArgs {
+    float *wf, *res, *states;
+    const float *k_sq, *src;
+    int src_batch, batch;
+    float* rmse_hist;   // base of the [n_iter, batch] table (rows are selected on the device through it_counter)
+};
+
+int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side) {
+    while (ctx->n_streams < ns) {
+        const int j = ctx->n_streams;
+        HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));
+        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming));
+        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[j], hipEventDisableTiming));
+        ctx->n_streams = j + 1;
     }
-    int ns = ctx->n_streams;
-    if (batch < 2 * ns) ns = 1;                       // tiny batches: not worth splitting
-    static const bool want_side = getenv("HN_SIDE_STREAM") == nullptr || atoi(getenv("HN_SIDE_STREAM")) != 0;
+    if (!ctx->ev_fork) HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    if (!ctx->it_counter) HN_HIP(ctx, hipMalloc((void**)&ctx->it_counter, 8 * sizeof(int)));
     if (want_side) {
         for (int j = 0; j < ns; ++j) {
             auto& sl = ctx->side[j];
@@ -433,48 +485,171 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
             HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
     }
-    if (n_iter == 0) ns = 1;
-    if (ns > 1) HN_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
-    int lo[9];
-    for (int j = 0; j <= ns; ++j) lo[j] = (int)((long)batch * j / ns);
-    for (int it = 0; it < n_iter; ++it) {
-        for (int j = 0; j < ns; ++j) {
-            hipStream_t sj = ns > 1 ? ctx->sub_stream[j] : s;
-            const int b0 = lo[j], nb = lo[j + 1] - lo[j];
-            if (ns > 1 && it == 0) {
-                HN_HIP(ctx, hipStreamWaitEvent(sj, ctx->ev_fork, 0));
-                // stagger: sub-batch j starts once sub-batch j-1 is past its first level-0 encoder kernels
-                if (j > 0) HN_HIP(ctx, hipStreamWaitEvent(sj, ctx->ev_stagger[j - 1], 0));
+    return HN_OK;
+}
+
+// One solver iteration of samples [b0, b0 + nb) on stream sj (hybridnet.py:558-584): the UNet update with the
+// wavefield updated in place by its last kernel, then the residual of the new wavefield.  `parity` selects the
+// direction of the hidden-state ping-pong (0: caller's buffer -> library buffer).
+int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, int lane, hipStream_t sj, hipEvent_t stagger) {
+    const long plane = (long)ctx->tab.n * ctx->tab.n, L = ctx->state_len;
+    float* wf_j = a.wf + (size_t)b0 * 2 * plane;
+    float* res_j = a.res + (size_t)b0 * 2 * plane;
+    float* st_user = a.states + (size_t)b0 * kState * L;
+    float* st_tmp = ctx->st_tmp + (size_t)b0 * kState * L;
+    const Src s_wf{wf_j, 2 * plane, plane, 1.f};
+    const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
+    const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
+    int rc = unet_forward(ctx, s_wf, s_res, s_sig, parity ? st_tmp : st_user, parity ? st_user : st_tmp, nullptr, wf_j, nb, sj, b0,
+                          stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr);
+    if (rc != HN_OK) return rc;
+    const float* src_j = a.src_batch == 1 ? a.src : a.src + (size_t)b0 * 2 * plane;
+    return spec_apply(ctx, wf_j, res_j, a.k_sq + (size_t)b0 * plane, src_j, a.src_batch == 1 ? 1 : nb, nb,
+                      a.rmse_hist ? a.rmse_hist + b0 : nullptr, sj, a.rmse_hist ? ctx->it_counter + lane : nullptr, a.batch);
+}
+
+void destroy_graph_entry(hn_ctx::StepGraph& g) {
+    for (auto& e : g.exec) { if (e) (void)hipGraphExecDestroy(e); e = nullptr; }
+}
+
+// The captured pair of iterations (both ping-pong directions) for exactly these arguments, or nullptr when
+// capture is unavailable (the caller then launches the kernels one by one).
+hn_ctx::StepGraph* step_graph(hn_ctx* ctx, const StepArgs& a) {
+    ++ctx->graph_clock;
+    for (auto& g : ctx->graphs)
+        if (g.wf == a.wf && g.res == a.res && g.states == a.states && g.k_sq == a.k_sq && g.src == a.src && g.rmse == a.rmse_hist &&
+            g.src_batch == a.src_batch && g.batch == a.batch && g.precision == ctx->precision && g.side == ctx->opt_side_stream) {
+            g.last_use = ctx->graph_clock;
+            return &g;
+        }
+    if (!ctx->cap_stream && hipStreamCreateWithFlags(&ctx->cap_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    hn_ctx::StepGraph g;
+    g.wf = a.wf; g.res = a.res; g.states = a.states; g.k_sq = a.k_sq; g.src = a.src; g.rmse = a.rmse_hist;
+    g.src_batch = a.src_batch; g.batch = a.batch; g.precision = ctx->precision; g.side = ctx->opt_side_stream;
+    for (int parity = 0; parity < 2; ++parity) {
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) { destroy_graph_entry(g); (void)hipGetLastError(); return nullptr; }
+        const int rc = one_iteration(ctx, a, parity, 0, a.batch, 0, ctx->cap_stream, nullptr);
+        const hipError_t e = hipStreamEndCapture(ctx->cap_stream, &graph);
+        if (rc != HN_OK || e != hipSuccess || graph == nullptr ||
+            hipGraphInstantiate(&g.exec[parity], graph, nullptr, nullptr, 0) != hipSuccess) {
+            if (graph) (void)hipGraphDestroy(graph);
+            destroy_graph_entry(g);
+            (void)hipGetLastError();
+            return nullptr;
+        }
+        (void)hipGraphDestroy(graph);
+    }
+    g.last_use = ctx->graph_clock;
+    ++ctx->graphs_captured;
+    if (ctx->graphs.size() >= 8) {  // least recently used entry makes room
+        size_t victim = 0;
+        for (size_t i = 1; i < ctx->graphs.size(); ++i) if (ctx->graphs[i].last_use < ctx->graphs[victim].last_use) victim = i;
+        destroy_graph_entry(ctx->graphs[victim]);
+        ctx->graphs[victim] = g;
+        return &ctx->graphs[victim];
+    }
+    ctx->graphs.push_back(g);
+    return &ctx->graphs.back();
+}
+
+}  // namespace
+
+void clear_step_graphs(hn_ctx* ctx) {
+    for (auto& g : ctx->graphs) destroy_graph_entry(g);
+    ctx->graphs.clear();
+}
+
+}  // namespace hn
+
+extern "C" {
+
+int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq, const float* src, int src_batch, int batch,
+            int n_iter, float* res_hist, float* wf_hist, float* st_hist, float* rmse_hist, void* stream) {
+    if (!ctx || !wf || !res || !states || !k_sq || !src) return fail(ctx, HN_ERR_ARG, "hn_step: NULL argument");
+    if (n_iter < 0) return fail(ctx, HN_ERR_ARG, "n_iter must be >= 0");
+    if (src_batch != 1 && src_batch != batch)
+        return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
+    int rc = check_ready(ctx, batch);
+    if (rc != HN_OK) return rc;
+    DeviceGuard guard(ctx);
+    if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
+    if (n_iter == 0) return HN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const long plane = (long)ctx->tab.n * ctx->tab.n;
+    const long L = ctx->state_len;
+    int ns = ctx->opt_lanes;
+    if (batch < 2 * ns) ns = 1;                       // tiny batches: not worth splitting
+    if ((rc = ensure_step_resources(ctx, ns, ctx->opt_side_stream != 0)) != HN_OK) return rc;
+    if (rmse_hist) {
+        HN_HIP(ctx, hipMemsetAsync(rmse_hist, 0, sizeof(float) * (size_t)n_iter * batch, s));
+        HN_HIP(ctx, hipMemsetAsync(ctx->it_counter, 0, 8 * sizeof(int), s));
+    }
+    const StepArgs a{wf, res, states, k_sq, src, src_batch, batch, rmse_hist};
+    const size_t fb_all = sizeof(float) * (size_t)batch * 2 * plane, sb_all = sizeof(float) * (size_t)batch * kState * L;
+    if (ns == 1) {
+        // One lane: an iteration is a fixed kernel sequence over fixed buffers (the hidden states ping-pong between the
+        // caller's buffer and the library's), so it is captured once per direction and replayed -- one host call per
+        // iteration instead of ~25 launches and 4 event operations.  Iterations in which hn_profile_* brackets a kernel,
+        // and everything when capture is unavailable, are launched kernel by kernel; the two forms are interchangeable
+        // iteration by iteration (same kernels, same arguments, same order).
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        const bool caller_capturing = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        hn_ctx::StepGraph* g = nullptr;
+        if (ctx->opt_graph && n_iter >= 4 && !caller_capturing) g = step_graph(ctx, a);
+        for (int it = 0; it < n_iter; ++it) {
+            bool bracket = false;
+            if (ctx->prof_mask) {
+                for (int id = 0; id < KID_COUNT; ++id)
+                    if ((ctx->prof_mask >> id & 1ull) && ctx->prof_seen[id] % ctx->prof_stride == 0) bracket = true;
             }
-            float* wf_j = wf + (size_t)b0 * 2 * plane;
-            float* res_j = res + (size_t)b0 * 2 * plane;
-            float* st_user = states + (size_t)b0 * kState * L;
-            float* st_tmp = ctx->st_tmp + (size_t)b0 * kState * L;
-            float* st_in = (it & 1) ? st_tmp : st_user;
-            float* st_out = (it & 1) ? st_user : st_tmp;
-            const Src s_wf{wf_j, 2 * plane, plane, 1.f};
-            const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
-            const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
-            hipEvent_t stg = (ns > 1 && it == 0 && j + 1 < ns) ? ctx->ev_stagger[j] : nullptr;
-            if ((rc = unet_forward(ctx, s_wf, s_res, s_sig, st_in, st_out, nullptr, wf_j, nb, sj, b0, stg,
-                                   want_side ? &ctx->side[j] : nullptr)) != HN_OK) return rc;
-            const float* src_j = src_batch == 1 ? src : src + (size_t)b0 * 2 * plane;
-            if ((rc = spec_apply(ctx, wf_j, res_j, k_sq + (size_t)b0 * plane, src_j, src_batch == 1 ? 1 : nb, nb,
-                                 rmse_hist ? rmse_hist + (size_t)it * batch + b0 : nullptr, sj)) != HN_OK) return rc;
-            const size_t fb = sizeof(float) * (size_t)nb * 2 * plane, sb = sizeof(float) * (size_t)nb * kState * L;
-            if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + ((size_t)it * batch + b0) * 2 * plane, res_j, fb, hipMemcpyDeviceToDevice, sj));
-            if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf_hist + ((size_t)it * batch + b0) * 2 * plane, wf_j, fb, hipMemcpyDeviceToDevice, sj));
-            if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + ((size_t)it * batch + b0) * kState * L, st_out, sb, hipMemcpyDeviceToDevice, sj));
-            if (it == n_iter - 1) {
-                if (n_iter & 1) HN_HIP(ctx, hipMemcpyAsync(st_user, st_tmp, sb, hipMemcpyDeviceToDevice, sj));
-                if (ns > 1) {
+            if (g != nullptr && !bracket) {
+                HN_HIP(ctx, hipGraphLaunch(g->exec[it & 1], s));
+                ++ctx->graph_replays;
+                if (ctx->prof_mask)
+                    for (int id = 0; id < KID_COUNT; ++id) if (ctx->prof_mask >> id & 1ull) ++ctx->prof_seen[id];
+            } else {
+                if ((rc = one_iteration(ctx, a, it & 1, 0, batch, 0, s, nullptr)) != HN_OK) return rc;
+                ++ctx->eager_iterations;
+            }
+            if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + (size_t)it * batch * 2 * plane, res, fb_all, hipMemcpyDeviceToDevice, s));
+            if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf_hist + (size_t)it * batch * 2 * plane, wf, fb_all, hipMemcpyDeviceToDevice, s));
+            if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + (size_t)it * batch * kState * L, (it & 1) ? states : ctx->st_tmp, sb_all, hipMemcpyDeviceToDevice, s));
+        }
+        if (n_iter & 1) HN_HIP(ctx, hipMemcpyAsync(states, ctx->st_tmp, sb_all, hipMemcpyDeviceToDevice, s));
+    } else {
+        // ---- sub-batch pipelining over internal streams: while one sub-batch walks the small, latency-bound UNet
+        // levels the other keeps the CUs busy (samples are independent) ----
+        HN_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+        int lo[9];
+        for (int j = 0; j <= ns; ++j) lo[j] = (int)((long)batch * j / ns);
+        for (int it = 0; it < n_iter; ++it) {
+            for (int j = 0; j < ns; ++j) {
+                hipStream_t sj = ctx->sub_stream[j];
+                const int b0 = lo[j], nb = lo[j + 1] - lo[j];
+                if (it == 0) {
+                    HN_HIP(ctx, hipStreamWaitEvent(sj, ctx->ev_fork, 0));
+                    // stagger: sub-batch j starts once sub-batch j-1 is past its first level-0 encoder kernels
+                    if (j > 0) HN_HIP(ctx, hipStreamWaitEvent(sj, ctx->ev_stagger[j - 1], 0));
+                }
+                hipEvent_t stg = (it == 0 && j + 1 < ns) ? ctx->ev_stagger[j] : nullptr;
+                if ((rc = one_iteration(ctx, a, it & 1, b0, nb, j, sj, stg)) != HN_OK) return rc;
+                const size_t fb = sizeof(float) * (size_t)nb * 2 * plane, sb = sizeof(float) * (size_t)nb * kState * L;
+                float* st_user = states + (size_t)b0 * kState * L;
+                float* st_tmp = ctx->st_tmp + (size_t)b0 * kState * L;
+                if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + ((size_t)it * batch + b0) * 2 * plane, res + (size_t)b0 * 2 * plane, fb, hipMemcpyDeviceToDevice, sj));
+                if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf_hist + ((size_t)it * batch + b0) * 2 * plane, wf + (size_t)b0 * 2 * plane, fb, hipMemcpyDeviceToDevice, sj));
+                if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + ((size_t)it * batch + b0) * kState * L, (it & 1) ? st_user : st_tmp, sb, hipMemcpyDeviceToDevice, sj));
+                if (it == n_iter - 1) {
+                    if (n_iter & 1) HN_HIP(ctx, hipMemcpyAsync(st_user, st_tmp, sb, hipMemcpyDeviceToDevice, sj));
                     HN_HIP(ctx, hipEventRecord(ctx->ev_join[j], sj));
                     HN_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join[j], 0));
                 }
             }
+            ++ctx->eager_iterations;
         }
     }
-    if (rmse_hist && n_iter > 0) {
+    if (rmse_hist) {
         const int count = n_iter * batch;
         hipLaunchKernelGGL(k_rmse_finalize, dim3((count + 255) / 256), dim3(256), 0, s, rmse_hist, count, 1.0f / (float)(2 * plane));
         HN_HIP(ctx, hipGetLastError());

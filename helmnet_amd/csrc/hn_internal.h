@@ -74,7 +74,12 @@ struct hn_ctx {
     float* fragdev = nullptr;
     const float *f_inc[2]{}, *f_sig[hn::kMaxDepth][2]{}, *f_dec[hn::kMaxDepth + 1][2]{};
     const float *f_down[hn::kMaxDepth]{}, *f_up[hn::kMaxDepth]{};
-    bool use_valu = false;  // HN_UNET_IMPL=valu selects the VALU direct-conv kernels (A/B testing)
+    // arithmetic of the UNet convolutions (hn_set_unet_precision; default from HN_UNET_IMPL at hn_create only)
+    int precision = HN_PREC_FP32;
+    // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
+    int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
+    int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
+    int opt_graph = 1;         // hn_step replays one captured iteration (HIP graph) instead of ~25 launches
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
     // domain
@@ -92,9 +97,21 @@ struct hn_ctx {
     // conv_state kernels run on a side stream per pipeline lane (HN_SIDE_STREAM, hn_step only)
     struct SideLane { hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr; };
     SideLane side[8];
-    int n_streams = 0;
+    int n_streams = 0;         // internal streams created so far
     hipStream_t sub_stream[8]{};
     hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};
+    int* it_counter = nullptr;  // device, one per lane: iterations done in the running hn_step (row index of rmse_hist)
+    // captured iterations of hn_step, keyed by every pointer / size / mode baked into the kernel arguments
+    struct StepGraph {
+        const void *wf = nullptr, *res = nullptr, *states = nullptr, *k_sq = nullptr, *src = nullptr, *rmse = nullptr;
+        int src_batch = 0, batch = 0, precision = 0, lanes = 0, side = 0;
+        hipGraphExec_t exec[2] = {nullptr, nullptr};  // [0]: states user -> tmp, [1]: tmp -> user
+        long last_use = 0;
+    };
+    std::vector<StepGraph> graphs;
+    long graph_clock = 0;
+    hipStream_t cap_stream = nullptr;              // iterations are captured here (the caller's stream may be the legacy default stream)
+    long graph_replays = 0, eager_iterations = 0, graphs_captured = 0;  // diagnostics (hn_get_counter)
     // optional per-kernel timing with HIP events on the caller's stream (hn_profile_*)
     uint64_t prof_mask = 0;
     int prof_stride = 1;          // bracket every prof_stride-th launch of a selected kernel
@@ -110,6 +127,7 @@ struct hn_ctx {
 namespace hn {
 
 int fail(hn_ctx* ctx, int code, const char* fmt, ...);
+void clear_step_graphs(hn_ctx* ctx);  // captured iterations bake in pointers, sizes and the precision mode
 void set_global_error(const char* msg);
 
 #define HN_HIP(ctx, call)                                                                   \
@@ -135,6 +153,19 @@ enum KernelId : int {
 };
 
 // RAII event pair around one launch when that kernel id is selected by hn_profile_enable.
+// Selects the context's device for the duration of an entry point and restores the caller's (the library must not
+// change the current device under PyTorch).
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const hn_ctx* ctx) {
+        int cur = -1;
+        if (ctx && hipGetDevice(&cur) == hipSuccess && cur != ctx->device && hipSetDevice(ctx->device) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 struct ProfScope {
     hn_ctx* c;
     hipStream_t s;
@@ -146,9 +177,11 @@ struct ProfScope {
 // ---- spectral (hn_spectral.hip) ----
 int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k);
 void spec_free(SpecTables& t);
-// out = L(wf) [+ ksq*wf - src]; `accum_sumsq` (nullable) receives sum over (c,h,w) of out^2 per sample.
+// out = L(wf) [+ ksq*wf - src]; `accum_sumsq` (nullable) receives sum over (c,h,w) of out^2 per sample, in row
+// `*it_counter - 1` of a [.., sumsq_stride] table when `it_counter` is given (the column pass increments it: one
+// captured iteration can then be replayed for every row of the RMSE history), else in row 0.
 int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, int src_batch,
-               int batch, float* accum_sumsq, hipStream_t s);
+               int batch, float* accum_sumsq, hipStream_t s, int* it_counter = nullptr, int sumsq_stride = 0);
 
 // ---- matrix-core kernels (hn_mfma.hip) ----
 void pack_frag_3x3(const float* w_oihw, int cin, float* dst);  // -> [cin][3][64]
@@ -165,8 +198,8 @@ void pack_frag_up_x16(const float* w_iohw, float* dst_split, float* dst_half);
 // kind: 0 inc (2+2+2 ch), 1 conv_signal (8+2), 2 bottleneck (8), 3 decoder (8+8; final_epi adds outc + wf update)
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
-void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
-void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
+void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
+void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
 
 // ---- unet (hn_unet.hip) ----
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the

@@ -30,43 +30,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Diagnostic build only (-DHN_STAMP): per-phase s_memtime stamps of the persistent DoubleConv,
-// written to a buffer nothing else reads.  Never enabled in the shipped library.
-#ifdef HN_STAMP
-__device__ unsigned long long g_stamps[256 * 4 * 64];
-__device__ int g_stamp_sel = 881;  // CA*100 + CB*10 + EPI of the instance that records
-__device__ int g_stamp_w = 256;    // ... and the image width it must be running on
-#define STAMP(slot)                                                                                      \
-    do {                                                                                                 \
-        if (lane == 0 && stamp_i + (slot) < 64 && blockIdx.x < 256 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == g_stamp_w) {                                                        \
-            unsigned long long t_;                                                                       \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
-            g_stamps[(blockIdx.x * 4 + wave) * 64 + stamp_i + (slot)] = t_;                              \
-        }                                                                                                \
-    } while (0)
-__device__ unsigned long long g_stamps2[2048 * 4 * 16];
-__device__ __forceinline__ unsigned long long stamp_now() {
-    unsigned long long t_;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  // 100 MHz wall clock (s_memtime is load-dependent)
-    return t_;
-}
-#define STAMP2_DECL unsigned long long st_[16] = {0}; unsigned long long st_t0_ = stamp_now(), st_prev_ = st_t0_;
-#define STAMP2(slot) do { unsigned long long now_ = stamp_now(); st_[slot] += now_ - st_prev_; st_prev_ = now_; } while (0)
-#define STAMP2_FLUSH()                                                                                    \
-    do {                                                                                                  \
-        const int blk_ = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;                  \
-        if (lane == 0 && blk_ < 2048 && g_stamp_sel == CA * 100 + CB * 10 + EPI && W == g_stamp_w) {            \
-            st_[15] = st_t0_;                                                                             \
-            for (int i_ = 0; i_ < 16; ++i_) g_stamps2[(blk_ * 4 + wave) * 16 + i_] = st_[i_];              \
-        }                                                                                                 \
-    } while (0)
-#else
-#define STAMP(slot) do { } while (0)
-#define STAMP2_DECL
-#define STAMP2(slot) do { } while (0)
-#define STAMP2_FLUSH() do { } while (0)
-#endif
-
 constexpr int cdiv_(int a, int b) { return (a + b - 1) / b; }
 constexpr int cmax_(int a, int b) { return a > b ? a : b; }
 
@@ -471,9 +434,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
 #pragma unroll
     for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){bias0, bias0, bias1, bias1};
 
-    STAMP2_DECL
     fetch(0);
-    STAMP2(0);  // prologue
 #pragma unroll
     for (int g = 0; g < C::NG; ++g) {
         const int buf = g & 1;
@@ -481,11 +442,8 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
         float afrag[6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) afrag[j] = afrag_next[j];
-        STAMP2(1);  // commit (includes waiting for the staged loads)
         __syncthreads();
-        STAMP2(2);  // chunk barrier
         if (g + 1 < C::NG) fetch(g + 1);
-        STAMP2(3);  // fetch issue
         const float* t = lds + buf * 2 * C::PLANE_P;
         float br[2][C::NR1 + 2], bvv[2][3];
 #pragma unroll
@@ -516,7 +474,6 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
             if (c == 0) interleave_mfma_dsread<C::NR1 + 2>();
             __builtin_amdgcn_sched_barrier(0);
         }
-        STAMP2(4);  // conv1 MFMAs of the chunk
     }
     float a2[kFeat * 3];
 #pragma unroll
@@ -558,9 +515,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
             put(accv, vrow0 + n, 32, (f32x2){m0, m1}, (f32x2){m0 * slope, m1 * slope});
         }
     }
-    STAMP2(5);  // barrier + mid write
     __syncthreads();
-    STAMP2(6);  // mid barrier
 
     // ---- conv2: output rows 8*half .. +7, pairs 16*strip + n ----
     const int rb2 = C::NR2 * half;
@@ -617,7 +572,6 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    STAMP2(7);  // conv2
     // acc2[r] = {channel 2q: pixels ox, ox+1; channel 2q+1: pixels ox, ox+1}
     if (EPI == 0) {
         if (xin) {
@@ -671,8 +625,6 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
             }
         }
     }
-    STAMP2(8);  // epilogue
-    STAMP2_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1173,19 +1125,13 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
     }
     const float ob_im = EPI == 1 ? epi.ob[1] : 0.f;
     int tile = blockIdx.x;
-    int stamp_i = 0;
-    (void)stamp_i;
     if (tile < ntiles) issue(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
         const int x0 = tx * C::TW, y0 = ty * C::TH;
-        STAMP(0);
         commit();
-        STAMP(1);
         __syncthreads();  // (1) input tile visible; every wave is past conv2 of the previous tile
-        STAMP(2);
         if (tile + (int)gridDim.x < ntiles) issue(tile + gridDim.x);
-        STAMP(3);
 
         // ---- conv1: cin*3 steps, LDS reads of step k+1 behind the MFMAs of step k ----
         f32x4 acc1[C::GW1];
@@ -1219,7 +1165,6 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
                 for (int j = 0; j < 6; ++j) af[j] = afn[j];
             }
         }
-        STAMP(4);
         // ---- mid tensor: bias, PReLU, zero outside the image ----
 #pragma unroll
         for (int gi = 0; gi < C::GW1; ++gi) {
@@ -1237,9 +1182,7 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
                 *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
             }
         }
-        STAMP(5);
         __syncthreads();  // (2) mid complete; the input region may be overwritten by the next commit
-        STAMP(6);
 
         // ---- conv2 ----
         f32x4 acc2[C::GW2];
@@ -1285,7 +1228,6 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
                 for (int j = 0; j < 6; ++j) af[j] = afn[j];
             }
         }
-        STAMP(7);
 #pragma unroll
         for (int gi = 0; gi < C::GW2; ++gi) {
             const int s = 16 * (wave + 4 * gi) + n;
@@ -1322,25 +1264,9 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
                 }
             }
         }
-        STAMP(8);
-#ifdef HN_STAMP
-        stamp_i += 9;
-#endif
     }
 }
 
-#ifdef HN_STAMP
-}  // namespace
-extern "C" int hn_debug_set_stamp_sel(int sel) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_sel), &sel, sizeof(int)); }
-extern "C" int hn_debug_set_stamp_w(int w) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_w), &w, sizeof(int)); }
-extern "C" int hn_debug_read_stamps2(unsigned long long* host, int count) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps2), sizeof(unsigned long long) * count);
-}
-extern "C" int hn_debug_read_stamps(unsigned long long* host, int count) {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * count);
-}
-namespace {
-#endif
 
 // ------------------------------------------------------------------------------------------
 // 8x8 stride-2 down convolution (architectures.py:209-211)
@@ -1841,48 +1767,33 @@ __global__ __launch_bounds__(256, 2) void k_up_x16(Src in, Dst out, const void* 
     }
 }
 
-// 0 = fp32 matrix core (default), 1 = bf16x3, 2 = fp16, 3 = bf16x2 (HN_UNET_IMPL, read once)
-inline int x16_mode() {
-    static const int mode = [] {
-        const char* e = getenv("HN_UNET_IMPL");
-        return e == nullptr ? 0 : std::strcmp(e, "bf16x3") == 0 ? 1 : std::strcmp(e, "fp16") == 0 ? 2 : std::strcmp(e, "bf16x2") == 0 ? 3 : 0;
-    }();
-    return mode;
-}
-
 template <int CA, int CB, int CC, int EPI>
-void launch_dc_mfma(Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
-    static const bool generic = getenv("HN_DC_GENERIC") != nullptr;  // A/B: force the generic chunked kernel
+void launch_dc_mfma(int x16, Src a, Src b, Src c, Dst out, const McW& w, const McEpi& e, int H, int W, int batch, hipStream_t s) {
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
-    const int x16 = x16_mode();
     if (x16 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC, 3>::SCALED)) {
-        static const int th8 = getenv("HN_X16_TH8") ? atoi(getenv("HN_X16_TH8")) : -1;   // experiment: 8-row tiles (more, smaller blocks per CU)
-        if (th8 > 0 || (th8 < 0 && x16 == 1)) {   // default: the 3-part split (65 KB per 16-row tile -> 39 KB, 3 blocks per CU: +4 % it/s)
+        if (x16 == 1) {   // the 3-part split in 8-row tiles (65 KB per 16-row tile -> 39 KB, 3 blocks per CU: +4 % it/s)
             const dim3 g8(cdiv_(W, 64), cdiv_(H, 8), batch);
-            if (x16 == 1) hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI, 8>), g8, dim3(256), 0, s, a, b, c, out, w, e, H, W);
-            else if (x16 == 2) hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI, 8>), g8, dim3(256), 0, s, a, b, c, out, w, e, H, W);
-            else hipLaunchKernelGGL((k_dc_x16<SplitBf16x2, CA, CB, CC, EPI, 8>), g8, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+            hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI, 8>), g8, dim3(256), 0, s, a, b, c, out, w, e, H, W);
             return;
         }
         const dim3 g(cdiv_(W, 64), cdiv_(H, 16), batch);
-        if (x16 == 1) hipLaunchKernelGGL((k_dc_x16<SplitBf16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
-        else if (x16 == 2) hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        if (x16 == 2) hipLaunchKernelGGL((k_dc_x16<HalfF16, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
         else hipLaunchKernelGGL((k_dc_x16<SplitBf16x2, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
         return;
     }
-    if (W >= 128 && even && !generic && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
+    if (W >= 128 && even && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
         hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
-    } else if (even && !generic && W > 16) {
+    } else if (even && W > 16) {
         // small levels are latency-bound: whole input tile staged at once (one barrier), small 8 x 32
         // tiles so that even a 32^2 image spreads over many CUs
         const int tx = cdiv_(W, 32), ty = cdiv_(H, 8), nt = tx * ty * batch;
         hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 32>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
-    } else if (even && !generic) {
+    } else if (even) {
         const int tx = cdiv_(W, 16), ty = cdiv_(H, 8), nt = tx * ty * batch;
         hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 16>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
-    } else if (W > 32) {
+    } else if (W > 32) {   // odd widths (e.g. the 3 x 3 bottleneck of a 48^2 domain): the any-shape kernel
         hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 64, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
     } else if (W > 16) {
         hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 32, EPI>), dim3(1, cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
@@ -2030,24 +1941,25 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
     const float* s2 = frag2 + (size_t)kFeat * 3 * 64;
     const McW mw{frag1, w.b1, w.slope, frag2, w.b2, s1, s2, s1 + frag_3x3_split_floats(cin), s2 + frag_3x3_split_floats(kFeat)};
     const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf};
+    const int x16 = (ctx->precision >= HN_PREC_BF16X3 && ctx->precision <= HN_PREC_BF16X2) ? ctx->precision : 0;
     switch (kind) {
-        case 0: launch_dc_mfma<2, 2, 2, 0>(a, b, c, out, mw, e, H, W, batch, s); break;          // inc
-        case 1: launch_dc_mfma<kFeat, kState, 0, 0>(a, b, c, out, mw, e, H, W, batch, s); break;  // conv_signal
-        case 2: launch_dc_mfma<kFeat, 0, 0, 0>(a, b, c, out, mw, e, H, W, batch, s); break;       // bottleneck
+        case 0: launch_dc_mfma<2, 2, 2, 0>(x16, a, b, c, out, mw, e, H, W, batch, s); break;          // inc
+        case 1: launch_dc_mfma<kFeat, kState, 0, 0>(x16, a, b, c, out, mw, e, H, W, batch, s); break;  // conv_signal
+        case 2: launch_dc_mfma<kFeat, 0, 0, 0>(x16, a, b, c, out, mw, e, H, W, batch, s); break;       // bottleneck
         case 3:
-            if (final_epi) launch_dc_mfma<kFeat, kFeat, 0, 1>(a, b, c, out, mw, e, H, W, batch, s);
-            else launch_dc_mfma<kFeat, kFeat, 0, 0>(a, b, c, out, mw, e, H, W, batch, s);
+            if (final_epi) launch_dc_mfma<kFeat, kFeat, 0, 1>(x16, a, b, c, out, mw, e, H, W, batch, s);
+            else launch_dc_mfma<kFeat, kFeat, 0, 0>(x16, a, b, c, out, mw, e, H, W, batch, s);
             break;
         default: return fail(ctx, HN_ERR_ARG, "internal: bad DoubleConv kind %d", kind);
     }
     return HN_OK;
 }
 
-void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
+void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     const int Wout = Win / 2, Hout = Hin / 2;
     // mixed-precision modes: levels 0 and 1 on the 16-bit matrix core; the 3-part split stays on the fp32 kernel
     // here (its 71 KB window and 288 MFMAs per wave measured 55 us against 48 us)
-    if (const int mode = x16_mode(); mode >= 2 && Wout >= 64) {
+    if (const int mode = ctx->precision; (mode == HN_PREC_FP16 || mode == HN_PREC_BF16X2) && Wout >= 64) {
         const dim3 g(cdiv_(Wout, 16), cdiv_(Hout, 16), batch);
         const float* split = frag + (size_t)kFeat * kFeat * 64;   // hn_load_weights stores the 16-bit twins behind the fp32 block
         const float* half = split + k8_split_floats();
@@ -2068,9 +1980,9 @@ void launch_down(Src in, Dst out, const float* frag, const float* bias, int Hin,
     }
 }
 
-void launch_up(Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
+void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
     // window rows -1 .. Hin-1
-    if (const int mode = x16_mode(); mode != 0 && Win >= 64) {
+    if (const int mode = ctx->precision; mode >= HN_PREC_BF16X3 && mode <= HN_PREC_BF16X2 && Win >= 64) {
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
         const float* split = frag + (size_t)kFeat * kFeat * 64;
         const float* half = split + k8_split_floats();

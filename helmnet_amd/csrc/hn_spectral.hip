@@ -214,10 +214,13 @@ struct ColCfg {
 
 template <int N, int C>
 __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict__ wf, float* __restrict__ out,
-                                                          SpecPtrs t) {
+                                                          SpecPtrs t, int* __restrict__ it_counter) {
     constexpr int T = N / 4, CPW = ColCfg<N, C>::CPW;
     __shared__ float2 buf[2 * N * C];
     const int c = threadIdx.x, j = threadIdx.y;
+    // one more iteration of the running hn_step: the row pass (next kernel on the stream) files its per-sample
+    // sum of squares under row *it_counter - 1 of the RMSE history
+    if (it_counter != nullptr && (blockIdx.x | blockIdx.y | c | j) == 0) atomicAdd(it_counter, 1);
     const int col0 = blockIdx.x * (C * CPW) + c;
     const long plane = (long)N * N;
     const float* pre = wf + (long)blockIdx.y * 2 * plane + col0;
@@ -288,7 +291,8 @@ struct RowOperands {  // everything one row still needs from HBM, requested in o
 template <int N>
 __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
     const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
-    const float* __restrict__ src, long src_sb, SpecPtrs t, int flags, float* __restrict__ sumsq) {
+    const float* __restrict__ src, long src_sb, SpecPtrs t, int flags, float* __restrict__ sumsq,
+    const int* __restrict__ it_counter, int sumsq_stride) {
     constexpr int T = RowCfg<N>::T, R = RowCfg<N>::R, RPW = RowCfg<N>::RPW;
     __shared__ float2 buf[2 * N * R];
     __shared__ float red[(T * R + 63) / 64];
@@ -332,7 +336,8 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
         if (tid == 0) {
             float s = 0.f;
             for (int w = 0; w < (T * R + 63) / 64; ++w) s += red[w];
-            atomicAdd(&sumsq[b], s);
+            const long row = it_counter != nullptr ? (long)(*it_counter - 1) * sumsq_stride : 0;
+            atomicAdd(&sumsq[row + b], s);
         }
     }
 }
@@ -341,7 +346,8 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
 __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf, float* __restrict__ out,
                                                     const float* __restrict__ ksq, const float* __restrict__ src,
                                                     long src_sb, const float2* __restrict__ mt, int n, int flags,
-                                                    float* __restrict__ sumsq) {
+                                                    float* __restrict__ sumsq, const int* __restrict__ it_counter,
+                                                    int sumsq_stride) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
     const long plane = (long)n * n;
@@ -370,23 +376,26 @@ __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf
         float ss = (x < n) ? re * re + im * im : 0.f;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[b], ss);
+        const long row = it_counter != nullptr ? (long)(*it_counter - 1) * sumsq_stride : 0;
+        if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[row + b], ss);
     }
 }
 
+__global__ void k_bump(int* counter) { atomicAdd(counter, 1); }
+
 template <int N>
 void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch,
-                 const SpecPtrs& p, bool resid, float* sumsq, hipStream_t s) {
+                 const SpecPtrs& p, bool resid, float* sumsq, hipStream_t s, int* it_counter, int sumsq_stride) {
     constexpr int T = N / 4;
     constexpr int C = (1024 / T) < 16 ? (1024 / T) : 16;
     {
         ProfScope ps(ctx, KID_SPEC_COLS, s);
-        hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / (C * ColCfg<N, C>::CPW), batch), dim3(C, T), 0, s, wf, out, p);
+        hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / (C * ColCfg<N, C>::CPW), batch), dim3(C, T), 0, s, wf, out, p, it_counter);
     }
     constexpr int R = RowCfg<N>::R;
     ProfScope ps(ctx, KID_SPEC_ROWS, s);
     hipLaunchKernelGGL((k_spec_rows<N>), dim3(N / (R * RowCfg<N>::RPW), batch), dim3(T, R), 0, s, wf, out, ksq, src, src_sb, p,
-                       1 | (resid ? 2 : 0), sumsq);
+                       1 | (resid ? 2 : 0), sumsq, it_counter, sumsq_stride);
 }
 
 template <typename T>
@@ -491,7 +500,7 @@ int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k) {
 }
 
 int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, int src_batch,
-               int batch, float* accum_sumsq, hipStream_t s) {
+               int batch, float* accum_sumsq, hipStream_t s, int* it_counter, int sumsq_stride) {
     const SpecTables& t = ctx->tab;
     if (t.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
     if (batch <= 0) return HN_OK;
@@ -501,20 +510,21 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
     if (t.pow2) {
         const SpecPtrs p{t.tw, t.k1, t.k2, t.a, t.b};
         switch (t.n) {
-            case 16: launch_pow2<16>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 32: launch_pow2<32>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 64: launch_pow2<64>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 128: launch_pow2<128>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 256: launch_pow2<256>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 512: launch_pow2<512>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 1024: launch_pow2<1024>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
-            case 2048: launch_pow2<2048>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s); break;
+            case 16: launch_pow2<16>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 32: launch_pow2<32>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 64: launch_pow2<64>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 128: launch_pow2<128>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 256: launch_pow2<256>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 512: launch_pow2<512>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 1024: launch_pow2<1024>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 2048: launch_pow2<2048>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             default: return fail(ctx, HN_ERR_ARG, "unsupported power-of-two size %d", t.n);
         }
     } else {
+        if (it_counter != nullptr) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, it_counter);
         ProfScope ps(ctx, KID_SPEC_ROWS, s);
         hipLaunchKernelGGL(k_spec_dense, dim3((t.n + 255) / 256, t.n, batch), dim3(256), 0, s, wf, out, ksq, src,
-                           src_sb, t.dense_t, t.n, resid ? 2 : 0, accum_sumsq);
+                           src_sb, t.dense_t, t.n, resid ? 2 : 0, accum_sumsq, it_counter, sumsq_stride);
     }
     HN_HIP(ctx, hipGetLastError());
     return HN_OK;

@@ -427,7 +427,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     const long L = ctx->state_len;
     const Src none{nullptr, 0, 0, 1.f};
     const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
-    const bool mfma = !ctx->use_valu;
+    const bool mfma = ctx->precision != HN_PREC_FP32_VALU;
     hipStream_t side = side_lane ? side_lane->stream : nullptr;
     auto plane = [&](int d) { const long m = n >> d; return m * m; };
     // ws_off: first sample slot of the workspace this call may use (sub-batches on parallel streams)
@@ -463,7 +463,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         }
         // x = down(out)                                                  (architectures.py:252)
         ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
-        if (mfma) launch_down(featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
+        if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
         else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
                                 dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                                 ctx->down[d], m, m);
@@ -496,7 +496,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // x = up[d](x)                                                   (architectures.py:456)
         {
             ProfScope ps(ctx, KID_UP0 + 2 * d, s);
-            if (mfma) launch_up(featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->f_up[d], ctx->up[d].b, m / 2, m / 2, batch, s);
+            if (mfma) launch_up(ctx, featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->f_up[d], ctx->up[d].b, m / 2, m / 2, batch, s);
             else hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
                                     featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
         }

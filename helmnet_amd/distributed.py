@@ -83,6 +83,9 @@ def solve_sharded(solve: Callable[[torch.Tensor, int], dict], sos_maps: torch.Te
     all ranks drops below it, checked every ``check_every`` iterations with one all-reduce.
     """
     total = sos_maps.shape[0]
+    if _ready() and total < dist.get_world_size():
+        # every rank evaluates the same condition, so every rank raises: no rank is left waiting in a collective
+        raise ValueError(f"{total} maps cannot be sharded over {dist.get_world_size()} ranks (an empty shard has nothing to solve)")
     local = shard_batch(sos_maps) if _ready() else sos_maps
     done, out, worst = 0, None, None
     while done < num_iterations:

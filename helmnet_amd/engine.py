@@ -105,6 +105,24 @@ class Engine:
         self.n = int(n)
         self.domain_key = (int(n), int(pml), float(sigma_max), float(k))
 
+    def set_unet_precision(self, mode: str):
+        """Arithmetic of the UNet convolutions for this context: 'fp32' (default), 'bf16x3', 'fp16', 'bf16x2', 'valu'."""
+        if mode not in _lib.HN_PRECISION:
+            raise ValueError(f"unknown UNet precision {mode!r} (choose from {sorted(_lib.HN_PRECISION)})")
+        _lib.check(self.lib.hn_set_unet_precision(self.ctx, _lib.HN_PRECISION[mode]), self.ctx, "hn_set_unet_precision")
+
+    @property
+    def unet_precision(self) -> str:
+        code = self.lib.hn_get_unet_precision(self.ctx)
+        return {v: k for k, v in _lib.HN_PRECISION.items()}[code]
+
+    def set_option(self, name: str, value: int):
+        """hn_step tuning knobs: 'lanes' (1..8), 'side_stream' (0/1), 'graph' (0/1)."""
+        _lib.check(self.lib.hn_set_option(self.ctx, _lib.HN_OPTION[name], int(value)), self.ctx, "hn_set_option")
+
+    def counter(self, name: str) -> int:
+        return int(self.lib.hn_get_counter(self.ctx, _lib.HN_COUNTER[name]))
+
     @property
     def state_len(self) -> int:
         return int(self.lib.hn_state_len(self.ctx))

@@ -94,3 +94,29 @@ def skull_sos(n: int = 512, batch: int = 1, seed: int = 0, boost: float = 0.87, 
         soft = brain * (0.5 + 0.5 * np.sin(6.28 * (2.0 * u / n + 0.3)) * np.sin(6.28 * (1.5 * v / n + 0.1)))
         out[b, 0] = 1.0 + shell * bone + inner * soft
     return np.clip(out, 1.0, 2.0).astype(np.float32)
+
+
+def arc_source_mask(n: int, arc_pos, radius: float, diameter: float, focus_pos) -> np.ndarray:
+    """[n, n] 0/1 mask of a focused bowl transducer in 2-D: the pixels on the circle of ``radius`` through
+    ``arc_pos`` (its mid point, [row, col]) curved towards ``focus_pos``, within the aperture ``diameter``
+    (chord length).  Geometry of matlab/skull_example.m:80 (k-Wave ``makeArc``, not part of the reference
+    checkout); the rasterisation rule here is: |distance to the centre of curvature - radius| < 0.5."""
+    ap, fp = np.asarray(arc_pos, np.float64), np.asarray(focus_pos, np.float64)
+    axis = (fp - ap) / np.linalg.norm(fp - ap)
+    centre = ap + radius * axis
+    half = np.arcsin(min(1.0, diameter / (2.0 * radius)))
+    yy, xx = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64), indexing="ij")
+    dy, dx = yy - centre[0], xx - centre[1]
+    r = np.hypot(dy, dx)
+    cosang = (dy * (-axis[0]) + dx * (-axis[1])) / np.maximum(r, 1e-9)
+    return ((np.abs(r - radius) < 0.5) & (cosang >= np.cos(half))).astype(np.float32)
+
+
+def arc_source_map(n: int = 512, arc_pos=(430, 380), radius: float = 122.0, diameter: float = 122.0,
+                   focus_pos=(320, 256), amplitude: float = 10.0) -> np.ndarray:
+    """[1, 2, n, n] source map of the transcranial example (BASELINE.json configs[4]): amplitude x arc mask in
+    BOTH channels -- support_functions.py:321-326 hands ``10 * src`` of shape [1, n, n] to ``set_domain_size``,
+    which broadcasts over the real and the imaginary channel in ``get_residual`` (hybridnet.py:556)."""
+    m = amplitude * arc_source_mask(n, [p * n / 512.0 for p in arc_pos], radius * n / 512.0, diameter * n / 512.0,
+                                    [p * n / 512.0 for p in focus_pos])
+    return np.stack([m, m])[None].astype(np.float32)

@@ -65,6 +65,7 @@ class IterativeSolver(nn.Module):
         hp.pop("__class__", None)
         self.hparams = AttributeDict(hp)  # save_hyperparameters() equivalent (hybridnet.py:54)
         self._engine: Optional[Engine] = None
+        self._unet_precision = None   # None: the library default (fp32, or HN_UNET_IMPL at context creation)
         self.register_buffer("sigmas", None)
         self.set_laplacian()
         self.setup_source()
@@ -88,7 +89,7 @@ class IterativeSolver(nn.Module):
 
     @classmethod
     def from_exported_weights(cls, npz_path: Optional[str] = None, hparams_json: Optional[str] = None, **kwargs):
-        """Build from the `f.*` tensors exported out of the shipped checkpoint (tests/golden)."""
+        """Build from the `f.*` tensors exported out of the shipped checkpoint (package data, helmnet_amd/data)."""
         from .checkpoint import default_exported_weights, read_exported_weights
         d_npz, d_json = default_exported_weights()
         hp, sd = read_exported_weights(npz_path or d_npz, hparams_json or d_json)
@@ -135,10 +136,23 @@ class IterativeSolver(nn.Module):
         key = (int(self.hparams.domain_size), int(self.hparams.PMLsize), float(self.hparams.sigma_max), float(self.hparams.k))
         if self._engine.domain_key != key:
             self._engine.set_domain(*key)
+        if self._unet_precision is not None and self._engine.unet_precision != self._unet_precision:
+            self._engine.set_unet_precision(self._unet_precision)
         self.f.bind(self._engine)
         self.Lap.bind(self._engine)
         self.f.sync_weights(self._engine)
         return self._engine
+
+    def set_unet_precision(self, mode: str):
+        """Extension (BASELINE.json configs[4]): arithmetic of the UNet convolutions -- 'fp32' (the reference's,
+        default), 'fp16' (mixed fp16 UNet / fp32 spectral residual), 'bf16x3' / 'bf16x2' (split-bf16 emulations),
+        'valu'.  Per solver (hn_set_unet_precision on its context), not per process."""
+        from . import _lib
+        if mode not in _lib.HN_PRECISION:
+            raise ValueError(f"unknown UNet precision {mode!r} (choose from {sorted(_lib.HN_PRECISION)})")
+        self._unet_precision = mode
+        if self._engine is not None:
+            self._engine.set_unet_precision(mode)
 
     # ------------------------------------------------------------------ setup ------------
     def set_domain_size(self, domain_size, source_location=None, source_map=None):
@@ -349,12 +363,17 @@ class IterativeSolver(nn.Module):
                 self.set_source_maps(next(maps))
                 res = self.get_residual(wf, k_sq)
             part = self._run(wf, res, st, k_sq, bnd - a, return_wavefields, return_states, residuals)
-            for key in ("residuals", "states"):
-                merged[key] += part[key]
+            if residuals == "all":
+                merged["residuals"] += part["residuals"]
+            merged["states"] += part["states"]
             if return_wavefields:
                 merged["wavefields"] += part["wavefields"]
             norms.append(part["residual_norms"])
         if not return_wavefields:
             merged["wavefields"].append(wf)
+        if residuals == "last":      # wf / res / st are updated in place by every segment: only the final ones are kept
+            merged["residuals"] = [res]
+        elif residuals == "norms":
+            merged["last_residual"] = res
         merged["residual_norms"] = torch.cat(norms, 0) if norms else None
         return merged

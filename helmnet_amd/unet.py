@@ -108,6 +108,7 @@ class HybridNet(nn.Module):
         self.outc = OutConv(features, 2)
         self._engine: Optional[Engine] = None
         self._owns_engine = True
+        self._unet_precision = None
 
     # ---- state bookkeeping (architectures.py:390-437) -----------------------------------
     def init_by_size(self):
@@ -144,6 +145,12 @@ class HybridNet(nn.Module):
     def bind(self, engine: Engine):
         self._engine, self._owns_engine = engine, False
 
+    def set_unet_precision(self, mode: str):
+        """Standalone use (no IterativeSolver around it): arithmetic of the convolutions, see Engine.set_unet_precision."""
+        self._unet_precision = mode
+        if self._engine is not None and self._owns_engine:
+            self._engine.set_unet_precision(mode)
+
     def weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
@@ -164,6 +171,8 @@ class HybridNet(nn.Module):
         if self._owns_engine and self._engine.n != self.domain_size:
             # standalone use: the spectral tables are not needed, but the library wants a domain
             self._engine.set_domain(self.domain_size, 1, 0.0, 1.0)
+        if self._owns_engine and self._unet_precision is not None and self._engine.unet_precision != self._unet_precision:
+            self._engine.set_unet_precision(self._unet_precision)
         self.sync_weights(self._engine)
         return self._engine
 

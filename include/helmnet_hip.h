@@ -12,7 +12,9 @@
  * Conventions
  *   - every function returns 0 on success and a negative hn_status on failure; the message
  *     is available from hn_last_error(ctx) (or hn_last_error(NULL) for hn_create failures).
- *     No exception crosses the ABI, no global mutable state except that last-error string.
+ *     No exception crosses the ABI, no global mutable state except that last-error string; environment
+ *     variables are read once per context, in hn_create, as defaults for hn_set_unet_precision / hn_set_option.
+ *   - every entry point selects the context's device for its own duration and restores the caller's.
  *   - all tensor arguments are DEVICE pointers to contiguous fp32, NCHW, owned by the caller,
  *     who guarantees their lifetime until `stream` has been synchronised.
  *   - all work is enqueued asynchronously on the caller's `stream` (a hipStream_t passed as
@@ -46,7 +48,25 @@ enum hn_status {
  * mirroring the reference's NotImplementedError for unknown names. */
 enum hn_act { HN_ACT_PRELU = 0, HN_ACT_RELU = 1, HN_ACT_LEAKYRELU = 2 };
 
-#define HN_ABI_VERSION 1
+/* Arithmetic of the UNet convolutions (hn_set_unet_precision).  Everything in HBM (activations, hidden state,
+ * wavefield, residual), the 1x1 out-conv, the wavefield update and the spectral residual are fp32 in every mode.
+ *   HN_PREC_FP32     every product in fp32 on the f32-input matrix core (default; the reference's arithmetic)
+ *   HN_PREC_BF16X3   3-term bf16 split of both operands, 6 product terms, fp32 accumulate: fp32-accurate emulation
+ *   HN_PREC_FP16     fp16 operands, fp32 accumulate: the "mixed fp16 UNet / fp32 spectral residual" configuration
+ *   HN_PREC_BF16X2   2-term bf16 split, 3 product terms (~2^-16 relative, full fp32 exponent range)
+ *   HN_PREC_FP32_VALU  fp32 on the vector ALU (direct convolution; A/B reference for the matrix-core kernels) */
+enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_PREC_BF16X2 = 3, HN_PREC_FP32_VALU = 4 };
+
+/* Tuning knobs of hn_step (hn_set_option); none changes a result bit. */
+enum hn_option {
+    HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
+    HN_OPT_SIDE_STREAM = 1,  /* 0/1: conv_state kernels on a library side stream (default 1)                     */
+    HN_OPT_GRAPH = 2         /* 0/1: replay one captured iteration as a HIP graph instead of ~25 launches (default 1) */
+};
+/* Diagnostics counters (hn_get_counter). */
+enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };
+
+#define HN_ABI_VERSION 2
 int hn_abi_version(void);
 
 /* Create / destroy a context on HIP device `device_id`. */
@@ -67,6 +87,15 @@ size_t hn_weight_count(int features, int depth, int state_ch);
  * Supported: features == 8, state_ch == 2, 1 <= depth <= 6, state_depth == depth. */
 int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int features, int depth,
                     int state_ch, int act_kind);
+
+/* Select the arithmetic of the UNet convolutions for every later call on this context (per context, not per
+ * process: two contexts may differ).  The default is HN_PREC_FP32, or what the environment variable HN_UNET_IMPL
+ * (fp32 | bf16x3 | fp16 | bf16x2 | valu) named when hn_create ran.  The reference has a single fp32 path
+ * (architectures.py:439-465); the 16-bit modes are this library's extension (BASELINE.json configs[4]). */
+int hn_set_unet_precision(hn_ctx* ctx, int precision);
+int hn_get_unet_precision(const hn_ctx* ctx);
+int hn_set_option(hn_ctx* ctx, int option, int value);
+int64_t hn_get_counter(const hn_ctx* ctx, int counter);
 
 /* Build the spectral-operator constants for an n x n domain (float64 on the host, fp32 on the
  * device): k grids, PML coefficients ax/bx/ay/by, sigma maps, FFT twiddles.

@@ -28,3 +28,20 @@ def teacher_inputs(n: int, b: int, seed: int):
         "states": (0.5 * rng.standard_normal((b, 2, state_len(n)))).astype(f32),
         "sos": (1.0 + rng.random((b, 1, n, n))).astype(f32),
     }
+
+
+def long_inputs(tag: str):
+    """Inputs of the long free-run fixtures (tests/golden/make_long_golden.py -> long_run.npz).
+
+    cfg2: BASELINE configs[1] -- README map + 4 ring maps, 256^2, source [30, 128], 1000 iterations
+    cfg4: BASELINE configs[3] -- one 512^2 ring map, source [450, 256], 2000 iterations
+    cfg5: BASELINE configs[4] -- synthetic transcranial map (full 1.87x contrast) + arc source map, 512^2
+    """
+    from helmnet_amd.phantoms import arc_source_map, skull_sos
+    if tag == "cfg2":
+        return {"sos": np.concatenate([readme_sos(), ring_sos_batch(256, 4, seed=11)]), "loc": [30, 128]}
+    if tag == "cfg4":
+        return {"sos": ring_sos_batch(512, 1, seed=12), "loc": [450, 256]}
+    if tag == "cfg5":
+        return {"sos": skull_sos(512, 1, seed=0), "src_map": arc_source_map(512)}
+    raise KeyError(tag)
