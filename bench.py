@@ -225,11 +225,12 @@ def main():
     eng, sos_np, (wf, res, st, k_sq, src) = make_problem(solver, n, B, loc, rank, dev, rank == 0)   # each rank: its own shard of maps
     eng.set_option("lanes", args.lanes)
     eng.set_option("graph", 0 if args.no_graph else 1)
-    rmse = torch.zeros(max(K, W, 4), B, device=dev)
+    rmse = torch.zeros(max(K, W, 8), B, device=dev)
 
-    # warm-up, W untimed steps (at least 5): all but the last 4 with every kernel bracketed by events to find the
-    # dominant one, the last 4 as the timed region will run them
-    W1 = max(W - 4, 1)
+    # warm-up, W untimed steps (at least 7): all but the last 4 with every kernel bracketed by events to find the
+    # dominant one (>= 3 passes: the first launch of a kernel is not representative), the last 4 as the timed region
+    # will run them
+    W1 = max(W - 4, 3)
     eng.profile_enable(None)
     eng.step(wf, res, st, k_sq, src, W1, rmse_hist=rmse[:W1])
     torch.cuda.synchronize()

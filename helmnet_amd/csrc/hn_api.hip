@@ -526,6 +526,9 @@ hn_ctx::StepGraph* step_graph(hn_ctx* ctx, const StepArgs& a) {
     hn_ctx::StepGraph g;
     g.wf = a.wf; g.res = a.res; g.states = a.states; g.k_sq = a.k_sq; g.src = a.src; g.rmse = a.rmse_hist;
     g.src_batch = a.src_batch; g.batch = a.batch; g.precision = ctx->precision; g.side = ctx->opt_side_stream;
+    const uint64_t mask = ctx->prof_mask;
+    ctx->prof_mask = 0;   // event brackets are host-timed launches: they never go into a captured iteration
+    struct Restore { hn_ctx* c; uint64_t m; ~Restore() { c->prof_mask = m; } } restore{ctx, mask};
     for (int parity = 0; parity < 2; ++parity) {
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) { destroy_graph_entry(g); (void)hipGetLastError(); return nullptr; }

@@ -153,6 +153,42 @@ def test_loss_function(res: Tensor) -> Tensor:
     return res.pow(2).mean((1, 2, 3)).sqrt()
 
 
+def axis_operator_matrix(n: int, pml: int, sigma_max: float, k: float) -> np.ndarray:
+    """Explicit complex128 [n, n] matrix of the 1-D operator  a . IDFT diag(i k) DFT + b . IDFT diag(-k^2) DFT  the
+    spectral Laplacian applies along one axis, assembled from DFT matrices the way the reference's classical baseline
+    assembles its derivative operators (matlab/spectral_gmres_solver.m:50-82: ``dftx = fft(eye(Nx))``, ``Dx = idftx *
+    (ikx * dftx)``), with the fp32-rounded k / a / b tables of spectral.py (so it is the same operator, in float64)."""
+    k1 = k_grid_1d(n).astype(np.float32)
+    k2 = -(k1 * k1)                                       # fp32 square of the fp32 grid (spectral.py:283)
+    _, a, b = pml_profiles(n, pml, sigma_max, k)
+    a = a.real.astype(np.float32).astype(np.float64) + 1j * a.imag.astype(np.float32).astype(np.float64)
+    b = b.real.astype(np.float32).astype(np.float64) + 1j * b.imag.astype(np.float32).astype(np.float64)
+    dft = np.fft.fft(np.eye(n))
+    idft = np.fft.ifft(np.eye(n))
+    d1 = idft @ (np.diag(1j * k1.astype(np.float64)) @ dft)
+    d2 = idft @ (np.diag(k2.astype(np.float64)) @ dft)
+    return np.diag(a) @ d1 + np.diag(b) @ d2
+
+
+def assemble_helmholtz_matrix(k_sq: np.ndarray, pml: int, sigma_max: float, k: float) -> np.ndarray:
+    """Full system matrix M = A + B + D of matlab/spectral_gmres_solver.m:77-90 for ONE [n, n] map of k_sq, acting on
+    the row-major flattened complex wavefield: A = I (x) Mx (along W), B = My (x) I (along H), D = diag(k_sq)."""
+    n = k_sq.shape[-1]
+    m1 = axis_operator_matrix(n, pml, sigma_max, k)
+    eye = np.eye(n)
+    return np.kron(eye, m1) + np.kron(m1, eye) + np.diag(k_sq.reshape(-1).astype(np.float64))
+
+
+def direct_solve(sos: np.ndarray, source: np.ndarray, pml: int, sigma_max: float, k: float, omega: float = 1.0) -> np.ndarray:
+    """float64 direct solution of (L + k_sq) u = source for one [n, n] sound-speed map; source [2, n, n] (re, im)
+    -> [2, n, n].  The role MATLAB's gmres to 1e-10 plays in the reference (spectral_gmres_solver.m:92-107)."""
+    k_sq = (omega / sos.astype(np.float64)) ** 2
+    mat = assemble_helmholtz_matrix(k_sq, pml, sigma_max, k)
+    rhs = (source[0].astype(np.float64) + 1j * source[1].astype(np.float64)).reshape(-1)
+    u = np.linalg.solve(mat, rhs).reshape(k_sq.shape)
+    return np.stack([u.real, u.imag])
+
+
 # --------------------------------------------------------------------------
 # Source
 # --------------------------------------------------------------------------

@@ -45,3 +45,19 @@ def long_inputs(tag: str):
     if tag == "cfg5":
         return {"sos": skull_sos(512, 1, seed=0), "src_map": arc_source_map(512)}
     raise KeyError(tag)
+
+
+def metric_inputs(seed: int = 2024):
+    """Seeded inputs of the accuracy-metric fixtures (tests/golden/make_golden_r2.py): smooth complex fields [3, 2,
+    96, 96] (re, im), a reference that differs by a few percent, a 0/1 mask and a two-frame stream."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.meshgrid(np.arange(96, dtype=np.float32), np.arange(96, dtype=np.float32), indexing="ij")
+    r = np.sqrt((yy - 82) ** 2 + (xx - 48) ** 2) + 1.0
+    base = np.stack([np.cos(r) / np.sqrt(r), np.sin(r) / np.sqrt(r)]).astype(np.float32)     # outgoing wave from [82, 48]
+    sample = np.stack([base * (1 + 0.1 * b) + 0.02 * rng.standard_normal(base.shape).astype(np.float32) for b in range(3)])
+    reference = np.stack([base * (1.3 - 0.2 * b) + 0.02 * rng.standard_normal(base.shape).astype(np.float32) for b in range(3)])
+    reference[:, 1] *= -1.0                                                                  # stored conjugated, as k-Wave's
+    mask = np.zeros((96, 96), np.float32)
+    mask[20:70, 15:80] = 1.0
+    stream = np.stack([0.5 * sample, sample], 1).astype(np.float32)                          # [B, T, 2, H, W]
+    return {"sample": sample.astype(np.float32), "reference": reference.astype(np.float32), "mask": mask, "stream": stream}

@@ -1,0 +1,161 @@
+"""Long free-run parity tier: the full iteration counts and batch
+sizes of BASELINE.json configs[1] (256^2, B = 32, 1000 it), configs[3] (512^2, B = 16, 2000 it) and configs[4]
+(512^2 transcranial map, arc source map, fp16 UNet / fp32 residual, convergence to tolerance) against the REFERENCE's
+own float64 and float32 trajectories (tests/golden/long_run.npz, made by tests/golden/make_long_golden.py).
+
+Bars.  The iteration amplifies rounding differences (the reference's own fp32 run drifts from its float64 run by up to
+9e-4 after 1000 iterations, recorded per sample and checkpoint in the fixture), so an fp32 implementation is held to
+    L_inf(wavefield - float64 trajectory) <= max(1e-4, 2 x the reference-fp32 deviation at that checkpoint)
+on the stored probe grid, the residual RMSE trace to 2 % over the first 300 iterations (before the trajectories
+decorrelate) and the converged RMSE floor to +-10 %.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_inputs import long_inputs
+from helmnet_amd.phantoms import ring_sos_batch
+from oracle import helmnet_oracle as O
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def g_long():
+    with np.load(os.path.join(REPO, "tests", "golden", "long_run.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_oracle_follows_the_float64_trajectory_first_100_iterations(g_long, weights):
+    """The CPU restatement on one of the five config-2 maps (a ring phantom): 100 iterations, against the float64 reference probes."""
+    li = long_inputs("cfg2")
+    sos = torch.from_numpy(li["sos"][1:2])
+    out = O.solve(sos, weights, O.point_source_map(256, li["loc"], 10.0), O.SpectralTables(256, 8, 2, 1.0), 100)
+    st = int(g_long["cfg2_stride"])
+    err = np.abs(out["wavefield"].numpy()[:, :, ::st, ::st] - g_long["cfg2_wf_it100"][1:2]).reshape(1, -1).max(1)
+    bar = np.maximum(1e-4, 2 * g_long["cfg2_f32dev_probe_it100"][1:2])
+    assert (err <= bar).all(), (err, bar)
+    trace = torch.stack(out["trace"]).numpy()
+    assert np.abs(trace / g_long["cfg2_rmse_f64"][:100, 1:2] - 1).max() <= 2e-2
+
+
+def _solver():
+    from helmnet_amd import IterativeSolver
+    s = IterativeSolver.from_exported_weights()
+    s.freeze()
+    s.to(DEV)
+    return s
+
+
+def _run_with_checkpoints(s, sos, checkpoints):
+    """forward() to the first checkpoint, n_steps between the others (states carry over in s.f as in the reference)."""
+    traces, fields, done = [], {}, 0
+    k_sq = None
+    for cp in checkpoints:
+        if done == 0:
+            o = s.forward(sos, num_iterations=cp, residuals="norms")
+            k_sq = s.get_initials(sos)[0].contiguous()
+        else:
+            o = s.n_steps(wf, k_sq, res, cp - done, residuals="norms")
+        wf, res = o["wavefields"][0], o["last_residual"]
+        traces.append(o["residual_norms"].cpu().numpy())
+        fields[cp] = wf.cpu().numpy()
+        done = cp
+    return np.concatenate(traces), fields
+
+
+def _check(tag, g, trace, fields, n_gold, early=300):
+    st = int(g[f"{tag}_stride"])
+    r64 = g[f"{tag}_rmse_f64"]
+    assert trace.shape[0] == r64.shape[0]
+    assert np.isfinite(trace).all()
+    rel = np.abs(trace[:early, :n_gold] / r64[:early] - 1).max()
+    assert rel <= 2e-2, rel
+    floor_got, floor_ref = trace[-50:, :n_gold].mean(0), r64[-50:].mean(0)
+    assert (np.abs(floor_got / floor_ref - 1) <= 0.10).all(), (floor_got, floor_ref)
+    report = {}
+    for cp, wf in fields.items():
+        err = np.abs(wf[:n_gold, :, ::st, ::st] - g[f"{tag}_wf_it{cp}"]).reshape(n_gold, -1).max(1)
+        bar = np.maximum(1e-4, 2 * g[f"{tag}_f32dev_probe_it{cp}"])
+        report[cp] = (err, bar)
+        assert (err <= bar).all(), (tag, cp, err, bar)
+    return report
+
+
+@pytest.mark.gpu
+def test_config2_batch32_1000_iterations_vs_float64_reference(g_long):
+    """BASELINE configs[1] at full size: B = 32 (the 5 fixture maps + 27 more ring maps), 256^2, 1000 iterations."""
+    li = long_inputs("cfg2")
+    sos = np.concatenate([li["sos"], ring_sos_batch(256, 27, seed=21)])
+    s = _solver()
+    s.set_domain_size(256, source_location=li["loc"])
+    trace, fields = _run_with_checkpoints(s, torch.from_numpy(sos).to(DEV), (100, 300, 1000))
+    assert trace.shape == (1000, 32)
+    _check("cfg2", g_long, trace, fields, 5)
+    # every one of the 32 maps converges like the reference's five (RMSE floor of the trained network ~1.3e-5 .. 2.1e-5)
+    assert trace[-1].max() < 1e-4 and trace[-1].min() > 5e-6, (trace[-1].min(), trace[-1].max())
+    # the same maps solved alone give the same answer bit for bit (samples are independent)
+    alone = s.forward(torch.from_numpy(sos[:2]).to(DEV), num_iterations=100, residuals="last")
+    assert np.array_equal(alone["wavefields"][0].cpu().numpy(), fields[100][:2])
+
+
+@pytest.mark.gpu
+def test_config4_batch16_512_2000_iterations_vs_float64_reference(g_long):
+    """BASELINE configs[3] at full size: set_domain_size(512), B = 16, 2000 iterations."""
+    if "cfg4_rmse_f64" not in g_long:
+        pytest.skip("cfg4 fixture not generated")
+    li = long_inputs("cfg4")
+    sos = np.concatenate([li["sos"], ring_sos_batch(512, 15, seed=22)])
+    s = _solver()
+    s.set_domain_size(512, source_location=li["loc"])
+    trace, fields = _run_with_checkpoints(s, torch.from_numpy(sos).to(DEV), (500, 1000, 2000))
+    assert trace.shape == (2000, 16)
+    _check("cfg4", g_long, trace, fields, 1)
+    assert np.isfinite(trace).all() and trace[-1].max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_config5_fp16_unet_arc_source_convergence_to_tolerance(g_long):
+    """BASELINE configs[4]: 512^2 transcranial map at the full 1.87x contrast, arc source map (support_functions.py:
+    321-333), fp16 UNet / fp32 spectral residual, run until the residual RMSE is below a tolerance the reference's own
+    fp32 run reaches -- against that run (fixture cfg5: RMSE trace of 3000 iterations, wavefield probes)."""
+    if "cfg5_rmse_f32" not in g_long:
+        pytest.skip("cfg5 fixture not generated")
+    li = long_inputs("cfg5")
+    ref = g_long["cfg5_rmse_f32"][:, 0]
+    # the reference's trace falls steeply to ~3e-4 by iteration 300 and flattens out at 1.2e-4..1.3e-4 from iteration
+    # ~1000 on (a property of the trained network on this out-of-distribution map); 2e-4 is crossed on the slope
+    tol = 2e-4
+    ref_cross = int(np.argmax(ref < tol)) + 1
+    assert 300 < ref_cross < 700, ref_cross
+    sos = torch.from_numpy(li["sos"]).to(DEV)
+    out = {}
+    for mode in ("fp32", "fp16"):
+        s = _solver()
+        s.set_unet_precision(mode)
+        s.set_domain_size(512, source_map=torch.from_numpy(li["src_map"]).to(DEV))
+        o = s.solve_to_tolerance(sos, tol=tol, max_iterations=3000, check_every=50)
+        assert o["converged"], (mode, float(o["residual_norms"][-1].max()), tol)
+        assert s.engine().unet_precision == mode
+        out[mode] = o
+        # iterations to tolerance: the reference's count rounded up to the check interval, within 15 %
+        assert abs(o["iterations"] - ref_cross) <= max(50, 0.15 * ref_cross), (mode, o["iterations"], ref_cross)
+        tr = o["residual_norms"][:, 0].cpu().numpy()
+        k = min(len(tr), 300)
+        bar = 2e-2 if mode == "fp32" else 5e-2
+        assert np.abs(tr[:k] / ref[:k] - 1).max() <= bar, (mode, np.abs(tr[:k] / ref[:k] - 1).max())
+    # the fp16 network converges to the fp32 answer: wavefield within 2e-3 of max after the same number of iterations
+    n_it = min(out["fp32"]["iterations"], out["fp16"]["iterations"])
+    a = _solver(); a.set_domain_size(512, source_map=torch.from_numpy(li["src_map"]).to(DEV))
+    b = _solver(); b.set_unet_precision("fp16"); b.set_domain_size(512, source_map=torch.from_numpy(li["src_map"]).to(DEV))
+    wa = a.forward(sos, num_iterations=1000, residuals="last")["wavefields"][0].cpu().numpy()
+    wb = b.forward(sos, num_iterations=1000, residuals="last")["wavefields"][0].cpu().numpy()
+    st = int(g_long["cfg5_stride"])
+    gold = g_long["cfg5_wf_it1000"]
+    scale = float(g_long["cfg5_wf_absmax_it1000"][0])
+    e32 = np.abs(wa[:, :, ::st, ::st] - gold).max() / scale
+    e16 = np.abs(wb[:, :, ::st, ::st] - gold).max() / scale
+    assert e32 <= 1e-3 and e16 <= 5e-3, (e32, e16, n_it)
