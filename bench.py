@@ -244,8 +244,9 @@ def main():
     eng.step(wf, res, st, k_sq, src, 4, rmse_hist=rmse[:4])
     allreduce_residual_norms(rmse[0], op="max")
     eng.profile_enable([dom_id])
-    stride = max(1, -(-K // 8))                       # at most 8 bracketed launches in the timed region (a bracket costs ~6 us of stream gap
-    eng.profile_stride(stride)                        # and runs its iteration kernel by kernel instead of as a graph replay)
+    cap = 8 if K >= 64 else 4                         # at most 8 (short runs: 4) bracketed launches in the timed region: a bracket costs
+    stride = max(1, -(-K // cap))                     # ~6 us of stream gap and runs its iteration kernel by kernel instead of as a graph replay
+    eng.profile_stride(stride)
     replays0, eager0 = eng.counter("graph_replays"), eng.counter("eager_iterations")
 
     def barrier():

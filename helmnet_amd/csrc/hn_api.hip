@@ -160,6 +160,7 @@ int hn_create(hn_ctx** out, int device_id) {
     if (const char* v = getenv("HN_STREAMS")) { const int n = atoi(v); c->opt_lanes = n < 1 ? 1 : n > 8 ? 8 : n; }
     if (const char* v = getenv("HN_SIDE_STREAM")) c->opt_side_stream = atoi(v) != 0;
     if (const char* v = getenv("HN_GRAPH")) c->opt_graph = atoi(v) != 0;
+    if (const char* v = getenv("HN_DEEP")) c->opt_deep = atoi(v) != 0;
     *out = c;
     return HN_OK;
 }
@@ -184,6 +185,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             break;
         case HN_OPT_SIDE_STREAM: ctx->opt_side_stream = value != 0; break;
         case HN_OPT_GRAPH: ctx->opt_graph = value != 0; break;
+        case HN_OPT_DEEP: ctx->opt_deep = value != 0; break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }
     clear_step_graphs(ctx);
@@ -276,7 +278,11 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         auto dc = [&](int cin, int cm, int co) {  // returns offsets of (frag1, frag2) or (npos, npos)
             const float* w1 = blob + pos; pos += (size_t)cm * cin * 9 + cm + 1;
             const float* w2 = blob + pos; pos += (size_t)co * cm * 9 + co;
-            if (cm != kFeat || co != kFeat) { off.push_back((size_t)-1); off.push_back((size_t)-1); return; }
+            if (cm != kFeat || co != kFeat) {   // conv_state: fp32 fragments with the two channels in rows 0..3 of M
+                off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3_c2(w1, cin, fr.data() + off.back());
+                off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cm * 3 * 64); pack_frag_3x3_c2(w2, cm, fr.data() + off.back());
+                return;
+            }
             // each fp32 fragment block is followed by its split-bf16 and fp16 twins (launch_dc8 relies on this order)
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3(w1, cin, fr.data() + off.back());
             { const size_t o = fr.size(); fr.resize(o + frag_3x3_split_floats(cin)); pack_frag_3x3_split(w1, cin, fr.data() + o); }
@@ -307,7 +313,9 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         size_t i = 0;
         auto nxt = [&]() { const size_t o = off[i++]; return o == (size_t)-1 ? (const float*)nullptr : ctx->fragdev + o; };
         ctx->f_inc[0] = nxt(); ctx->f_inc[1] = nxt();
-        for (int d = 0; d < depth; ++d) { ctx->f_sig[d][0] = nxt(); ctx->f_sig[d][1] = nxt(); ctx->f_down[d] = nxt(); nxt(); nxt(); }
+        for (int d = 0; d < depth; ++d) {
+            ctx->f_sig[d][0] = nxt(); ctx->f_sig[d][1] = nxt(); ctx->f_down[d] = nxt(); ctx->f_st[d][0] = nxt(); ctx->f_st[d][1] = nxt();
+        }
         for (int d = 0; d <= depth; ++d) { ctx->f_dec[d][0] = nxt(); ctx->f_dec[d][1] = nxt(); }
         for (int d = 0; d < depth; ++d) ctx->f_up[d] = nxt();
     }

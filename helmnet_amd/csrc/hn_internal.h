@@ -74,12 +74,15 @@ struct hn_ctx {
     float* fragdev = nullptr;
     const float *f_inc[2]{}, *f_sig[hn::kMaxDepth][2]{}, *f_dec[hn::kMaxDepth + 1][2]{};
     const float *f_down[hn::kMaxDepth]{}, *f_up[hn::kMaxDepth]{};
+    const float* f_st[hn::kMaxDepth][2]{};   // conv_state (2 output channels in rows 0..3 of M): [10][3][64], [2][3][64] (hn_deep.hip)
+    bool deep_attr_set = false;
     // arithmetic of the UNet convolutions (hn_set_unet_precision; default from HN_UNET_IMPL at hn_create only)
     int precision = HN_PREC_FP32;
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
     int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
     int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
     int opt_graph = 1;         // hn_step replays one captured iteration (HIP graph) instead of ~25 launches
+    int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
     // domain
@@ -149,7 +152,8 @@ enum KernelId : int {
     KID_DEC0 = 21,        // + 2*d : decoder DoubleConv 16->8->8 at level d (d = 0: + outc + wf update)
     KID_SPEC_COLS = 32,   // spectral column pass
     KID_SPEC_ROWS = 33,   // spectral row pass + residual terms (or the dense operator)
-    KID_COUNT = 34
+    KID_DEEP = 34,        // deepest level in one per-sample kernel: conv_signal, conv_state, down, bottleneck, up, decoder
+    KID_COUNT = 35
 };
 
 // RAII event pair around one launch when that kernel id is selected by hn_profile_enable.
@@ -200,6 +204,12 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
 void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
 void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
+
+// ---- deep levels in one per-sample kernel (hn_deep.hip) ----
+void pack_frag_3x3_c2(const float* w_oihw, int cin, float* dst);  // 2 output channels -> [cin][3][64], rows 4..15 of M zero
+bool deep_applies(const hn_ctx* ctx);
+int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, float* st_out, long st_sb, long st_sc, float* y_out,
+                long y_sb, int batch, hipStream_t s);
 
 // ---- unet (hn_unet.hip) ----
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the

@@ -440,7 +440,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     if (mfma) launch_dc8(ctx, 0, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, ctx->f_inc[0], ctx->f_inc[1], false, nullptr, nullptr, n, n, batch, s);
     else launch_dc<2, 2, 2, kFeat, kFeat, 0>(in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, noepi, n, n, batch, s);
     }
-    for (int d = 0; d < depth; ++d) {
+    // the deepest level (32 x 32) and the bottleneck run as one per-sample kernel (hn_deep.hip) where they fit LDS
+    const bool deep = mfma && deep_applies(ctx);
+    const int n_enc = deep ? depth - 1 : depth;   // encoder levels launched layer by layer
+    for (int d = 0; d < n_enc; ++d) {
         const int m = n >> d;
         const Src st_old{states_in + ctx->state_off[d], 2 * L, L, 1.f};
         const Dst st_new{states_out + ctx->state_off[d], 2 * L, L};
@@ -468,13 +471,13 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                 dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                                 ctx->down[d], m, m);
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
-        if (side != nullptr && d == depth - 1) {
+        if (side != nullptr && d == n_enc - 1) {
             // One release for all four conv_state kernels, after the last down: every skip tensor exists, and
             // the main chain is entering its small, latency-bound levels, whose idle CUs the side stream
             // fills.  (An event record costs the main stream a ~6 us bubble, so there is exactly one.)
             HN_HIP(ctx, hipEventRecord(side_lane->ev[0], s));
             HN_HIP(ctx, hipStreamWaitEvent(side, side_lane->ev[0], 0));
-            for (int e = 0; e < depth; ++e) {
+            for (int e = 0; e < n_enc; ++e) {
                 const int me = n >> e;
                 const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
                 const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
@@ -483,15 +486,22 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             }
         }
     }
+    if (deep) {
+        const int d = depth - 1;
+        ProfScope ps(ctx, KID_DEEP, s);
+        int rc = launch_deep(ctx, ctx->buf_a[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), states_in + ctx->state_off[d],
+                             states_out + ctx->state_off[d], 2 * L, L, ctx->buf_y[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), batch, s);
+        if (rc != HN_OK) return rc;
+    }
     // bottleneck: decode[depth]                                          (architectures.py:453)
-    {
+    if (!deep) {
         ProfScope ps(ctx, KID_BOTTLENECK, s);
         if (mfma) launch_dc8(ctx, 2, featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth), ctx->dec[depth],
                              ctx->f_dec[depth][0], ctx->f_dec[depth][1], false, nullptr, nullptr, n >> depth, n >> depth, batch, s);
         else launch_dc<kFeat, 0, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth),
                                                      ctx->dec[depth], noepi, n >> depth, n >> depth, batch, s);
     }
-    for (int d = depth - 1; d >= 0; --d) {
+    for (int d = n_enc - 1; d >= 0; --d) {
         const int m = n >> d;
         // x = up[d](x)                                                   (architectures.py:456)
         {

@@ -117,7 +117,7 @@ class Engine:
         return {v: k for k, v in _lib.HN_PRECISION.items()}[code]
 
     def set_option(self, name: str, value: int):
-        """hn_step tuning knobs: 'lanes' (1..8), 'side_stream' (0/1), 'graph' (0/1)."""
+        """hn_step tuning knobs: 'lanes' (1..8), 'side_stream' (0/1), 'graph' (0/1), 'deep' (0/1)."""
         _lib.check(self.lib.hn_set_option(self.ctx, _lib.HN_OPTION[name], int(value)), self.ctx, "hn_set_option")
 
     def counter(self, name: str) -> int:
@@ -208,7 +208,7 @@ class Engine:
         _lib.check(rc, self.ctx, "hn_step")
 
     # ---- measurement hooks ---------------------------------------------------------------
-    KERNEL_IDS = 34
+    KERNEL_IDS = 35
 
     @staticmethod
     def kernel_name(kid: int) -> str:
@@ -220,7 +220,7 @@ class Engine:
             return "bottleneck"
         if 20 <= kid <= 31:
             return ("up", "decode")[(kid - 20) % 2] + str((kid - 20) // 2)
-        return {32: "spectral_cols", 33: "spectral_rows"}[kid]
+        return {32: "spectral_cols", 33: "spectral_rows", 34: "deep"}[kid]
 
     def profile_enable(self, kernel_ids=None):
         """Bracket the selected kernels (None = all, [] = none) with HIP events on the launch stream."""

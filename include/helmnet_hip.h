@@ -61,7 +61,8 @@ enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_P
 enum hn_option {
     HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
     HN_OPT_SIDE_STREAM = 1,  /* 0/1: conv_state kernels on a library side stream (default 1)                     */
-    HN_OPT_GRAPH = 2         /* 0/1: replay one captured iteration as a HIP graph instead of ~25 launches (default 1) */
+    HN_OPT_GRAPH = 2,        /* 0/1: replay one captured iteration as a HIP graph instead of ~25 launches (default 1) */
+    HN_OPT_DEEP = 3          /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };
@@ -152,10 +153,12 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
  * hn_residual is bracketed by a HIP event pair recorded on the caller's stream.  Kernel ids:
  *   0 inc | 1+3d conv_signal(d) | 2+3d conv_state(d) | 3+3d down(d) | 19 bottleneck |
  *   20+2d up(d) | 21+2d decoder(d) (d=0 includes outc + wavefield update) |
- *   32 spectral column pass | 33 spectral row pass (or the dense operator).
+ *   32 spectral column pass | 33 spectral row pass (or the dense operator) |
+ *   34 the fused deepest level (conv_signal, conv_state, down, bottleneck, up, decoder of level depth-1 in one kernel;
+ *      those six ids then do not occur).
  * hn_profile_collect synchronises the recorded events, returns per-id total milliseconds and
  * launch counts for ids [0, n_ids) and resets the accumulators. */
-#define HN_KERNEL_IDS 34
+#define HN_KERNEL_IDS 35
 int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
 /* Bracket only every `every_nth` launch of a selected kernel (default 1).  An event pair costs a few
  * microseconds of stream gap, so timed runs sample instead of bracketing every launch. */

@@ -353,3 +353,41 @@ def test_standalone_hybridnet_matches_oracle(weights):
     want, st = O.unet_forward(x, [torch.zeros(2, 2, s, s) for s in O.state_dims(64, 4)], weights)
     assert (d - want).abs().max().item() <= 1e-5 * want.abs().max().item()
     assert (net.get_states(flatten=True).cpu() - O.flatten_states(st)).abs().max().item() <= 1e-5
+
+
+def test_fused_deep_level_kernel_matches_the_layer_by_layer_path(weights):
+    """hn_deep.hip (conv_signal, conv_state, down, bottleneck, up, decoder of the 32 x 32 level in one per-sample LDS
+    kernel) against the same layers launched one by one (HN_OPT_DEEP = 0) and against the oracle; N = 256 (depth 4) is
+    the shape it applies to."""
+    from helmnet_amd import IterativeSolver
+    n, b = 256, 3
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=555).items()}
+    outs = {}
+    for deep in (1, 0):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=SRC[n])
+        s.engine().set_option("deep", deep)
+        g = {k: v.to(DEV) for k, v in ti.items()}
+        k_sq, _ = s.get_initials(g["sos"])
+        s.f.set_states(g["states"], flatten=True)
+        wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
+        outs[deep] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
+        prof = s.engine()
+        prof.profile_enable(None)
+        s.f.set_states(g["states"], flatten=True)
+        s.single_step(g["wf"], k_sq, g["res"])
+        torch.cuda.synchronize()
+        names = set(prof.profile_collect())
+        prof.profile_enable([])
+        assert ("deep" in names) == bool(deep) and ("bottleneck" in names) == (not deep), names
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, SRC[n], 10.0), t)
+    want = (want[0], want[1], O.flatten_states(want[2]))
+    for a, bb, w in zip(outs[1], outs[0], want):
+        scale = w.abs().max().item()
+        assert (a - bb).abs().max().item() <= 2e-6 * scale
+        assert (a - w).abs().max().item() <= 1e-5 * scale
+    # level-3 slice of the new hidden state (written by the fused kernel) specifically
+    L3 = slice(256 * 256 + 128 * 128 + 64 * 64, None)
+    assert (outs[1][2][:, :, L3] - want[2][:, :, L3]).abs().max().item() <= 1e-5 * want[2][:, :, L3].abs().max().item()

@@ -74,7 +74,7 @@ def test_oracle_parameter_free_activations_vs_reference_fixture(g_r2, weights, a
     x = torch.from_numpy(g_r2["act_input"])
     d, st = O.unet_forward(x, O.unflatten_states(torch.from_numpy(ti["states"]), 64, 4), w)
     assert (d - torch.from_numpy(g_r2[f"{act}_d"])).abs().max().item() <= 1e-5 * np.abs(g_r2[f"{act}_d"]).max()
-    assert (O.flatten_states(st) - torch.from_numpy(g_r2[f"{act}_states"])).abs().max().item() <= 1e-5
+    assert (O.flatten_states(st) - torch.from_numpy(g_r2[f"{act}_states"])).abs().max().item() <= 1e-5 * np.abs(g_r2[f"{act}_states"]).max()
 
 
 def test_explicit_operator_is_the_oracle_operator():
@@ -112,7 +112,7 @@ def test_gpu_parameter_free_activations_vs_reference_fixture(g_r2, weights, act)
     net.set_states(torch.from_numpy(ti["states"]).to(DEV), flatten=True)
     d = net(torch.from_numpy(g_r2["act_input"]).to(DEV)).cpu().numpy()
     assert np.abs(d - g_r2[f"{act}_d"]).max() <= 1e-5 * np.abs(g_r2[f"{act}_d"]).max()
-    assert np.abs(net.get_states(flatten=True).cpu().numpy() - g_r2[f"{act}_states"]).max() <= 1e-5
+    assert np.abs(net.get_states(flatten=True).cpu().numpy() - g_r2[f"{act}_states"]).max() <= 1e-5 * np.abs(g_r2[f"{act}_states"]).max()
 
 
 @pytest.mark.gpu
@@ -159,7 +159,7 @@ def solve(local, n_iter):
     return {"wavefield": state["wf"], "rmse": o["residual_norms"][-1]}
 r = solve_sharded(solve, sos, 60, tol=None, gather=True)
 assert torch.equal(r["wavefield_all"], plain["wavefields"][0]), "sharded solve differs from forward()"
-assert torch.equal(r["worst_rmse"].cpu(), plain["residual_norms"][-1].max().reshape(1).cpu())
+assert torch.allclose(r["worst_rmse"].cpu(), plain["residual_norms"][-1].max().reshape(1).cpu(), rtol=1e-5)   # per-sample sums are float atomics
 t = s.solve_to_tolerance(sos, tol=1e-3, max_iterations=200, check_every=20, norm_reduce=allreduce_residual_norms)
 u = s.solve_to_tolerance(sos, tol=1e-3, max_iterations=200, check_every=20)
 assert t["converged"] and t["iterations"] == u["iterations"] and torch.equal(t["wavefield"], u["wavefield"])
