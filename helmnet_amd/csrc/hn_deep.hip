@@ -63,65 +63,182 @@ struct DeepW {
 // PReLU as median(x, s x, +-inf) (exactly x or s x), see hn_mfma.hip
 __device__ __forceinline__ float prelu(float x, float slope, float sel) { return __builtin_amdgcn_fmed3f(x, slope * x, sel); }
 
-// 3x3 convolution over a 32 x 32 plane set held in LDS.  Wave `wave` computes output rows 4 wave .. 4 wave + 3, all
-// 32 columns: acc[r] = {ch 2q: pixels 2n, 2n + 1; ch 2q + 1: pixels 2n, 2n + 1}.  Channels come from two plane sets
-// (the implicit concatenation); `afr` is [CA + CB][3][64].  The A fragments of the next channel and the LDS rows of
-// the next channel are requested while the current channel's 12 MFMAs issue.
-template <int CA, int CB>
-__device__ __forceinline__ void conv3x3_s32(f32x4 (&acc)[4], const float* pa, int pitch_a, int plane_a, const float* pb, int pitch_b,
-                                            int plane_b, const float* __restrict__ afr, int wave, int lane) {
-    const int n = lane & 15, q = lane >> 4;
-    constexpr int C = CA + CB;
-    // element (row 4 wave - 1 + j, column 2n + q - 1) of channel c; pa / pb point at pixel (0, 0)
-    const float* ba = pa + (4 * wave - 1) * pitch_a + 2 * n + q - 1;
-    const float* bb = pb + (4 * wave - 1) * pitch_b + 2 * n + q - 1;
-    float br[2][6], af[2][3];
-    auto rows = [&](int c, float (&dst)[6]) {
-        const float* p = c < CA ? ba + c * plane_a : bb + (c - CA) * plane_b;
-        const int pitch = c < CA ? pitch_a : pitch_b;
+// Scheduling: hipcc would sink every LDS read and weight load next to its first use (it minimises registers), which
+// exposes one LDS / L2 round trip per MFMA group.  The loops below are explicit software pipelines, pinned with
+// sched_barrier / sched_group_barrier: operands of step k + 1 (LDS) and k + 2 (weights, from L2) are requested while
+// step k's MFMAs issue.
+template <int N_DS, int N_VMEM>
+__device__ __forceinline__ void interleave(int n_mfma_total) {
+    (void)n_mfma_total;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) dst[j] = p[j * pitch];
-    };
-    auto frag = [&](int c, float (&dst)[3]) {
+    for (int i = 0; i < N_DS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) dst[dy] = afr[(c * 3 + dy) * 64 + lane];
-    };
-    rows(0, br[0]);
-    frag(0, af[0]);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        if (c + 1 < C) {
-            rows(c + 1, br[(c + 1) & 1]);
-            frag(c + 1, af[(c + 1) & 1]);
-        }
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r] = mfma4(af[c & 1][dy], br[c & 1][r + dy], acc[r]);
+    for (int i = 0; i < N_VMEM; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // VMEM read
     }
 }
 
-// the same at 16 x 16: wave owns rows 2 wave, 2 wave + 1; lane n -> (row n >> 3, pair n & 7); one accumulator
+// 3x3 convolution over a 32 x 32 plane set held in LDS.  Wave `wave` computes output rows 4 wave .. 4 wave + 3, all
+// 32 columns: acc[r] = {ch 2q: pixels 2n, 2n + 1; ch 2q + 1: pixels 2n, 2n + 1}.  Channels come from two plane sets
+// (the implicit concatenation); `afr` is [CA + CB][3][64].  prefetch() may run before the barrier that publishes the
+// input planes (it only touches the weights).
+template <int CA, int CB>
+struct Conv32 {
+    static constexpr int C = CA + CB;
+    float af[3][3];   // A fragments of channels c, c + 1, c + 2 (ring)
+    __device__ __forceinline__ void frag(const float* __restrict__ afr, int c, int lane) {
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) af[c % 3][dy] = afr[(c * 3 + dy) * 64 + lane];
+    }
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int lane) {
+        frag(afr, 0, lane);
+        if (C > 1) frag(afr, 1, lane);
+    }
+    __device__ __forceinline__ void run(f32x4 (&acc)[4], const float* pa, int pitch_a, int plane_a, const float* pb, int pitch_b,
+                                        int plane_b, const float* __restrict__ afr, int wave, int lane) {
+        const int n = lane & 15, q = lane >> 4;
+        // element (row 4 wave - 1 + j, column 2n + q - 1) of channel c; pa / pb point at pixel (0, 0)
+        const float* ba = pa + (4 * wave - 1) * pitch_a + 2 * n + q - 1;
+        const float* bb = pb + (4 * wave - 1) * pitch_b + 2 * n + q - 1;
+        float br[2][6];
+        auto rows = [&](int c, float (&dst)[6]) {
+            const float* p = c < CA ? ba + c * plane_a : bb + (c - CA) * plane_b;
+            const int pitch = c < CA ? pitch_a : pitch_b;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) dst[j] = p[j * pitch];
+        };
+        rows(0, br[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (c + 1 < C) rows(c + 1, br[(c + 1) & 1]);
+            if (c + 2 < C) frag(afr, c + 2, lane);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = mfma4(af[c % 3][dy], br[c & 1][r + dy], acc[r]);
+            if (c + 2 < C) interleave<6, 3>(12);
+            else if (c + 1 < C) interleave<6, 0>(12);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+// the same at 16 x 16: wave owns rows 2 wave, 2 wave + 1; lane n -> (row n >> 3, pair n & 7); one accumulator.  Only 3 MFMAs
+// per channel: all 24 fragments are requested up front (prefetch, before the barrier), the LDS operands 2 channels ahead.
 template <int C>
-__device__ __forceinline__ void conv3x3_s16(f32x4& acc, const float* p, int pitch, int plane, const float* __restrict__ afr, int wave, int lane) {
-    const int n = lane & 15, q = lane >> 4;
-    const float* b = p + (2 * wave + (n >> 3) - 1) * pitch + 2 * (n & 7) + q - 1;
-    float bv[2][3], af[2][3];
+struct Conv16 {
+    float af[C][3];
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int lane) {
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) { bv[0][dy] = b[dy * pitch]; af[0][dy] = afr[dy * 64 + lane]; }
+        for (int c = 0; c < C; ++c)
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-        if (c + 1 < C) {
+            for (int dy = 0; dy < 3; ++dy) af[c][dy] = afr[(c * 3 + dy) * 64 + lane];
+    }
+    __device__ __forceinline__ void run(f32x4& acc, const float* p, int pitch, int plane, int wave, int lane) {
+        const int n = lane & 15, q = lane >> 4;
+        const float* b = p + (2 * wave + (n >> 3) - 1) * pitch + 2 * (n & 7) + q - 1;
+        float bv[C][3];
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                bv[(c + 1) & 1][dy] = b[(c + 1) * plane + dy * pitch];
-                af[(c + 1) & 1][dy] = afr[((c + 1) * 3 + dy) * 64 + lane];
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) bv[c][dy] = b[c * plane + dy * pitch];
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) acc = mfma4(af[c][dy], bv[c][dy], acc);
+    }
+};
+
+// 8x8 stride-2 down convolution 32 x 32 -> 16 x 16: wave owns output rows 2 wave, 2 wave + 1 = window rows 2 wave .. + 3;
+// 64 steps (ci, kx) of 4 MFMAs; the 8 fragments of channel ci + 1 arrive one per step of channel ci.
+struct Down32 {
+    float af[2][8];
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int lane) {
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) af[0][kx] = afr[kx * 64 + lane];
+    }
+    __device__ __forceinline__ void run(f32x4 (&acc)[4], const float* out_px00, int wave, int lane, const float* __restrict__ afr) {
+        const int n = lane & 15, q = lane >> 4;
+        // B of window row i, tap kx: out[ci][2 (2 wave + i) - 3 + q][2 n - 3 + kx]
+        const float* bbase = out_px00 + (4 * wave - 3 + q) * OUT_PITCH + 2 * n - 3;
+        float bv[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[0][i] = bbase[2 * i * OUT_PITCH];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 64; ++u) {
+            const int ci = u >> 3, kx = u & 7;
+            if (u + 1 < 64) {
+                const int c1 = (u + 1) >> 3, k1 = (u + 1) & 7;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[(u + 1) & 1][i] = bbase[c1 * OUT_PLANE + 2 * i * OUT_PITCH + k1];
+            }
+            if (ci + 1 < 8) af[(ci + 1) & 1][kx] = afr[((ci + 1) * 8 + kx) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mfma4(af[ci & 1][kx], bv[u & 1][i], acc[i]);
+            if (ci + 1 < 8) interleave<4, 1>(4);
+            else if (u + 1 < 64) interleave<4, 0>(4);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+};
+
+// 8x8 stride-2 transposed convolution 16 x 16 -> 32 x 32: wave owns output-column parity px and NROW window rows
+// i0, i0 + 4, ... (i = Y + 1); 32 steps (ci, bb) of NROW MFMAs.
+template <int NROW>
+struct Up16 {
+    float af[2][4];
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr_px_lane) {
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) af[0][bb] = afr_px_lane[bb * 64];
+    }
+    __device__ __forceinline__ void run(f32x4 (&acc)[NROW], const float* y4_px00, int i0, int px, int lane, const float* __restrict__ afr_px_lane) {
+        const int n = lane & 15, q = lane >> 4;
+        // B of window row i, tap bb: y4[ci][i - 2 + q][n - 2 + px + bb]
+        const float* bbase = y4_px00 + (i0 - 2 + q) * Y4_PITCH + n - 2 + px;
+        float bv[2][NROW];
+#pragma unroll
+        for (int k = 0; k < NROW; ++k) bv[0][k] = bbase[4 * k * Y4_PITCH];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+            const int ci = u >> 2, bb = u & 3;
+            if (u + 1 < 32) {
+                const int c1 = (u + 1) >> 2, b1 = (u + 1) & 3;
+#pragma unroll
+                for (int k = 0; k < NROW; ++k) bv[(u + 1) & 1][k] = bbase[c1 * Y4_PLANE + 4 * k * Y4_PITCH + b1];
+            }
+            if (ci + 1 < 8) af[(ci + 1) & 1][bb] = afr_px_lane[((ci + 1) * 8 + bb) * 64];
+#pragma unroll
+            for (int k = 0; k < NROW; ++k) acc[k] = mfma4(af[ci & 1][bb], bv[u & 1][k], acc[k]);
+            if (ci + 1 < 8) interleave<NROW, 1>(NROW);
+            else if (u + 1 < 32) interleave<NROW, 0>(NROW);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // D rows of lane (n, q): (co = 2q, py = 0), (2q, 1), (2q + 1, 0), (2q + 1, 1) for output column 2 n + px
+    __device__ __forceinline__ void store(const f32x4 (&acc)[NROW], float* u_px00, int i0, int px, int lane, float b0, float b1) {
+        const int n = lane & 15, q = lane >> 4;
+#pragma unroll
+        for (int k = 0; k < NROW; ++k) {
+            const int Y = i0 + 4 * k - 1;
+#pragma unroll
+            for (int py = 0; py < 2; ++py) {
+                const int y = 2 * Y + 1 + py;
+                if (y >= 0 && y < S) {
+                    float* u = u_px00 + (2 * q) * P32_PLANE + y * P32_PITCH + 2 * n + px;
+                    u[0] = acc[k][py] + b0;
+                    u[P32_PLANE] = acc[k][2 + py] + b1;
+                }
             }
         }
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy) acc = mfma4(af[c & 1][dy], bv[c & 1][dy], acc);
     }
-}
+};
 
 __device__ __forceinline__ void zero_fill(float* p, int count, int tid) {  // count % 4 == 0, p 16-byte aligned
     for (int i = tid; i < count / 4; i += 512) reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -152,6 +269,9 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         const int c = tid >> 8, r = tid & 255;                                          // 2 planes x 256 float4
         vs = reinterpret_cast<const float4*>(st_in + (long)b * st_sb + (long)c * st_sc)[r];
     }
+    Conv32<8, 2> cv_sig1;
+    Conv32<8, 0> cv_sig2;
+    cv_sig1.prefetch(w.sig1, lane);
     zero_fill(lds, LDS_FLOATS, tid);
     __syncthreads();
     {
@@ -170,6 +290,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
     __syncthreads();
 
     const float inf = __builtin_inff();
+    Conv32<8, 2> cv_st1;
+    Conv32<2, 0> cv_st2;
     // ---- stage 1 + 2: out = conv_signal(cat[x, state]) ----
     {
         const float b0 = w.sig1_b[2 * q], b1 = w.sig1_b[2 * q + 1], slope = w.sig_slope[0];
@@ -177,7 +299,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (f32x4){b0, b0, b1, b1};
-        conv3x3_s32<8, 2>(acc, X, P32_PITCH, P32_PLANE, ST, P32_PITCH, P32_PLANE, w.sig1, wave, lane);
+        cv_sig1.run(acc, X, P32_PITCH, P32_PLANE, ST, P32_PITCH, P32_PLANE, w.sig1, wave, lane);
+        cv_sig2.prefetch(w.sig2, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float* m = MID + (2 * q) * P32_PLANE + (4 * wave + r) * P32_PITCH + 2 * n;
@@ -191,7 +314,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (f32x4){b0, b0, b1, b1};
-        conv3x3_s32<8, 0>(acc, MID, P32_PITCH, P32_PLANE, MID, P32_PITCH, P32_PLANE, w.sig2, wave, lane);
+        cv_sig2.run(acc, MID, P32_PITCH, P32_PLANE, MID, P32_PITCH, P32_PLANE, w.sig2, wave, lane);
+        cv_st1.prefetch(w.st1, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float* o = OUT + (2 * q) * OUT_PLANE + (4 * wave + r) * OUT_PITCH + 2 * n;   // odd pitch: 4-byte stores
@@ -209,7 +333,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (f32x4){b0, b0, b1, b1};   // only the q == 0 lanes hold real rows of M
-        conv3x3_s32<8, 2>(acc, OUT, OUT_PITCH, OUT_PLANE, ST, P32_PITCH, P32_PLANE, w.st1, wave, lane);
+        cv_st1.run(acc, OUT, OUT_PITCH, OUT_PLANE, ST, P32_PITCH, P32_PLANE, w.st1, wave, lane);
+        cv_st2.prefetch(w.st2, lane);
         if (q == 0) {   // x_D's planes are dead since stage 1
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -225,7 +350,7 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (f32x4){b0, b0, b1, b1};
-        conv3x3_s32<2, 0>(acc, X, P32_PITCH, P32_PLANE, X, P32_PITCH, P32_PLANE, w.st2, wave, lane);
+        cv_st2.run(acc, X, P32_PITCH, P32_PLANE, X, P32_PITCH, P32_PLANE, w.st2, wave, lane);
         if (q == 0) {
             float* g = st_out + (long)b * st_sb + (4 * wave) * S + 2 * n;
 #pragma unroll
@@ -235,32 +360,16 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
             }
         }
     }
-    // ---- stage 5: x = down(out): wave owns output rows 2 wave, 2 wave + 1 = window rows 2 wave .. 2 wave + 3 ----
+    // ---- stage 5: x = down(out) ----
+    Conv16<8> cv_bot;
     {
+        Down32 dn;
+        dn.prefetch(w.down, lane);
+        cv_bot.prefetch(w.bot1, lane);   // lands while the 256 MFMAs of the down convolution issue
         f32x4 acc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // B of window row i, tap kx: out[ci][2 (2 wave + i) - 3 + q][2 n - 3 + kx]
-        const float* bbase = OUT + (4 * wave - 3 + q) * OUT_PITCH + 2 * n - 3;
-        float af[2][8];
-#pragma unroll
-        for (int kx = 0; kx < 8; ++kx) af[0][kx] = w.down[kx * 64 + lane];
-#pragma unroll
-        for (int ci = 0; ci < 8; ++ci) {
-            if (ci + 1 < 8) {
-#pragma unroll
-                for (int kx = 0; kx < 8; ++kx) af[(ci + 1) & 1][kx] = w.down[((ci + 1) * 8 + kx) * 64 + lane];
-            }
-            const float* t = bbase + ci * OUT_PLANE;
-#pragma unroll
-            for (int kx = 0; kx < 8; ++kx) {
-                float bv[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) bv[i] = t[2 * i * OUT_PITCH + kx];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] = mfma4(af[ci & 1][kx], bv[i], acc[i]);
-            }
-        }
+        dn.run(acc, OUT, wave, lane, w.down);
         const float b0 = w.down_b[2 * q], b1 = w.down_b[2 * q + 1];
 #pragma unroll
         for (int r = 0; r < 2; ++r) {   // out[Y] = P0[Y] + P1[Y + 2]
@@ -275,67 +384,46 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         const float b0 = w.bot1_b[2 * q], b1 = w.bot1_b[2 * q + 1], slope = w.bot_slope[0];
         const float sel = slope <= 1.f ? inf : -inf;
         f32x4 acc = (f32x4){b0, b0, b1, b1};
-        conv3x3_s16<8>(acc, X4, P16_PITCH, P16_PLANE, w.bot1, wave, lane);
+        cv_bot.run(acc, X4, P16_PITCH, P16_PLANE, wave, lane);
+        cv_bot.prefetch(w.bot2, lane);
         float* m = MID4 + (2 * q) * P16_PLANE + (2 * wave + (n >> 3)) * P16_PITCH + 2 * (n & 7);
         *reinterpret_cast<float2*>(m) = make_float2(prelu(acc[0], slope, sel), prelu(acc[1], slope, sel));
         *reinterpret_cast<float2*>(m + P16_PLANE) = make_float2(prelu(acc[2], slope, sel), prelu(acc[3], slope, sel));
     }
     __syncthreads();
+    const int px = wave & 1, i0 = wave >> 1;   // stage 8: output-column parity and first window row of this wave
+    const float* const up_afr = w.up + px * 4 * 64 + lane;
+    Up16<5> up5;   // waves 0, 1 take the 17th window row (Y = 15)
+    Up16<4> up4;
     {
         const float b0 = w.bot2_b[2 * q], b1 = w.bot2_b[2 * q + 1];
         f32x4 acc = (f32x4){b0, b0, b1, b1};
-        conv3x3_s16<8>(acc, MID4, P16_PITCH, P16_PLANE, w.bot2, wave, lane);
+        cv_bot.run(acc, MID4, P16_PITCH, P16_PLANE, wave, lane);
+        if (wave < 2) up5.prefetch(up_afr); else up4.prefetch(up_afr);
         float* y = Y4 + (2 * q) * Y4_PLANE + (2 * wave + (n >> 3)) * Y4_PITCH + 2 * (n & 7);
         y[0] = acc[0]; y[1] = acc[1];
         y[Y4_PLANE] = acc[2]; y[Y4_PLANE + 1] = acc[3];
     }
     __syncthreads();
-    // ---- stage 8: x = up(x): wave owns output-column parity px = wave & 1 and window rows i0, i0 + 4, .. (i = Y + 1) ----
+    // ---- stage 8: x = up(x) ----
+    Conv32<8, 8> cv_dec1;
+    Conv32<8, 0> cv_dec2;
     {
-        const int px = wave & 1, i0 = wave >> 1;
-        const int nrow = wave < 2 ? 5 : 4;           // 17 window rows (Y = -1 .. 15): waves 0, 1 take the 17th
-        f32x4 acc[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        // B of window row i, tap bb: y4[ci][i - 2 + q][n - 2 + px + bb]
-        const float* bbase = Y4 + (i0 - 2 + q) * Y4_PITCH + n - 2 + px;
-        const float* afr = w.up + px * 4 * 64 + lane;
-        float af[2][4];
-#pragma unroll
-        for (int bb = 0; bb < 4; ++bb) af[0][bb] = afr[bb * 64];
-#pragma unroll
-        for (int ci = 0; ci < 8; ++ci) {
-            if (ci + 1 < 8) {
-#pragma unroll
-                for (int bb = 0; bb < 4; ++bb) af[(ci + 1) & 1][bb] = afr[((ci + 1) * 8 + bb) * 64];
-            }
-            const float* t = bbase + ci * Y4_PLANE;
-#pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
-                float bv[5];
-#pragma unroll
-                for (int k = 0; k < 5; ++k) bv[k] = (k < 4 || nrow == 5) ? t[4 * k * Y4_PITCH + bb] : 0.f;
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    if (k < 4 || nrow == 5) acc[k] = mfma4(af[ci & 1][bb], bv[k], acc[k]);
-            }
-        }
         const float b0 = w.up_b[2 * q], b1 = w.up_b[2 * q + 1];
+        if (wave < 2) {
+            f32x4 acc[5];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            if (k < 4 || nrow == 5) {
-                const int Y = i0 + 4 * k - 1;
+            for (int k = 0; k < 5; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            up5.run(acc, Y4, i0, px, lane, up_afr);
+            up5.store(acc, X, i0, px, lane, b0, b1);
+        } else {
+            f32x4 acc[4];
 #pragma unroll
-                for (int py = 0; py < 2; ++py) {
-                    const int y = 2 * Y + 1 + py;
-                    if (y >= 0 && y < S) {
-                        float* u = X + (2 * q) * P32_PLANE + y * P32_PITCH + 2 * n + px;
-                        u[0] = acc[k][py] + b0;
-                        u[P32_PLANE] = acc[k][2 + py] + b1;
-                    }
-                }
-            }
+            for (int k = 0; k < 4; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            up4.run(acc, Y4, i0, px, lane, up_afr);
+            up4.store(acc, X, i0, px, lane, b0, b1);
         }
+        cv_dec1.prefetch(w.dec1, lane);
     }
     __syncthreads();   // up(x) complete; the 16 x 16 tensors are dead
     // ---- stage 9 + 10: y_D = decode_D(cat[up(x), out]) ----
@@ -346,7 +434,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (f32x4){b0, b0, b1, b1};
-        conv3x3_s32<8, 8>(acc, X, P32_PITCH, P32_PLANE, OUT, OUT_PITCH, OUT_PLANE, w.dec1, wave, lane);
+        cv_dec1.run(acc, X, P32_PITCH, P32_PLANE, OUT, OUT_PITCH, OUT_PLANE, w.dec1, wave, lane);
+        cv_dec2.prefetch(w.dec2, lane);
         __syncthreads();   // the zero fill of every thread has landed before any interior write
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -361,7 +450,7 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         f32x4 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = (f32x4){b0, b0, b1, b1};
-        conv3x3_s32<8, 0>(acc, MID, P32_PITCH, P32_PLANE, MID, P32_PITCH, P32_PLANE, w.dec2, wave, lane);
+        cv_dec2.run(acc, MID, P32_PITCH, P32_PLANE, MID, P32_PITCH, P32_PLANE, w.dec2, wave, lane);
         float* g = y_out + (long)b * y_sb + (long)(2 * q) * (S * S) + (4 * wave) * S + 2 * n;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
