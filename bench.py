@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--precision", "--unet-impl", dest="precision", default="fp32", choices=sorted(PEAK_TFLOPS),
                     help="UNet arithmetic of the HEADLINE run; the reported metric is fp32 (the reference's arithmetic)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured iteration")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning knob for A/B runs (hn_set_option): deep=0, side_stream=0, ...")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short 512^2 / bf16x3 side measurements")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel time table (stderr)")
@@ -225,6 +227,9 @@ def main():
     eng, sos_np, (wf, res, st, k_sq, src) = make_problem(solver, n, B, loc, rank, dev, rank == 0)   # each rank: its own shard of maps
     eng.set_option("lanes", args.lanes)
     eng.set_option("graph", 0 if args.no_graph else 1)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
     rmse = torch.zeros(max(K, W, 8), B, device=dev)
 
     # warm-up, W untimed steps (at least 7): all but the last 4 with every kernel bracketed by events to find the
@@ -315,7 +320,7 @@ def main():
             "dtype": DTYPE[prec], "data": "synthetic",
             "config": {"workload": f"{n}x{n} ring-phantom SoS maps, batch={B} per GPU, point source {loc}, "
                                    f"shipped jcp checkpoint weights, UNet precision {prec} ({cfg_name})",
-                       "batch_per_gpu": B, "domain": n, "lanes": args.lanes, "unet_precision": prec,
+                       "batch_per_gpu": B, "domain": n, "lanes": args.lanes, "unet_precision": prec, "options": args.opt,
                        "iteration_launch": {"graph_replays": replays, "kernel_by_kernel": eager},
                        "parallelism": f"dp{world} (batch shards, no data-path collective)"},
             "sample_iterations_per_s": round(world * B * K / dt, 1),

@@ -158,7 +158,7 @@ int hn_create(hn_ctx** out, int device_id) {
                      : std::strcmp(v, "bf16x2") == 0 ? HN_PREC_BF16X2 : std::strcmp(v, "valu") == 0 ? HN_PREC_FP32_VALU : HN_PREC_FP32;
     }
     if (const char* v = getenv("HN_STREAMS")) { const int n = atoi(v); c->opt_lanes = n < 1 ? 1 : n > 8 ? 8 : n; }
-    if (const char* v = getenv("HN_SIDE_STREAM")) c->opt_side_stream = atoi(v) != 0;
+    if (const char* v = getenv("HN_SIDE_STREAM")) { const int n = atoi(v); c->opt_side_stream = n < 0 ? 0 : n > 3 ? 3 : n; }
     if (const char* v = getenv("HN_GRAPH")) c->opt_graph = atoi(v) != 0;
     if (const char* v = getenv("HN_DEEP")) c->opt_deep = atoi(v) != 0;
     *out = c;
@@ -183,9 +183,13 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             if (value < 1 || value > 8) return fail(ctx, HN_ERR_ARG, "HN_OPT_LANES must be in [1, 8] (got %d)", value);
             ctx->opt_lanes = value;
             break;
-        case HN_OPT_SIDE_STREAM: ctx->opt_side_stream = value != 0; break;
+        case HN_OPT_SIDE_STREAM:
+            if (value < 0 || value > 3) return fail(ctx, HN_ERR_ARG, "HN_OPT_SIDE_STREAM must be in [0, 3] (got %d)", value);
+            ctx->opt_side_stream = value;
+            break;
         case HN_OPT_GRAPH: ctx->opt_graph = value != 0; break;
         case HN_OPT_DEEP: ctx->opt_deep = value != 0; break;
+        case HN_OPT_SPECTRAL_PFA: ctx->opt_pfa = value != 0; break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }
     clear_step_graphs(ctx);

@@ -54,7 +54,13 @@ struct SpecTables {
     float* k2 = nullptr;       // -(k1*k1) evaluated in fp32 like the reference
     float2* a = nullptr;       // PML first-derivative coefficient  (-gamma' / gamma^3)
     float2* b = nullptr;       // PML second-derivative coefficient (1 / gamma^2)
-    // dense fallback (n not a power of two): complex n x n operator, stored transposed
+    // prime-factor path (n = P * Q, P in {3, 5}, Q a power of two): Q-point twiddles and the derivative multipliers in
+    // the (k1, k2) order of the Good-Thomas output map; a / b above stay in natural order
+    int pfa_p = 0, pfa_q = 0;
+    float2* tw_q = nullptr;    // exp(-2 pi i m / Q)
+    float* k1_pfa = nullptr;   // [P][Q]
+    float* k2_pfa = nullptr;
+    // dense fallback (any other n): complex n x n operator, stored transposed
     float2* dense_t = nullptr; // dense_t[m*n + j] = M[j][m]
     float* sigmas = nullptr;   // [2, n, n]
 };
@@ -75,13 +81,14 @@ struct hn_ctx {
     const float *f_inc[2]{}, *f_sig[hn::kMaxDepth][2]{}, *f_dec[hn::kMaxDepth + 1][2]{};
     const float *f_down[hn::kMaxDepth]{}, *f_up[hn::kMaxDepth]{};
     const float* f_st[hn::kMaxDepth][2]{};   // conv_state (2 output channels in rows 0..3 of M): [10][3][64], [2][3][64] (hn_deep.hip)
-    bool deep_attr_set = false;
+    bool deep_attr_set = false, pfa_attr_set = false;
     // arithmetic of the UNet convolutions (hn_set_unet_precision; default from HN_UNET_IMPL at hn_create only)
     int precision = HN_PREC_FP32;
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
     int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
     int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
     int opt_graph = 1;         // hn_step replays one captured iteration (HIP graph) instead of ~25 launches
+    int opt_pfa = 1;           // prime-factor FFT for n = 3 * 2^k, 5 * 2^k (0: dense operator, A/B; takes effect at hn_set_domain)
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]

@@ -86,10 +86,10 @@ __device__ __forceinline__ void exchange_sync() {
 
 // NB independent transforms of the same direction run in lock step and share the exchange points (transform nb
 // lives at buf + nb * bstride): the passes are latency-bound, so two transforms cost little more than one.
-template <int N, int STRIDE, bool INV, int NB>
+template <int N, int STRIDE, bool INV, int NB, bool BLOCK_SYNC = false>
 __device__ __forceinline__ void fft_pass(float2 (&v)[NB][4], float2* buf, int bstride, int j, const Twiddles<N>& tw) {
     constexpr int T = N / 4;
-    constexpr bool WAVE = (STRIDE == 1 && T == 64);
+    constexpr bool WAVE = (STRIDE == 1 && T == 64 && !BLOCK_SYNC);   // BLOCK_SYNC: the threads of a line may span wavefronts
     int s = 0;
 #pragma unroll
     for (int ns = 1; ns * 4 <= N; ns *= 4) {
@@ -342,6 +342,167 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
     }
 }
 
+__global__ void k_bump(int* counter) { atomicAdd(counter, 1); }
+
+// ------------------------------------------------------------------------------------------
+// Prime-factor (Good-Thomas) path for n = P * Q, P in {3, 5}, Q = 2^k: the 96^2 training size, 160, 192, 320, ...
+//   input map   n = (Q n1 + P n2) mod N        output map   k = (Q (Q^-1 mod P) k1 + P (P^-1 mod Q) k2) mod N
+//   X[k(k1, k2)] = sum_n1 W_P^(n1 k1) sum_n2 W_Q^(n2 k2) x[n(n1, n2)]          (no twiddles between the factors)
+// so a length-N transform is P interleaved Q-point transforms -- run in lock step by the in-LDS Stockham pass above
+// (thread j of a line holds n2 = j + t Q/4 of every sub-sequence) -- followed by a P-point DFT ACROSS the lock-step
+// index, which is register-local.  The inverse runs the two steps in the opposite order, and the spectrum is consumed
+// in (k1, k2) order, so nothing is ever permuted.  One kernel serves both axes; lines are independent.
+//   AXIS 0: along W (row pass: adds the column part, the residual terms and the sum of squares)   AXIS 1: along H
+// ------------------------------------------------------------------------------------------
+template <int P>
+struct PfaConst {
+    float2 wp[P];       // exp(-2 pi i m / P); the output map k(k1, k2) is baked into the k tables on the host
+};
+
+template <int Q, int P, int AXIS>
+__global__ void k_spec_pfa(const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
+                           const float* __restrict__ src, long src_sb, const float2* __restrict__ tw_q,
+                           const float* __restrict__ k1p, const float* __restrict__ k2p, const float2* __restrict__ ca,
+                           const float2* __restrict__ cb, PfaConst<P> pc, int lines_per_block, int flags,
+                           float* __restrict__ sumsq, const int* __restrict__ it_counter, int sumsq_stride) {
+    constexpr int N = P * Q, T = Q / 4;
+    extern __shared__ float2 pbuf[];                       // [line][2 P][Q]
+    // AXIS 0: consecutive threads walk along the line; AXIS 1: consecutive threads own consecutive columns (coalescing)
+    const int j = AXIS == 0 ? threadIdx.x : threadIdx.y;
+    const int l = AXIS == 0 ? threadIdx.y : threadIdx.x;
+    const int line = blockIdx.x * lines_per_block + l, b = blockIdx.y;
+    const bool live = line < N;                            // all threads take part in the barriers
+    const int ln = live ? line : 0;
+    const long plane = (long)N * N;
+    const long lstride = AXIS == 0 ? 1 : N, lbase = AXIS == 0 ? (long)ln * N : ln;   // element n of the line at lbase + n * lstride
+    float2* buf = pbuf + (size_t)l * 2 * P * Q;
+    Twiddles<Q> tw;
+    tw.load(j, tw_q);
+    const float* pre = wf + (long)b * 2 * plane + lbase;
+    float2 u[P][4];
+    int pos[P][4];
+#pragma unroll
+    for (int s = 0; s < P; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            pos[s][t] = (Q * s + P * (j + t * T)) % N;
+            const long o = (long)pos[s][t] * lstride;
+            u[s][t] = make_float2(pre[o], pre[o + plane]);
+        }
+    float2 f[P][4];
+#pragma unroll
+    for (int s = 0; s < P; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[s][t] = u[s][t];
+    fft_pass<Q, 1, false, P, true>(f, buf, Q, j, tw);
+    // P-point DFT across the sub-sequences, derivative multipliers, inverse P-point DFT
+    float2 d[2 * P][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float2 z[P];
+#pragma unroll
+        for (int k1 = 0; k1 < P; ++k1) {
+            float2 acc = f[0][t];
+#pragma unroll
+            for (int s = 1; s < P; ++s) {
+                const float2 w = pc.wp[(s * k1) % P];
+                const float2 m = cmul(f[s][t], w);
+                acc.x += m.x; acc.y += m.y;
+            }
+            z[k1] = acc;
+        }
+        float2 g1[P], g2[P];
+#pragma unroll
+        for (int k1 = 0; k1 < P; ++k1) {
+            const float kk1 = k1p[k1 * Q + j + t * T], kk2 = k2p[k1 * Q + j + t * T];
+            g1[k1] = make_float2(-z[k1].y * kk1, z[k1].x * kk1);   // (0, k) * U     (spectral.py:50, 281)
+            g2[k1] = make_float2(kk2 * z[k1].x, kk2 * z[k1].y);    // (-k^2, 0) * U  (spectral.py:52, 283)
+        }
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
+            float2 a1 = g1[0], a2 = g2[0];
+#pragma unroll
+            for (int k1 = 1; k1 < P; ++k1) {
+                float2 w = pc.wp[(s * k1) % P];
+                w.y = -w.y;
+                const float2 m1 = cmul(g1[k1], w), m2 = cmul(g2[k1], w);
+                a1.x += m1.x; a1.y += m1.y;
+                a2.x += m2.x; a2.y += m2.y;
+            }
+            d[s][t] = a1;
+            d[P + s][t] = a2;
+        }
+    }
+    fft_pass<Q, 1, true, 2 * P, true>(d, buf, Q, j, tw);
+    constexpr float inv_n = 1.0f / N;
+    float ss = 0.f;
+    float* po = out + (long)b * 2 * plane + lbase;
+#pragma unroll
+    for (int s = 0; s < P; ++s)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = pos[s][t];
+            const float2 p = cmul(ca[n], d[s][t]), r = cmul(cb[n], d[P + s][t]);
+            float re = (p.x + r.x) * inv_n, im = (p.y + r.y) * inv_n;
+            const long o = (long)n * lstride;
+            if (AXIS == 0) {
+                if (flags & 1) { re += po[o]; im += po[o + plane]; }
+                if (flags & 2) {
+                    const float kq = ksq[(long)b * plane + lbase + o];
+                    const float* ps = src + (long)b * src_sb + lbase + o;
+                    re = re + kq * u[s][t].x - ps[0];
+                    im = im + kq * u[s][t].y - ps[plane];
+                }
+            }
+            if (live) {
+                po[o] = re;
+                po[o + plane] = im;
+                ss += re * re + im * im;
+            }
+        }
+    if (AXIS == 0 && sumsq != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        const int tid = threadIdx.y * blockDim.x + threadIdx.x;
+        if ((tid & 63) == 0) {
+            const long row = it_counter != nullptr ? (long)(*it_counter - 1) * sumsq_stride : 0;
+            atomicAdd(&sumsq[row + b], ss);
+        }
+    }
+}
+
+template <int Q, int P>
+int launch_pfa(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch, bool resid,
+               float* sumsq, hipStream_t s, int* it_counter, int sumsq_stride) {
+    constexpr int N = P * Q, T = Q / 4;
+    const SpecTables& t = ctx->tab;
+    PfaConst<P> pc;
+    const double pi = 3.14159265358979323846;
+    for (int m = 0; m < P; ++m) pc.wp[m] = make_float2((float)std::cos(2.0 * pi * m / P), (float)-std::sin(2.0 * pi * m / P));
+    // lines per block: at most 256 threads and 96 KB of LDS (lines * 2 P Q float2); fewer lines (down to one wavefront)
+    // while the launch would not even give every CU two blocks -- these sizes are small problems
+    int lpb = 256 / T > 0 ? 256 / T : 1;
+    while (lpb > 1 && (size_t)lpb * 2 * P * Q * sizeof(float2) > 96 * 1024) lpb >>= 1;
+    while (lpb * T > 64 && (long)((N + lpb - 1) / lpb) * batch < 512) lpb >>= 1;
+    const size_t lds = (size_t)lpb * 2 * P * Q * sizeof(float2);
+    const dim3 grid((N + lpb - 1) / lpb, batch);
+    if (lds > 48 * 1024 && !ctx->pfa_attr_set) {
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_pfa<Q, P, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_pfa<Q, P, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        ctx->pfa_attr_set = true;
+    }
+    if (it_counter != nullptr) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, it_counter);
+    {
+        ProfScope ps(ctx, KID_SPEC_COLS, s);
+        hipLaunchKernelGGL((k_spec_pfa<Q, P, 1>), grid, dim3(lpb, T), lds, s, wf, out, nullptr, nullptr, 0L, t.tw_q, t.k1_pfa, t.k2_pfa,
+                           t.a, t.b, pc, lpb, 0, nullptr, nullptr, 0);
+    }
+    ProfScope ps(ctx, KID_SPEC_ROWS, s);
+    hipLaunchKernelGGL((k_spec_pfa<Q, P, 0>), grid, dim3(T, lpb), lds, s, wf, out, ksq, src, src_sb, t.tw_q, t.k1_pfa, t.k2_pfa, t.a, t.b,
+                       pc, lpb, 1 | (resid ? 2 : 0), sumsq, it_counter, sumsq_stride);
+    return HN_OK;
+}
+
 // Dense fallback: one thread per pixel, both axes; mt[m*n + j] = M[j][m].
 __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf, float* __restrict__ out,
                                                     const float* __restrict__ ksq, const float* __restrict__ src,
@@ -381,8 +542,6 @@ __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf
     }
 }
 
-__global__ void k_bump(int* counter) { atomicAdd(counter, 1); }
-
 template <int N>
 void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch,
                  const SpecPtrs& p, bool resid, float* sumsq, hipStream_t s, int* it_counter, int sumsq_stride) {
@@ -398,6 +557,16 @@ void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, con
                        1 | (resid ? 2 : 0), sumsq, it_counter, sumsq_stride);
 }
 
+// n = P * Q with P in {3, 5} and Q a power of two (16 .. 512 for P = 3, 16 .. 256 for P = 5): returns P, else 0
+int pfa_factor(int n) {
+    for (int P : {3, 5}) {
+        if (n % P != 0) continue;
+        const int Q = n / P;
+        if (Q >= 16 && (Q & (Q - 1)) == 0 && Q <= (P == 3 ? 512 : 256)) return P;
+    }
+    return 0;
+}
+
 template <typename T>
 int upload(hn_ctx* ctx, T** dst, const std::vector<T>& h) {
     HN_HIP(ctx, hipMalloc((void**)dst, h.size() * sizeof(T)));
@@ -408,7 +577,8 @@ int upload(hn_ctx* ctx, T** dst, const std::vector<T>& h) {
 }  // namespace
 
 void spec_free(SpecTables& t) {
-    for (void* p : {(void*)t.tw, (void*)t.k1, (void*)t.k2, (void*)t.a, (void*)t.b, (void*)t.dense_t, (void*)t.sigmas}) (void)hipFree(p);
+    for (void* p : {(void*)t.tw, (void*)t.k1, (void*)t.k2, (void*)t.a, (void*)t.b, (void*)t.dense_t, (void*)t.sigmas, (void*)t.tw_q,
+                    (void*)t.k1_pfa, (void*)t.k2_pfa}) (void)hipFree(p);
     t = SpecTables{};
 }
 
@@ -418,6 +588,7 @@ int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k) {
     if (n < 16 || n > 2048) return fail(ctx, HN_ERR_ARG, "domain size %d outside [16, 2048]", n);
     if (pml < 1 || 2 * pml > n) return fail(ctx, HN_ERR_ARG, "PML size %d does not fit domain %d", pml, n);
     spec_free(ctx->tab);
+    ctx->pfa_attr_set = false;   // another (P, Q) kernel instance from now on
     SpecTables& t = ctx->tab;
     t.n = n;
     t.pow2 = (n & (n - 1)) == 0;
@@ -467,6 +638,27 @@ int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k) {
         if ((rc = upload(ctx, &t.tw, tw)) != HN_OK) return rc;
         if ((rc = upload(ctx, &t.k1, k1)) != HN_OK) return rc;
         if ((rc = upload(ctx, &t.k2, k2)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.a, fa)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.b, fb)) != HN_OK) return rc;
+    } else if (ctx->opt_pfa && pfa_factor(n) != 0) {
+        const int P = pfa_factor(n), Q = n / P;
+        t.pfa_p = P;
+        t.pfa_q = Q;
+        int qinv = 1, pinv = 1;
+        while ((Q * qinv) % P != 1) ++qinv;
+        while ((P * pinv) % Q != 1) ++pinv;
+        std::vector<float2> twq(Q);
+        for (int m = 0; m < Q; ++m) twq[m] = make_float2((float)std::cos(2.0 * pi * m / Q), (float)-std::sin(2.0 * pi * m / Q));
+        std::vector<float> k1p((size_t)P * Q), k2p((size_t)P * Q);
+        for (int a1 = 0; a1 < P; ++a1)
+            for (int a2 = 0; a2 < Q; ++a2) {
+                const int kk = (int)(((long)Q * qinv * a1 + (long)P * pinv * a2) % n);   // Good-Thomas output map
+                k1p[(size_t)a1 * Q + a2] = k1[kk];
+                k2p[(size_t)a1 * Q + a2] = k2[kk];
+            }
+        if ((rc = upload(ctx, &t.tw_q, twq)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.k1_pfa, k1p)) != HN_OK) return rc;
+        if ((rc = upload(ctx, &t.k2_pfa, k2p)) != HN_OK) return rc;
         if ((rc = upload(ctx, &t.a, fa)) != HN_OK) return rc;
         if ((rc = upload(ctx, &t.b, fb)) != HN_OK) return rc;
     } else {
@@ -520,6 +712,16 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
             case 2048: launch_pow2<2048>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             default: return fail(ctx, HN_ERR_ARG, "unsupported power-of-two size %d", t.n);
         }
+    } else if (t.pfa_p != 0) {
+        int rc = HN_OK;
+#define HN_PFA(QQ, PP) case (PP) * 1024 + (QQ): rc = launch_pfa<QQ, PP>(ctx, wf, out, ksq, src, src_sb, batch, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+        switch (t.pfa_p * 1024 + t.pfa_q) {
+            HN_PFA(16, 3) HN_PFA(32, 3) HN_PFA(64, 3) HN_PFA(128, 3) HN_PFA(256, 3) HN_PFA(512, 3)
+            HN_PFA(16, 5) HN_PFA(32, 5) HN_PFA(64, 5) HN_PFA(128, 5) HN_PFA(256, 5)
+            default: return fail(ctx, HN_ERR_ARG, "internal: no prime-factor kernel for %d x %d", t.pfa_p, t.pfa_q);
+        }
+#undef HN_PFA
+        if (rc != HN_OK) return rc;
     } else {
         if (it_counter != nullptr) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, it_counter);
         ProfScope ps(ctx, KID_SPEC_ROWS, s);

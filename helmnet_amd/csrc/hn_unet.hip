@@ -443,6 +443,26 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     // the deepest level (32 x 32) and the bottleneck run as one per-sample kernel (hn_deep.hip) where they fit LDS
     const bool deep = mfma && deep_applies(ctx);
     const int n_enc = deep ? depth - 1 : depth;   // encoder levels launched layer by layer
+    // conv_state_d (architectures.py:248) feeds nothing in this iteration, so with a side stream it leaves the main
+    // chain.  When it is released (ctx->opt_side_stream):
+    //   1  all levels after the last layer-by-layer `down`: the main chain is entering its small, latency-bound levels
+    //   2  level d right behind conv_signal_d (beside down_d): nothing is pending when the per-sample deep kernel,
+    //      which needs whole CUs (136 KB of LDS), is dispatched.  Costs one event record per level when the launch
+    //      sequence is not being captured into a graph (an event record is a ~6 us bubble on the stream).
+    //   3  all levels behind the deep kernel (beside the decoder's small levels)
+    const int policy = side != nullptr ? ctx->opt_side_stream : 0;
+    auto release_states = [&](int d0, int d1, hipEvent_t ev) -> int {
+        HN_HIP(ctx, hipEventRecord(ev, s));
+        HN_HIP(ctx, hipStreamWaitEvent(side, ev, 0));
+        for (int e = d0; e < d1; ++e) {
+            const int me = n >> e;
+            const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
+            const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
+            ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
+            launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
+        }
+        return HN_OK;
+    };
     for (int d = 0; d < n_enc; ++d) {
         const int m = n >> d;
         const Src st_old{states_in + ctx->state_off[d], 2 * L, L, 1.f};
@@ -456,34 +476,26 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                                               ctx->sig[d], noepi, m, m, batch, s);
         }
         // state = conv_state(cat[out, state_old])                        (architectures.py:248)
-        // Nothing downstream in this iteration reads the new state, so with a side stream the four
-        // conv_state kernels are deferred until the main chain is in the small, latency-bound levels
-        // (see below) and fill the CUs those leave idle.
-        if (side == nullptr) {
+        if (policy == 0) {
             ProfScope ps(ctx, KID_STATE0 + 3 * d, s);
             launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
                                                             noepi, m, m, batch, s);
+        } else if (policy == 2) {
+            int rc = release_states(d, d + 1, side_lane->ev[d]);
+            if (rc != HN_OK) return rc;
         }
         // x = down(out)                                                  (architectures.py:252)
-        ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
-        if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
-        else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
-                                dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
-                                ctx->down[d], m, m);
+        {
+            ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
+            if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
+            else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
+                                    dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
+                                    ctx->down[d], m, m);
+        }
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
-        if (side != nullptr && d == n_enc - 1) {
-            // One release for all four conv_state kernels, after the last down: every skip tensor exists, and
-            // the main chain is entering its small, latency-bound levels, whose idle CUs the side stream
-            // fills.  (An event record costs the main stream a ~6 us bubble, so there is exactly one.)
-            HN_HIP(ctx, hipEventRecord(side_lane->ev[0], s));
-            HN_HIP(ctx, hipStreamWaitEvent(side, side_lane->ev[0], 0));
-            for (int e = 0; e < n_enc; ++e) {
-                const int me = n >> e;
-                const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
-                const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
-                ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
-                launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
-            }
+        if (policy == 1 && d == n_enc - 1) {
+            int rc = release_states(0, n_enc, side_lane->ev[0]);
+            if (rc != HN_OK) return rc;
         }
     }
     if (deep) {
@@ -491,6 +503,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         ProfScope ps(ctx, KID_DEEP, s);
         int rc = launch_deep(ctx, ctx->buf_a[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), states_in + ctx->state_off[d],
                              states_out + ctx->state_off[d], 2 * L, L, ctx->buf_y[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), batch, s);
+        if (rc != HN_OK) return rc;
+    }
+    if (policy == 3) {
+        int rc = release_states(0, n_enc, side_lane->ev[0]);
         if (rc != HN_OK) return rc;
     }
     // bottleneck: decode[depth]                                          (architectures.py:453)
@@ -525,7 +541,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                                         Dst{nullptr, 0, 0}, ctx->dec[0], e, m, m, batch, s);
         }
     }
-    if (side != nullptr) {  // the next iteration's conv_signal reads the new states
+    if (policy != 0) {  // the next iteration's conv_signal reads the new states
         HN_HIP(ctx, hipEventRecord(side_lane->done, side));
         HN_HIP(ctx, hipStreamWaitEvent(s, side_lane->done, 0));
     }

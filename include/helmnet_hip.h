@@ -60,9 +60,12 @@ enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_P
 /* Tuning knobs of hn_step (hn_set_option); none changes a result bit. */
 enum hn_option {
     HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
-    HN_OPT_SIDE_STREAM = 1,  /* 0/1: conv_state kernels on a library side stream (default 1)                     */
+    HN_OPT_SIDE_STREAM = 1,  /* conv_state kernels: 0 in line; on a library side stream released 1 after the last `down`,
+                              * 2 level by level behind conv_signal, 3 behind the fused deep level               */
     HN_OPT_GRAPH = 2,        /* 0/1: replay one captured iteration as a HIP graph instead of ~25 launches (default 1) */
-    HN_OPT_DEEP = 3          /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
+    HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
+    HN_OPT_SPECTRAL_PFA = 4  /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k instead of the dense n x n operator (default 1;
+                              * read by the next hn_set_domain)                                                     */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };

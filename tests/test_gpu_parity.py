@@ -80,7 +80,7 @@ def test_teacher_forced_ops_vs_reference_golden(solver, n, b, g_teacher):
 
 
 # 160 / 208 / 320: widths that are not a multiple of the 64-pixel strip tile (partial tiles, odd tile counts)
-@pytest.mark.parametrize("n,b", [(64, 3), (128, 2), (48, 2), (32, 1), (1024, 1), (160, 2), (208, 1), (320, 1)])
+@pytest.mark.parametrize("n,b", [(64, 3), (128, 2), (48, 2), (32, 1), (1024, 1), (160, 2), (208, 1), (320, 1), (80, 2), (192, 1), (384, 1), (112, 1)])
 def test_ops_vs_oracle_other_sizes(solver, n, b, weights):
     """Sizes without golden vectors: compare with the CPU oracle on the same seeded inputs."""
     ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=77 + n).items()}

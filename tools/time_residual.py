@@ -1,23 +1,21 @@
-"""Diagnostic: the spectral residual timed alone (back-to-back launches) versus inside the solver loop."""
-import os, sys, time
-import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Time get_residual (hn_residual) alone: python tools/time_residual.py [N] [B] [--dense]   (--dense: the O(N^3) operator for non-power-of-two N)"""
+import sys, time, torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from helmnet_amd import IterativeSolver
-from helmnet_amd.phantoms import ring_sos_batch
-s = IterativeSolver.from_exported_weights(); s.freeze(); s.to("cuda:0"); s.set_domain_size(256, source_location=[30, 128])
-B = 32
-sos = torch.from_numpy(ring_sos_batch(256, B, seed=0)).cuda()
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 256
+b = int(args[1]) if len(args) > 1 else 32
+s = IterativeSolver.from_exported_weights(); s.freeze(); s.to("cuda:0")
+s.set_domain_size(n, source_location=[n // 4, n // 2])
+if "--dense" in sys.argv:
+    s._engine = None
+    from helmnet_amd.engine import Engine
+    e = Engine(torch.device("cuda:0")); e.set_option("spectral_pfa", 0); s._engine = e
 eng = s.engine()
-k_sq, wf = s.get_initials(sos)
-src = s._src()
-wf = torch.randn_like(wf) * 1e-3
-for mode in ("alone", "alone-after-heavy"):
-    if mode == "alone-after-heavy":
-        out = s.forward(sos, num_iterations=300, residuals="norms")
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(200):
-        r = eng.residual(wf, k_sq, src)
-    e1.record(); torch.cuda.synchronize()
-    print(mode, "residual (cols+rows) us per call:", e0.elapsed_time(e1) / 200 * 1e3)
+wf = torch.randn(b, 2, n, n, device="cuda:0"); ksq = torch.rand(b, 1, n, n, device="cuda:0") + 0.5
+src = s.source.detach().contiguous()
+for _ in range(5): eng.residual(wf, ksq, src)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(200): eng.residual(wf, ksq, src)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 200
+print(f"N={n} B={b} {'dense' if '--dense' in sys.argv else 'fft'}: {dt * 1e6:.1f} us per residual, {5 * 4 * n * n * b / dt / 1e9:.0f} GB/s compulsory")
