@@ -17,7 +17,7 @@ import torch  # noqa: F401  (must be imported before the library is loaded, see 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhelmnet_hip.so")
 _lib = None
 
-HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2}
+HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2, "celu": 3, "tanh": 4, "gelu": 5, "tanhshrink": 6, "softplus": 7}
 # enum hn_precision / hn_option / hn_counter of include/helmnet_hip.h
 HN_PRECISION = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16x2": 3, "valu": 4}
 HN_OPTION = {"lanes": 0, "side_stream": 1, "graph": 2, "deep": 3, "spectral_pfa": 4}

@@ -61,9 +61,11 @@ struct Packer {
     const float* src;
     std::vector<float>& dst;
     float* dev;
+    int act;
     size_t pos = 0;
     DcW dc(int cin, int cm, int co) {
         DcW w;
+        w.act = act;
         repack_oihw(src + pos, dst.data() + pos, cm, cin, 9);
         w.w1 = dev + pos; pos += (size_t)cm * cin * 9;
         std::memcpy(dst.data() + pos, src + pos, sizeof(float) * cm);
@@ -249,8 +251,8 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     if (features != kFeat || state_ch != kState)
         return fail(ctx, HN_ERR_UNSUPPORTED, "only features=8, state_channels=2 are implemented (got %d, %d)", features, state_ch);
     if (depth < 1 || depth > kMaxDepth) return fail(ctx, HN_ERR_UNSUPPORTED, "depth %d outside [1, %d]", depth, kMaxDepth);
-    if (act_kind != HN_ACT_PRELU && act_kind != HN_ACT_RELU && act_kind != HN_ACT_LEAKYRELU)
-        return fail(ctx, HN_ERR_UNSUPPORTED, "activation kind %d is not implemented (prelu / relu / leakyrelu only)", act_kind);
+    if (act_kind < HN_ACT_PRELU || act_kind > HN_ACT_SOFTPLUS)
+        return fail(ctx, HN_ERR_UNSUPPORTED, "activation kind %d is not implemented (hn_act: prelu .. softplus)", act_kind);
     const size_t want = hn_weight_count(features, depth, state_ch);
     if (n_floats != want) return fail(ctx, HN_ERR_ARG, "weight blob has %zu floats, expected %zu", n_floats, want);
     DeviceGuard guard(ctx);
@@ -260,7 +262,8 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     ctx->wdev = nullptr;
     HN_HIP(ctx, hipMalloc((void**)&ctx->wdev, want * sizeof(float)));
     std::vector<float> packed(want);
-    Packer p{blob, packed, ctx->wdev};
+    Packer p{blob, packed, ctx->wdev, act_kind};
+    ctx->act_kind = act_kind;
     ctx->inc = p.dc(kInCh, kFeat, kFeat);
     for (int d = 0; d < depth; ++d) {
         ctx->sig[d] = p.dc(kFeat + kState, kFeat, kFeat);

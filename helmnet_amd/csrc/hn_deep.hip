@@ -58,10 +58,14 @@ struct DeepW {
     const float *bot1, *bot1_b, *bot_slope, *bot2, *bot2_b;       // bottleneck: [8][3][64] x 2
     const float *up, *up_b;                                       // [8][2][4][64], [8]
     const float *dec1, *dec1_b, *dec_slope, *dec2, *dec2_b;       // decoder: [16][3][64], [8][3][64]
+    int act;                                                      // hn_act
 };
 
-// PReLU as median(x, s x, +-inf) (exactly x or s x), see hn_mfma.hip
-__device__ __forceinline__ float prelu(float x, float slope, float sel) { return __builtin_amdgcn_fmed3f(x, slope * x, sel); }
+// PReLU as median(x, s x, +-inf) (exactly x or s x), see hn_mfma.hip; GEN: the smooth activations (act = w.act)
+template <bool GEN>
+__device__ __forceinline__ float activ(float x, float slope, float sel, int act) {
+    return GEN ? act_general(x, act) : __builtin_amdgcn_fmed3f(x, slope * x, sel);
+}
 
 // Scheduling: hipcc would sink every LDS read and weight load next to its first use (it minimises registers), which
 // exposes one LDS / L2 round trip per MFMA group.  The loops below are explicit software pipelines, pinned with
@@ -244,6 +248,7 @@ __device__ __forceinline__ void zero_fill(float* p, int count, int tid) {  // co
     for (int i = tid; i < count / 4; i += 512) reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+template <bool GEN>
 __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, long x_sb, const float* __restrict__ st_in,
                                                 float* __restrict__ st_out, long st_sb, long st_sc, float* __restrict__ y_out, long y_sb,
                                                 DeepW w) {
@@ -304,8 +309,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float* m = MID + (2 * q) * P32_PLANE + (4 * wave + r) * P32_PITCH + 2 * n;
-            *reinterpret_cast<float2*>(m) = make_float2(prelu(acc[r][0], slope, sel), prelu(acc[r][1], slope, sel));
-            *reinterpret_cast<float2*>(m + P32_PLANE) = make_float2(prelu(acc[r][2], slope, sel), prelu(acc[r][3], slope, sel));
+            *reinterpret_cast<float2*>(m) = make_float2(activ<GEN>(acc[r][0], slope, sel, w.act), activ<GEN>(acc[r][1], slope, sel, w.act));
+            *reinterpret_cast<float2*>(m + P32_PLANE) = make_float2(activ<GEN>(acc[r][2], slope, sel, w.act), activ<GEN>(acc[r][3], slope, sel, w.act));
         }
     }
     __syncthreads();
@@ -339,8 +344,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float* m = X + (4 * wave + r) * P32_PITCH + 2 * n;
-                *reinterpret_cast<float2*>(m) = make_float2(prelu(acc[r][0], slope, sel), prelu(acc[r][1], slope, sel));
-                *reinterpret_cast<float2*>(m + P32_PLANE) = make_float2(prelu(acc[r][2], slope, sel), prelu(acc[r][3], slope, sel));
+                *reinterpret_cast<float2*>(m) = make_float2(activ<GEN>(acc[r][0], slope, sel, w.act), activ<GEN>(acc[r][1], slope, sel, w.act));
+                *reinterpret_cast<float2*>(m + P32_PLANE) = make_float2(activ<GEN>(acc[r][2], slope, sel, w.act), activ<GEN>(acc[r][3], slope, sel, w.act));
             }
         }
     }
@@ -387,8 +392,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
         cv_bot.run(acc, X4, P16_PITCH, P16_PLANE, wave, lane);
         cv_bot.prefetch(w.bot2, lane);
         float* m = MID4 + (2 * q) * P16_PLANE + (2 * wave + (n >> 3)) * P16_PITCH + 2 * (n & 7);
-        *reinterpret_cast<float2*>(m) = make_float2(prelu(acc[0], slope, sel), prelu(acc[1], slope, sel));
-        *reinterpret_cast<float2*>(m + P16_PLANE) = make_float2(prelu(acc[2], slope, sel), prelu(acc[3], slope, sel));
+        *reinterpret_cast<float2*>(m) = make_float2(activ<GEN>(acc[0], slope, sel, w.act), activ<GEN>(acc[1], slope, sel, w.act));
+        *reinterpret_cast<float2*>(m + P16_PLANE) = make_float2(activ<GEN>(acc[2], slope, sel, w.act), activ<GEN>(acc[3], slope, sel, w.act));
     }
     __syncthreads();
     const int px = wave & 1, i0 = wave >> 1;   // stage 8: output-column parity and first window row of this wave
@@ -440,8 +445,8 @@ __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float* m = MID + (2 * q) * P32_PLANE + (4 * wave + r) * P32_PITCH + 2 * n;
-            *reinterpret_cast<float2*>(m) = make_float2(prelu(acc[r][0], slope, sel), prelu(acc[r][1], slope, sel));
-            *reinterpret_cast<float2*>(m + P32_PLANE) = make_float2(prelu(acc[r][2], slope, sel), prelu(acc[r][3], slope, sel));
+            *reinterpret_cast<float2*>(m) = make_float2(activ<GEN>(acc[r][0], slope, sel, w.act), activ<GEN>(acc[r][1], slope, sel, w.act));
+            *reinterpret_cast<float2*>(m + P32_PLANE) = make_float2(activ<GEN>(acc[r][2], slope, sel, w.act), activ<GEN>(acc[r][3], slope, sel, w.act));
         }
     }
     __syncthreads();
@@ -487,11 +492,16 @@ int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, f
     w.bot1 = ctx->f_dec[d + 1][0]; w.bot1_b = ctx->dec[d + 1].b1; w.bot_slope = ctx->dec[d + 1].slope; w.bot2 = ctx->f_dec[d + 1][1]; w.bot2_b = ctx->dec[d + 1].b2;
     w.up = ctx->f_up[d]; w.up_b = ctx->up[d].b;
     w.dec1 = ctx->f_dec[d][0]; w.dec1_b = ctx->dec[d].b1; w.dec_slope = ctx->dec[d].slope; w.dec2 = ctx->f_dec[d][1]; w.dec2_b = ctx->dec[d].b2;
+    w.act = ctx->act_kind;
     if (!ctx->deep_attr_set) {   // 135.6 KB of dynamic LDS: above the default limit of a launch
-        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_deep32), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * (int)sizeof(float)));
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_deep32<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * (int)sizeof(float)));
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_deep32<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_FLOATS * (int)sizeof(float)));
         ctx->deep_attr_set = true;
     }
-    hipLaunchKernelGGL(k_deep32, dim3(batch), dim3(512), LDS_FLOATS * sizeof(float), s, x_in, x_sb, st_in, st_out, st_sb, st_sc, y_out, y_sb, w);
+    if (w.act > HN_ACT_LEAKYRELU)
+        hipLaunchKernelGGL(k_deep32<true>, dim3(batch), dim3(512), LDS_FLOATS * sizeof(float), s, x_in, x_sb, st_in, st_out, st_sb, st_sc, y_out, y_sb, w);
+    else
+        hipLaunchKernelGGL(k_deep32<false>, dim3(batch), dim3(512), LDS_FLOATS * sizeof(float), s, x_in, x_sb, st_in, st_out, st_sb, st_sc, y_out, y_sb, w);
     return HN_OK;
 }
 

@@ -38,7 +38,22 @@ struct DcW {
     const float* slope;
     const float* w2;
     const float* b2;
+    int act;   // hn_act
 };
+
+// The reference's smooth activations (architectures.py:22-39: nn.CELU(), nn.Tanh(), nn.GELU(), nn.Tanhshrink(),
+// nn.Softplus() with their default arguments), evaluated in fp32.  Kernels carry them as a separate template
+// instance (GEN): the piecewise-linear instances used by the shipped checkpoint do not change by one instruction.
+__device__ __forceinline__ float act_general(float x, int act) {
+    switch (act) {
+        case HN_ACT_CELU: return fmaxf(x, 0.f) + fminf(0.f, expm1f(x));
+        case HN_ACT_TANH: return tanhf(x);
+        case HN_ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+        case HN_ACT_TANHSHRINK: return x - tanhf(x);
+        case HN_ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+        default: return x;
+    }
+}
 // 8x8 stride-2 conv / transposed conv weights re-packed [cin][8][8][cout], bias [cout].
 struct K8W {
     const float* w;
@@ -73,6 +88,7 @@ struct hn_ctx {
     // network
     bool have_weights = false;
     int depth = 0;
+    int act_kind = HN_ACT_PRELU;
     float* wdev = nullptr;  // all re-packed weights
     hn::DcW inc{}, sig[hn::kMaxDepth]{}, st[hn::kMaxDepth]{}, dec[hn::kMaxDepth + 1]{};
     hn::K8W down[hn::kMaxDepth]{}, up[hn::kMaxDepth]{};

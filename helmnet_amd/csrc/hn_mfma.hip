@@ -91,6 +91,7 @@ struct McW {
     const void* a2s;  // split-bf16 conv2 fragments [1][3][3][64] x 8 bf16
     const void* a1h;  // fp16 conv1 fragments [groups][3 dy][64 lanes] x 8 half (mixed-precision mode)
     const void* a2h;
+    int act;          // hn_act; kinds > HN_ACT_LEAKYRELU run the GEN template instances
 };
 struct McEpi {
     const float* ow;  // outc weight [8][2]
@@ -99,7 +100,7 @@ struct McEpi {
     float* wf;
 };
 
-template <int CA, int CB, int CC, int TW, int EPI>
+template <int CA, int CB, int CC, int TW, int EPI, bool GEN = false>
 __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
     using C = McCfg<CA, CB, CC, TW>;
     // one array: the staged input (2 buffers x 2 channels) is dead once conv1 is done, the mid
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
                 const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
                 float v[4] = {acc1[gi][0] + bias0, acc1[gi][1] + bias0, acc1[gi][2] + bias1, acc1[gi][3] + bias1};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : slope * v[r];  // PReLU (architectures.py:32-33)
+                for (int r = 0; r < 4; ++r) v[r] = GEN ? act_general(v[r], w.act) : (v[r] > 0.f ? v[r] : slope * v[r]);  // PReLU (architectures.py:32-33)
                 // conv2 zero-pads the MID tensor: outside the image it is zero, not conv1's value
                 float* m0 = lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
                 *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
@@ -350,8 +351,8 @@ struct ScCfg {
     static constexpr bool SCALED = CC > 0;         // only the 3-source input layer carries a staging scale (1e3 * residual)
 };
 
-template <int CA, int CB, int CC, int EPI>
-__global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
+template <int CA, int CB, int CC, int EPI, bool GEN = false>
+__global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W) {
     using C = ScCfg<CA, CB, CC>;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -487,6 +488,11 @@ __global__ __launch_bounds__(256, 4) void k_dc_mfma_s(Src sa, Src sb, Src sc, Ds
         const float sel = slope <= 1.f ? __builtin_inff() : -__builtin_inff();
         auto put = [&](const f32x4& a, int mrow, int pc, f32x2 mk, f32x2 sk) {
             float2* m = reinterpret_cast<float2*>(lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc);
+            if (GEN) {   // smooth activations: f(x) first, then the padding mask (f(0) need not be 0)
+                m[0] = make_float2(mk[0] * act_general(a[0], w.act), mk[1] * act_general(a[1], w.act));
+                m[C::MPLANE / 2] = make_float2(mk[0] * act_general(a[2], w.act), mk[1] * act_general(a[3], w.act));
+                return;
+            }
             const f32x2 lo = (f32x2){a[0], a[1]}, hi = (f32x2){a[2], a[3]};
             const f32x2 lm = lo * mk, ls = lo * sk, hm = hi * mk, hs = hi * sk;  // v_pk_mul_f32
             m[0] = make_float2(__builtin_amdgcn_fmed3f(lm[0], ls[0], sel), __builtin_amdgcn_fmed3f(lm[1], ls[1], sel));
@@ -1015,7 +1021,7 @@ struct PcCfg {
     static constexpr int LDS_FLOATS = AF_OFF + (CIN * 3 + kFeat * 3 + 6) * 64 + 8;  // +6: fragments are read one channel pair ahead
 };
 
-template <int CA, int CB, int CC, int EPI, int TH_, int TW_>
+template <int CA, int CB, int CC, int EPI, int TH_, int TW_, bool GEN = false>
 __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst out, McW w, McEpi epi, int H, int W,
                                                     int tiles_x, int tiles_y, int ntiles) {
     using C = PcCfg<CA, CB, CC, TH_, TW_>;
@@ -1176,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
                 const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
                 float v[4] = {acc1[gi][0] + bm0, acc1[gi][1] + bm0, acc1[gi][2] + bm1, acc1[gi][3] + bm1};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : slope * v[r];
+                for (int r = 0; r < 4; ++r) v[r] = GEN ? act_general(v[r], w.act) : (v[r] > 0.f ? v[r] : slope * v[r]);
                 float* m0 = lds + C::MID_OFF + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
                 *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
                 *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
@@ -1772,6 +1778,24 @@ void launch_dc_mfma(int x16, Src a, Src b, Src c, Dst out, const McW& w, const M
     const bool even = (W & 1) == 0;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;  // the strip kernel addresses a sample's planes with 32-bit byte offsets
+    if (w.act > HN_ACT_LEAKYRELU) {   // smooth activations: fp32 instances with the general epilogue (every precision mode)
+        if (W >= 128 && even && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
+            hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI, true>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        } else if (even && W > 16) {
+            const int tx = cdiv_(W, 32), ty = cdiv_(H, 8), nt = tx * ty * batch;
+            hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 32, true>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+        } else if (even) {
+            const int tx = cdiv_(W, 16), ty = cdiv_(H, 8), nt = tx * ty * batch;
+            hipLaunchKernelGGL((k_dc_mfma_p<CA, CB, CC, EPI, 8, 16, true>), dim3(nt), dim3(256), 0, s, a, b, c, out, w, e, H, W, tx, ty, nt);
+        } else if (W > 32) {
+            hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 64, EPI, true>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        } else if (W > 16) {
+            hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 32, EPI, true>), dim3(1, cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        } else {
+            hipLaunchKernelGGL((k_dc_mfma<CA, CB, CC, 16, EPI, true>), dim3(1, cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
+        }
+        return;
+    }
     if (x16 && W >= 128 && even && off32 && w.a1s != nullptr && (!scaled || B3Cfg<CA, CB, CC, 3>::SCALED)) {
         if (x16 == 1) {   // the 3-part split in 8-row tiles (65 KB per 16-row tile -> 39 KB, 3 blocks per CU: +4 % it/s)
             const dim3 g8(cdiv_(W, 64), cdiv_(H, 8), batch);
@@ -1939,7 +1963,7 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
     // hn_load_weights stores the split-bf16 fragments right behind the fp32 ones
     const float* s1 = frag1 + (size_t)cin * 3 * 64;      // split-bf16 twin, then the fp16 twin
     const float* s2 = frag2 + (size_t)kFeat * 3 * 64;
-    const McW mw{frag1, w.b1, w.slope, frag2, w.b2, s1, s2, s1 + frag_3x3_split_floats(cin), s2 + frag_3x3_split_floats(kFeat)};
+    const McW mw{frag1, w.b1, w.slope, frag2, w.b2, s1, s2, s1 + frag_3x3_split_floats(cin), s2 + frag_3x3_split_floats(kFeat), w.act};
     const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf};
     const int x16 = (ctx->precision >= HN_PREC_BF16X3 && ctx->precision <= HN_PREC_BF16X2) ? ctx->precision : 0;
     switch (kind) {

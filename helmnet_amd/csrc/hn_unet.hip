@@ -68,7 +68,7 @@ __device__ __forceinline__ void conv3x3_channel(const float* __restrict__ t, con
     }
 }
 
-template <int CA, int CB, int CC, int CM, int CO, int TW, int EPI>
+template <int CA, int CB, int CC, int CM, int CO, int TW, int EPI, bool GEN = false>
 __global__ __launch_bounds__((DcCfg<CA, CB, CC, CM, CO, TW>::NT)) void k_double_conv(
     Src sa, Src sb, Src sc, Dst out, DcW w, DcEpi epi, int H, int W) {
     using C = DcCfg<CA, CB, CC, CM, CO, TW>;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__((DcCfg<CA, CB, CC, CM, CO, TW>::NT)) void k_double_
             for (int p = 0; p < 4; ++p) {
                 const int x = x0 - 1 + 4 * s1 + p;
                 float v = acc1[p][m] + bias;
-                v = v > 0.f ? v : slope * v;  // PReLU, one scalar slope (architectures.py:32-33)
+                v = GEN ? act_general(v, w.act) : (v > 0.f ? v : slope * v);  // PReLU, one scalar slope (architectures.py:32-33)
                 // conv2 zero-pads the MID tensor: positions outside the image are zero, not conv1 values
                 op[p] = (yin && x >= 0 && x < W) ? v : 0.f;
             }
@@ -230,7 +230,8 @@ template <int CA, int CB, int CC, int CM, int CO, int TW, int EPI>
 void launch_dc_tw(Src a, Src b, Src c, Dst out, const DcW& w, const DcEpi& e, int H, int W, int batch, hipStream_t s) {
     using C = DcCfg<CA, CB, CC, CM, CO, TW>;
     dim3 grid(cdiv(W, TW), cdiv(H, C::TH), batch);
-    hipLaunchKernelGGL((k_double_conv<CA, CB, CC, CM, CO, TW, EPI>), grid, dim3(C::NT), 0, s, a, b, c, out, w, e, H, W);
+    if (w.act > HN_ACT_LEAKYRELU) hipLaunchKernelGGL((k_double_conv<CA, CB, CC, CM, CO, TW, EPI, true>), grid, dim3(C::NT), 0, s, a, b, c, out, w, e, H, W);
+    else hipLaunchKernelGGL((k_double_conv<CA, CB, CC, CM, CO, TW, EPI>), grid, dim3(C::NT), 0, s, a, b, c, out, w, e, H, W);
 }
 template <int CA, int CB, int CC, int CM, int CO, int EPI>
 void launch_dc(Src a, Src b, Src c, Dst out, const DcW& w, const DcEpi& e, int H, int W, int batch, hipStream_t s) {

@@ -37,7 +37,7 @@ def pack_weights(state: dict, depth: int = 4, activation: str = "prelu") -> np.n
     """Flatten a HybridNet state_dict (tensors or arrays) into the fp32 blob of hn_load_weights.
     Parameter-free activations (relu / leakyrelu) get their constant slope written where the
     PReLU weight would be, so the blob layout never changes."""
-    const_slope = {"relu": 0.0, "leakyrelu": 0.01}
+    const_slope = {"relu": 0.0, "leakyrelu": 0.01, "celu": 0.0, "tanh": 0.0, "gelu": 0.0, "tanhshrink": 0.0, "softplus": 0.0}
     parts = []
     for name in weight_names(depth):
         if name.endswith(".double_conv.1.weight") and name not in state:
@@ -93,7 +93,7 @@ class Engine:
     def load_weights(self, blob: np.ndarray, features: int, depth: int, state_channels: int, activation: str):
         act = _lib.HN_ACT.get(activation.lower())
         if act is None:
-            raise NotImplementedError(f"Unknown activation function {activation} (HIP kernels: prelu, relu, leakyrelu)")
+            raise NotImplementedError(f"Unknown activation function {activation} (HIP kernels: {sorted(_lib.HN_ACT)})")
         blob = np.ascontiguousarray(blob, dtype=np.float32)
         rc = self.lib.hn_load_weights(self.ctx, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), blob.size,
                                       features, depth, state_channels, act)

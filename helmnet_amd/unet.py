@@ -20,13 +20,13 @@ import torch.nn as nn
 
 from .engine import Engine, pack_weights
 
-_PIECEWISE_LINEAR = ("prelu", "relu", "leakyrelu")
+_IMPLEMENTED = ("prelu", "relu", "leakyrelu", "celu", "tanh", "gelu", "tanhshrink", "softplus")
 
 
 def getActivationFunction(act_function_name: str, features=None, end=False) -> nn.Module:
-    """architectures.py:5-44.  The HIP kernels implement the piecewise-linear activations
-    (the shipped checkpoint uses 'prelu'); anything else raises NotImplementedError, as the
-    reference does for unknown names."""
+    """architectures.py:5-44: every name the reference knows except 'relu_batchnorm' (BatchNorm2d parameters and
+    running statistics are not part of the kernels' weight blob); unknown names raise NotImplementedError as in
+    the reference.  The returned modules are parameter containers / markers only (see module docstring)."""
     name = act_function_name.lower()
     if name == "prelu":
         return nn.PReLU()
@@ -34,7 +34,17 @@ def getActivationFunction(act_function_name: str, features=None, end=False) -> n
         return nn.ReLU(inplace=True)
     if name == "leakyrelu":
         return nn.LeakyReLU(inplace=True)
-    raise NotImplementedError("Unknown activation function {} (implemented: {})".format(act_function_name, _PIECEWISE_LINEAR))
+    if name == "celu":
+        return nn.CELU(inplace=True)
+    if name == "tanh":
+        return nn.Tanh()
+    if name == "gelu":
+        return nn.GELU()
+    if name == "tanhshrink":
+        return nn.Tanhshrink()
+    if name == "softplus":
+        return nn.Softplus()
+    raise NotImplementedError("Unknown activation function {} (implemented: {})".format(act_function_name, _IMPLEMENTED))
 
 
 class _ContainerOnly(nn.Module):

@@ -43,10 +43,14 @@ enum hn_status {
     HN_ERR_NOMEM = -5
 };
 
-/* activation kinds accepted by hn_load_weights (architectures.py:5-44 getActivationFunction).
- * Only piecewise-linear ones are implemented; everything else returns HN_ERR_UNSUPPORTED,
- * mirroring the reference's NotImplementedError for unknown names. */
-enum hn_act { HN_ACT_PRELU = 0, HN_ACT_RELU = 1, HN_ACT_LEAKYRELU = 2 };
+/* activation kinds accepted by hn_load_weights (architectures.py:5-44 getActivationFunction): every name the
+ * reference knows except 'relu_batchnorm' (it carries BatchNorm2d parameters and running statistics in the
+ * state_dict); an unknown kind returns HN_ERR_UNSUPPORTED, mirroring the reference's NotImplementedError.
+ * The piecewise-linear ones (0..2) take their slope from the blob (constant for relu / leakyrelu); 3..7 are
+ * evaluated in fp32 in the kernels' epilogues: celu (alpha 1), tanh, gelu (erf form), tanhshrink, softplus
+ * (beta 1, threshold 20). */
+enum hn_act { HN_ACT_PRELU = 0, HN_ACT_RELU = 1, HN_ACT_LEAKYRELU = 2, HN_ACT_CELU = 3, HN_ACT_TANH = 4, HN_ACT_GELU = 5,
+              HN_ACT_TANHSHRINK = 6, HN_ACT_SOFTPLUS = 7 };
 
 /* Arithmetic of the UNet convolutions (hn_set_unet_precision).  Everything in HBM (activations, hidden state,
  * wavefield, residual), the 1x1 out-conv, the wavefield update and the spectral residual are fp32 in every mode.

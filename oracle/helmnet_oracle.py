@@ -219,11 +219,33 @@ def prelu(x: Tensor, a: Tensor) -> Tensor:
     return torch.clamp_min(x, 0) + a * torch.clamp_max(x, 0)
 
 
-def double_conv(x: Tensor, w: Dict[str, Tensor], prefix: str) -> Tensor:
-    """helmnet/architectures.py:63-84: conv3x3(pad 1) -> PReLU -> conv3x3(pad 1)."""
+def activation(h: Tensor, name: str, slope: Optional[Tensor]) -> Tensor:
+    """helmnet/architectures.py:5-44 (getActivationFunction), default arguments of the torch modules it returns."""
+    name = name.lower()
+    if name == "prelu":
+        return prelu(h, slope)
+    if name == "relu":
+        return torch.clamp_min(h, 0)
+    if name == "leakyrelu":
+        return torch.clamp_min(h, 0) + 0.01 * torch.clamp_max(h, 0)
+    if name == "celu":
+        return torch.clamp_min(h, 0) + torch.clamp_max(torch.expm1(h), 0)
+    if name == "tanh":
+        return torch.tanh(h)
+    if name == "gelu":
+        return 0.5 * h * (1.0 + torch.erf(h * 0.7071067811865476))
+    if name == "tanhshrink":
+        return h - torch.tanh(h)
+    if name == "softplus":
+        return torch.where(h > 20, h, torch.log1p(torch.exp(h)))
+    raise NotImplementedError(name)
+
+
+def double_conv(x: Tensor, w: Dict[str, Tensor], prefix: str, act: str = "prelu") -> Tensor:
+    """helmnet/architectures.py:63-84: conv3x3(pad 1) -> activation -> conv3x3(pad 1)."""
     p = prefix + ".double_conv."
     h = F.conv2d(x, w[p + "0.weight"], w[p + "0.bias"], padding=1)
-    h = prelu(h, w[p + "1.weight"])
+    h = activation(h, act, w.get(p + "1.weight"))
     return F.conv2d(h, w[p + "2.weight"], w[p + "2.bias"], padding=1)
 
 
@@ -246,20 +268,20 @@ def unflatten_states(flat: Tensor, n: int, depth: int) -> List[Tensor]:
     return out
 
 
-def unet_forward(x6: Tensor, states: List[Tensor], w: Dict[str, Tensor], depth: int = 4) -> Tuple[Tensor, List[Tensor]]:
+def unet_forward(x6: Tensor, states: List[Tensor], w: Dict[str, Tensor], depth: int = 4, act: str = "prelu") -> Tuple[Tensor, List[Tensor]]:
     """helmnet/architectures.py:439-465 (HybridNet.forward) with
     EncoderBlock.forward (:240-252) inlined.  Returns (d, new_states)."""
-    x = double_conv(x6, w, "inc")
+    x = double_conv(x6, w, "inc", act)
     skips, new_states = [], []
     for d in range(depth):
-        out = double_conv(torch.cat([x, states[d]], 1), w, f"enc.{d}.conv_signal")
-        new_states.append(double_conv(torch.cat([out, states[d]], 1), w, f"enc.{d}.conv_state"))
+        out = double_conv(torch.cat([x, states[d]], 1), w, f"enc.{d}.conv_signal", act)
+        new_states.append(double_conv(torch.cat([out, states[d]], 1), w, f"enc.{d}.conv_state", act))
         skips.append(out)
         x = F.conv2d(out, w[f"enc.{d}.down.weight"], w[f"enc.{d}.down.bias"], stride=2, padding=3)
-    x = double_conv(x, w, f"decode.{depth}")
+    x = double_conv(x, w, f"decode.{depth}", act)
     for d in range(depth - 1, -1, -1):
         x = F.conv_transpose2d(x, w[f"up.{d}.weight"], w[f"up.{d}.bias"], stride=2, padding=3)
-        x = double_conv(torch.cat([x, skips[d]], 1), w, f"decode.{d}")
+        x = double_conv(torch.cat([x, skips[d]], 1), w, f"decode.{d}", act)
     return F.conv2d(x, w["outc.conv.weight"], w["outc.conv.bias"]), new_states
 
 

@@ -328,7 +328,9 @@ def test_mixed_fp16_unet_configuration():
 def test_error_behaviour(solver):
     from helmnet_amd import HybridNet, IterativeSolver
     with pytest.raises(NotImplementedError):
-        HybridNet("tanh", 4, 64, 8, 6, 2, 4)
+        HybridNet("relu_batchnorm", 4, 64, 8, 6, 2, 4)   # BatchNorm statistics are not part of the kernels' weight blob
+    with pytest.raises(NotImplementedError):
+        HybridNet("swish", 4, 64, 8, 6, 2, 4)            # unknown to the reference as well (architectures.py:42-44)
     net = HybridNet("prelu", 4, 64, 8, 6, 2, 4).to(DEV)
     with pytest.raises(ValueError):  # state unset (architectures.py:242-245)
         net(torch.zeros(1, 6, 64, 64, device=DEV))

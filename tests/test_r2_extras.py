@@ -63,16 +63,15 @@ def test_smoothed_source_vs_reference_fixture(g_r2):
     assert (sharp - torch.from_numpy(g_r2["smooth96"])).abs().max().item() > 1.0
 
 
-@pytest.mark.parametrize("act,slope", [("relu", 0.0), ("leakyrelu", 0.01)])
-def test_oracle_parameter_free_activations_vs_reference_fixture(g_r2, weights, act, slope):
-    """architectures.py:20-21,40-41: nn.ReLU / nn.LeakyReLU(0.01) == the PReLU formula with a constant slope."""
-    w = dict(weights)
-    for k in list(w):
-        if k.endswith("double_conv.1.weight"):
-            w[k] = torch.tensor([slope])
+ACTS = ["relu", "leakyrelu", "celu", "tanh", "gelu", "tanhshrink", "softplus"]
+
+
+@pytest.mark.parametrize("act", ACTS)
+def test_oracle_parameter_free_activations_vs_reference_fixture(g_r2, weights, act):
+    """architectures.py:20-41: the oracle's activation() against the reference network built with each name."""
     ti = teacher_inputs(64, 2, seed=4242)
     x = torch.from_numpy(g_r2["act_input"])
-    d, st = O.unet_forward(x, O.unflatten_states(torch.from_numpy(ti["states"]), 64, 4), w)
+    d, st = O.unet_forward(x, O.unflatten_states(torch.from_numpy(ti["states"]), 64, 4), weights, act=act)
     assert (d - torch.from_numpy(g_r2[f"{act}_d"])).abs().max().item() <= 1e-5 * np.abs(g_r2[f"{act}_d"]).max()
     assert (O.flatten_states(st) - torch.from_numpy(g_r2[f"{act}_states"])).abs().max().item() <= 1e-5 * np.abs(g_r2[f"{act}_states"]).max()
 
@@ -101,7 +100,7 @@ def test_empty_shard_raises_instead_of_hanging():
 
 # ---------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-@pytest.mark.parametrize("act", ["relu", "leakyrelu"])
+@pytest.mark.parametrize("act", ACTS)
 def test_gpu_parameter_free_activations_vs_reference_fixture(g_r2, weights, act):
     from helmnet_amd import HybridNet
     net = HybridNet(act, 4, 64, 8, 6, 2, 4)
@@ -113,6 +112,24 @@ def test_gpu_parameter_free_activations_vs_reference_fixture(g_r2, weights, act)
     d = net(torch.from_numpy(g_r2["act_input"]).to(DEV)).cpu().numpy()
     assert np.abs(d - g_r2[f"{act}_d"]).max() <= 1e-5 * np.abs(g_r2[f"{act}_d"]).max()
     assert np.abs(net.get_states(flatten=True).cpu().numpy() - g_r2[f"{act}_states"]).max() <= 1e-5 * np.abs(g_r2[f"{act}_states"]).max()
+
+
+@pytest.mark.gpu
+def test_gpu_smooth_activation_at_256_strip_and_deep_kernels(g_r2, weights):
+    """tanh at 256^2: the GEN instances of the strip DoubleConv kernels and of the fused deep-level kernel."""
+    from helmnet_amd import HybridNet
+    net = HybridNet("tanh", 4, 256, 8, 6, 2, 4)
+    net.load_state_dict(weights, strict=False)
+    net.to(DEV)
+    ti = teacher_inputs(256, 1, seed=4343)
+    from helmnet_amd.laplacian import FastLaplacianWithPML
+    sx, sy = FastLaplacianWithPML(domain_size=256, PMLsize=8, k=1.0, sigma_max=2.0).sigmas()
+    x = torch.cat([torch.from_numpy(ti["wf"]), 1e3 * torch.from_numpy(ti["res"]), torch.stack([sx, sy]).float().unsqueeze(0)], 1)
+    net.set_states(torch.from_numpy(ti["states"]).to(DEV), flatten=True)
+    d = net(x.to(DEV)).cpu().numpy()
+    assert np.abs(d[:, :, 3::7, 5::11] - g_r2["tanh256_d"]).max() <= 1e-5 * float(g_r2["tanh256_d_absmax"])
+    st = net.get_states(flatten=True).cpu().numpy()[:, :, 1::37]
+    assert np.abs(st - g_r2["tanh256_states"]).max() <= 1e-5 * np.abs(g_r2["tanh256_states"]).max()
 
 
 @pytest.mark.gpu
