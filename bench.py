@@ -190,7 +190,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=1, help="hn_step pipeline lanes (sub-batches on parallel streams)")
     ap.add_argument("--precision", "--unet-impl", dest="precision", default="fp32", choices=sorted(PEAK_TFLOPS),
                     help="UNet arithmetic of the HEADLINE run; the reported metric is fp32 (the reference's arithmetic)")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured iteration")
+    ap.add_argument("--graph", type=int, default=0, metavar="N",
+                    help="replay captured iterations as HIP graphs (1: one iteration per graph, even N: N per graph); default 0 = launch "
+                         "every kernel, which measures ~4 %% faster (tools/graph_ab.py)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning knob for A/B runs (hn_set_option): deep=0, side_stream=0, ...")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -226,16 +228,16 @@ def main():
     solver.set_unet_precision(prec)
     eng, sos_np, (wf, res, st, k_sq, src) = make_problem(solver, n, B, loc, rank, dev, rank == 0)   # each rank: its own shard of maps
     eng.set_option("lanes", args.lanes)
-    eng.set_option("graph", 0 if args.no_graph else 1)
+    eng.set_option("graph", args.graph)
     for kv in args.opt:
         name, value = kv.split("=")
         eng.set_option(name, int(value))
     rmse = torch.zeros(max(K, W, 8), B, device=dev)
 
-    # warm-up, W untimed steps (at least 7): all but the last 4 with every kernel bracketed by events to find the
-    # dominant one (>= 3 passes: the first launch of a kernel is not representative), the last 4 as the timed region
-    # will run them
-    W1 = max(W - 4, 3)
+    # warm-up, W untimed steps (at least 11): all but the last 8 with every kernel bracketed by events to find the
+    # dominant one (>= 3 passes: the first launch of a kernel is not representative), the last 8 as the timed region
+    # will run them (graph replays)
+    W1 = max(W - 8, 3)
     eng.profile_enable(None)
     eng.step(wf, res, st, k_sq, src, W1, rmse_hist=rmse[:W1])
     torch.cuda.synchronize()
@@ -246,10 +248,10 @@ def main():
     eng.profile_enable([])
     # everything the timed region touches runs once before it: the captured iteration (graph instantiation), the
     # first reduction / collective of the process (code-object loads cost milliseconds on first use)
-    eng.step(wf, res, st, k_sq, src, 4, rmse_hist=rmse[:4])
+    eng.step(wf, res, st, k_sq, src, 8, rmse_hist=rmse[:8])   # the first replays of a freshly instantiated graph are slow
     allreduce_residual_norms(rmse[0], op="max")
     eng.profile_enable([dom_id])
-    cap = 8 if K >= 64 else 4                         # at most 8 (short runs: 4) bracketed launches in the timed region: a bracket costs
+    cap = 8 if K >= 64 else 2                         # at most 8 (short runs: 4) bracketed launches in the timed region: a bracket costs
     stride = max(1, -(-K // cap))                     # ~6 us of stream gap and runs its iteration kernel by kernel instead of as a graph replay
     eng.profile_stride(stride)
     replays0, eager0 = eng.counter("graph_replays"), eng.counter("eager_iterations")

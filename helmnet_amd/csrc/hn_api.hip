@@ -161,7 +161,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     if (const char* v = getenv("HN_STREAMS")) { const int n = atoi(v); c->opt_lanes = n < 1 ? 1 : n > 8 ? 8 : n; }
     if (const char* v = getenv("HN_SIDE_STREAM")) { const int n = atoi(v); c->opt_side_stream = n < 0 ? 0 : n > 3 ? 3 : n; }
-    if (const char* v = getenv("HN_GRAPH")) c->opt_graph = atoi(v) != 0;
+    if (const char* v = getenv("HN_GRAPH")) { const int n = atoi(v); c->opt_graph = n < 0 ? 0 : n > 64 ? 64 : n; }
     if (const char* v = getenv("HN_DEEP")) c->opt_deep = atoi(v) != 0;
     *out = c;
     return HN_OK;
@@ -189,9 +189,14 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             if (value < 0 || value > 3) return fail(ctx, HN_ERR_ARG, "HN_OPT_SIDE_STREAM must be in [0, 3] (got %d)", value);
             ctx->opt_side_stream = value;
             break;
-        case HN_OPT_GRAPH: ctx->opt_graph = value != 0; break;
+        case HN_OPT_GRAPH:
+            if (value < 0 || value > 64 || (value > 1 && (value & 1)))
+                return fail(ctx, HN_ERR_ARG, "HN_OPT_GRAPH must be 0, 1 or an even number of iterations per graph <= 64 (got %d)", value);
+            ctx->opt_graph = value;
+            break;
         case HN_OPT_DEEP: ctx->opt_deep = value != 0; break;
         case HN_OPT_SPECTRAL_PFA: ctx->opt_pfa = value != 0; break;
+        case HN_OPT_SPECTRAL_RADIX16: ctx->opt_radix16 = value != 0; break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }
     clear_step_graphs(ctx);
@@ -533,7 +538,8 @@ hn_ctx::StepGraph* step_graph(hn_ctx* ctx, const StepArgs& a) {
     ++ctx->graph_clock;
     for (auto& g : ctx->graphs)
         if (g.wf == a.wf && g.res == a.res && g.states == a.states && g.k_sq == a.k_sq && g.src == a.src && g.rmse == a.rmse_hist &&
-            g.src_batch == a.src_batch && g.batch == a.batch && g.precision == ctx->precision && g.side == ctx->opt_side_stream) {
+            g.src_batch == a.src_batch && g.batch == a.batch && g.precision == ctx->precision && g.side == ctx->opt_side_stream &&
+            g.lanes == ctx->opt_graph) {
             g.last_use = ctx->graph_clock;
             return &g;
         }
@@ -541,13 +547,16 @@ hn_ctx::StepGraph* step_graph(hn_ctx* ctx, const StepArgs& a) {
     hn_ctx::StepGraph g;
     g.wf = a.wf; g.res = a.res; g.states = a.states; g.k_sq = a.k_sq; g.src = a.src; g.rmse = a.rmse_hist;
     g.src_batch = a.src_batch; g.batch = a.batch; g.precision = ctx->precision; g.side = ctx->opt_side_stream;
+    g.lanes = ctx->opt_graph;   // iterations per graph (the field doubles as part of the key)
+    const int per_graph = ctx->opt_graph > 1 ? ctx->opt_graph : 1;
     const uint64_t mask = ctx->prof_mask;
     ctx->prof_mask = 0;   // event brackets are host-timed launches: they never go into a captured iteration
     struct Restore { hn_ctx* c; uint64_t m; ~Restore() { c->prof_mask = m; } } restore{ctx, mask};
-    for (int parity = 0; parity < 2; ++parity) {
+    for (int parity = 0; parity < (per_graph > 1 ? 1 : 2); ++parity) {   // several iterations per graph: even count, starts at parity 0
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(ctx->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) { destroy_graph_entry(g); (void)hipGetLastError(); return nullptr; }
-        const int rc = one_iteration(ctx, a, parity, 0, a.batch, 0, ctx->cap_stream, nullptr);
+        int rc = HN_OK;
+        for (int k = 0; k < per_graph && rc == HN_OK; ++k) rc = one_iteration(ctx, a, (parity + k) & 1, 0, a.batch, 0, ctx->cap_stream, nullptr);
         const hipError_t e = hipStreamEndCapture(ctx->cap_stream, &graph);
         if (rc != HN_OK || e != hipSuccess || graph == nullptr ||
             hipGraphInstantiate(&g.exec[parity], graph, nullptr, nullptr, 0) != hipSuccess) {
@@ -557,7 +566,10 @@ hn_ctx::StepGraph* step_graph(hn_ctx* ctx, const StepArgs& a) {
             return nullptr;
         }
         (void)hipGraphDestroy(graph);
+        (void)hipGraphUpload(g.exec[parity], ctx->cap_stream);   // make the first replay as cheap as the later ones
     }
+    (void)hipStreamSynchronize(ctx->cap_stream);
+    (void)hipGetLastError();
     g.last_use = ctx->graph_clock;
     ++ctx->graphs_captured;
     if (ctx->graphs.size() >= 8) {  // least recently used entry makes room
@@ -614,9 +626,17 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool caller_capturing = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
         hn_ctx::StepGraph* g = nullptr;
-        if (ctx->opt_graph && n_iter >= 4 && !caller_capturing) g = step_graph(ctx, a);
+        const int per_graph = ctx->opt_graph > 1 ? ctx->opt_graph : 1;
+        const bool hist = res_hist || wf_hist || st_hist;
+        if (ctx->opt_graph && n_iter >= 4 * per_graph && !caller_capturing && !(per_graph > 1 && (hist || ctx->prof_mask))) g = step_graph(ctx, a);
         for (int it = 0; it < n_iter; ++it) {
-            bool bracket = false;
+            if (g != nullptr && per_graph > 1 && (it & 1) == 0 && it + per_graph <= n_iter) {   // several iterations per replay
+                HN_HIP(ctx, hipGraphLaunch(g->exec[0], s));
+                ctx->graph_replays += per_graph;
+                it += per_graph - 1;
+                continue;
+            }
+            bool bracket = per_graph > 1;
             if (ctx->prof_mask) {
                 for (int id = 0; id < KID_COUNT; ++id)
                     if ((ctx->prof_mask >> id & 1ull) && ctx->prof_seen[id] % ctx->prof_stride == 0) bracket = true;

@@ -103,8 +103,13 @@ struct hn_ctx {
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
     int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
     int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
-    int opt_graph = 1;         // hn_step replays one captured iteration (HIP graph) instead of ~25 launches
+    int opt_graph = 0;         // hn_step replays captured iterations (HIP graph; n > 1: n iterations per graph) instead of launching
+                               // ~25 kernels per iteration.  Off by default: [measured] replay is 4 % SLOWER (586 vs 563 us per
+                               // iteration at 256^2 x 32, graphs of 1, 2 or 8 iterations alike) -- the host keeps ahead of the GPU
+                               // anyway (~100 us of launch calls per 560 us iteration) and the graph's node-to-node dependencies
+                               // cost more than in-order stream launches
     int opt_pfa = 1;           // prime-factor FFT for n = 3 * 2^k, 5 * 2^k (0: dense operator, A/B; takes effect at hn_set_domain)
+    int opt_radix16 = 1;       // 256-point transforms as two register-resident radix-16 passes (0: the radix-4 Stockham kernels)
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]

@@ -342,6 +342,210 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// N = 256 = 16 x 16: two register-resident radix-16 passes with ONE LDS exchange between them.
+//   x[t + 16 k]  --DFT16 over k-->  A_t[q]  --x W_256^(t q)-->  transpose (t <-> q) through LDS  --DFT16 over t-->  X[u + 16 p]
+// Thread u of the 16 threads of a transform ends up with X[u + 16 p], p = 0..15: the spectrum has the layout the input
+// had, so the derivative multipliers and the inverse transform (same structure, conjugate twiddles) follow without any
+// reordering.  A wavefront holds 4 transforms; their 16 threads never leave the wavefront, so an exchange is a
+// wave-level fence, not a workgroup barrier -- for the column pass too.  Against the radix-4 passes above: 2 exchange
+// rounds per line instead of 8, a quarter of the LDS instructions and about half the instructions overall (these
+// kernels are issue-bound: ~150 instructions per element before).
+// ------------------------------------------------------------------------------------------
+// complex numbers as 2-vectors: hipcc maps the arithmetic below onto v_pk_add / v_pk_mul / v_pk_fma_f32 (one instruction
+// per complex add, two per complex multiply; swaps, broadcasts and sign flips ride on the op_sel / neg modifiers)
+typedef float v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2 cmulv(v2 a, v2 b) { return a.xx * b + a.yy * (v2){-b.y, b.x}; }
+__device__ __forceinline__ v2 cmulv_conj(v2 a, v2 b) { return a.xx * (v2){b.x, -b.y} + a.yy * (v2){b.y, b.x}; }   // a * conj(b)
+template <bool INV>
+__device__ __forceinline__ v2 rot(v2 a) { return INV ? (v2){-a.y, a.x} : (v2){a.y, -a.x}; }   // a * (+i | -i)
+
+template <bool INV>
+__device__ __forceinline__ void bfly4(v2& x0, v2& x1, v2& x2, v2& x3) {
+    const v2 a0 = x0 + x2, a1 = x0 - x2, a2 = x1 + x3, r3 = rot<INV>(x1 - x3);
+    x0 = a0 + a2;
+    x1 = a1 + r3;
+    x2 = a0 - a2;
+    x3 = a1 - r3;
+}
+
+// in-register 16-point DFT, X[k] = sum_n x[n] W16^(+-n k): 4 + 4 radix-4 butterflies around the W16^(m q) twiddles
+template <bool INV>
+__device__ __forceinline__ void dft16(v2 (&x)[16]) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, H = 0.70710678118654752f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) bfly4<INV>(x[m], x[m + 4], x[m + 8], x[m + 12]);   // y_q of column m now in x[m + 4 q]
+    // x[m + 4 q] *= W16^(m q), W16^j = (cos, -+sin)(2 pi j / 16)
+    auto tw = [](v2 v, float c, float sn) { return cmulv(v, (v2){c, INV ? sn : -sn}); };
+    x[5] = tw(x[5], C1, S1);        // m q = 1
+    x[9] = tw(x[9], H, H);          // 2
+    x[13] = tw(x[13], S1, C1);      // 3
+    x[6] = tw(x[6], H, H);          // 2
+    x[10] = rot<INV>(x[10]);        // 4
+    x[14] = tw(x[14], -H, H);       // 6
+    x[7] = tw(x[7], S1, C1);        // 3
+    x[11] = tw(x[11], -H, H);       // 6
+    x[15] = tw(x[15], -C1, -S1);    // 9
+    v2 o[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v2 z0 = x[4 * q], z1 = x[4 * q + 1], z2 = x[4 * q + 2], z3 = x[4 * q + 3];
+        bfly4<INV>(z0, z1, z2, z3);
+        o[q] = z0; o[q + 4] = z1; o[q + 8] = z2; o[q + 12] = z3;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = o[k];
+}
+
+// transpose the 16 x 16 values of NB lock-step transforms among the 16 threads of each transform (row pitch 17 float2:
+// stores of one q and loads of one t' are conflict-free); reg = this transform's LDS region, nbs = float2 stride between
+// the lock-step transforms
+template <int NB>
+__device__ __forceinline__ void xchg16(v2 (&v)[NB][16], v2* reg, int nbs, int t) {
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) reg[nb * nbs + q * 17 + t] = v[nb][q];
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[nb][q] = reg[nb * nbs + t * 17 + q];
+}
+
+// Forward transform of one line of 256 and the two derivative spectra: in u[k] = x[t + 16 k]; out d[0] = i k U, d[1] = -k^2 U
+// after the first inverse radix-16 pass and its twiddles, i.e. ready for the inverse exchange.
+__device__ __forceinline__ void axis_forward16(const v2 (&u)[16], v2 (&d)[2][16], v2* reg, int nbs, int t, const SpecPtrs& tab) {
+    v2 w[16];   // W_256^(t q)
+#pragma unroll
+    for (int q = 1; q < 16; ++q) { const float2 f = tab.tw[t * q]; w[q] = (v2){f.x, f.y}; }
+    v2 f[1][16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f[0][k] = u[k];
+    dft16<false>(f[0]);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) f[0][q] = cmulv(f[0][q], w[q]);
+    xchg16<1>(f, reg, nbs, t);
+    dft16<false>(f[0]);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const float k1 = tab.k1[t + 16 * p], k2 = tab.k2[t + 16 * p];
+        const v2 U = f[0][p];
+        d[0][p] = (v2){-U.y, U.x} * k1;   // (0, k) * U     (spectral.py:50, 281)
+        d[1][p] = U * k2;                 // (-k^2, 0) * U  (spectral.py:52, 283)
+    }
+    dft16<true>(d[0]);
+    dft16<true>(d[1]);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) {
+        d[0][q] = cmulv_conj(d[0][q], w[q]);
+        d[1][q] = cmulv_conj(d[1][q], w[q]);
+    }
+}
+// ... and the rest: inverse exchange, second inverse pass, PML coefficients: acc[k] = (a du + b ddu)[t + 16 k]
+__device__ __forceinline__ void axis_finish16(v2 (&d)[2][16], v2 (&acc)[16], int t, const SpecPtrs& tab) {
+    dft16<true>(d[0]);
+    dft16<true>(d[1]);
+    constexpr float inv_n = 1.0f / 256.0f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float2 ca = tab.a[t + 16 * k], cb = tab.b[t + 16 * k];
+        acc[k] = (cmulv(d[0][k], (v2){ca.x, ca.y}) + cmulv(d[1][k], (v2){cb.x, cb.y})) * inv_n;
+    }
+}
+
+constexpr int kReg16Rows = 272;   // float2 per transform region: 16 x 17; 544 dwords = 32 (mod 64): the two transforms of a 32-lane group on disjoint banks
+constexpr int kReg16Cols = 280;   // 560 dwords = 48 (mod 64): the four transforms of a 32-lane group (lane = 4 t + c) on disjoint quarters
+
+// column pass at N = 256: workgroup = 16 columns (4 wavefronts x 4 columns), lane = 4 t + c
+__global__ __launch_bounds__(256) void k_spec16_cols(const float* __restrict__ wf, float* __restrict__ out, SpecPtrs tab,
+                                                     int* __restrict__ it_counter) {
+    constexpr int N = 256;
+    __shared__ v2 buf[4 * 4 * 2 * kReg16Cols];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane >> 2, c = lane & 3;
+    if (it_counter != nullptr && (blockIdx.x | blockIdx.y | threadIdx.x) == 0) atomicAdd(it_counter, 1);
+    const int col = blockIdx.x * 16 + wave * 4 + c;
+    const long plane = (long)N * N;
+    const float* pre = wf + (long)blockIdx.y * 2 * plane + col;
+    v2 u[16], d[2][16], acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long o = (long)(t + 16 * k) * N;
+        u[k] = (v2){pre[o], pre[o + plane]};
+    }
+    v2* reg = buf + (wave * 4 + c) * 2 * kReg16Cols;
+    axis_forward16(u, d, reg, kReg16Cols, t, tab);
+    xchg16<2>(d, reg, kReg16Cols, t);
+    axis_finish16(d, acc, t, tab);
+    float* po = out + (long)blockIdx.y * 2 * plane + col;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const long o = (long)(t + 16 * k) * N;
+        po[o] = acc[k].x;
+        po[o + plane] = acc[k].y;
+    }
+}
+
+// row pass at N = 256: workgroup = 16 rows (4 wavefronts x 4 rows), lane = 16 r + t
+__global__ __launch_bounds__(256) void k_spec16_rows(const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
+                                                     const float* __restrict__ src, long src_sb, SpecPtrs tab, int flags,
+                                                     float* __restrict__ sumsq, const int* __restrict__ it_counter, int sumsq_stride) {
+    constexpr int N = 256;
+    __shared__ v2 buf[4 * 4 * 2 * kReg16Rows];
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane & 15, r = lane >> 4;
+    const int row = blockIdx.x * 16 + wave * 4 + r, b = blockIdx.y;
+    const long plane = (long)N * N, ro = (long)row * N;
+    const float* pre = wf + (long)b * 2 * plane + ro;
+    float* po = out + (long)b * 2 * plane + ro;
+    v2 u[16], d[2][16], acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) u[k] = (v2){pre[t + 16 * k], pre[plane + t + 16 * k]};
+    v2* reg = buf + (wave * 4 + r) * 2 * kReg16Rows;
+    axis_forward16(u, d, reg, kReg16Rows, t, tab);
+    xchg16<2>(d, reg, kReg16Rows, t);
+    // the other operands of the row are requested now (the twiddles are dead: registers are free) and arrive while the last
+    // radix-16 pass runs
+    v2 part[16], sv[16];
+    float kq[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int x = t + 16 * k;
+        part[k] = (flags & 1) ? (v2){po[x], po[plane + x]} : (v2){0.f, 0.f};
+        kq[k] = 0.f;
+        sv[k] = (v2){0.f, 0.f};
+        if (flags & 2) {
+            kq[k] = ksq[(long)b * plane + ro + x];
+            const float* ps = src + (long)b * src_sb + ro + x;
+            sv[k] = (v2){ps[0], ps[plane]};
+        }
+    }
+    axis_finish16(d, acc, t, tab);
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int x = t + 16 * k;
+        v2 o = acc[k] + part[k];
+        if (flags & 2) o = o + u[k] * kq[k] - sv[k];
+        po[x] = o.x;
+        po[plane + x] = o.y;
+        ss += o.x * o.x + o.y * o.y;
+    }
+    if (sumsq != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long hist_row = it_counter != nullptr ? (long)(*it_counter - 1) * sumsq_stride : 0;
+            atomicAdd(&sumsq[hist_row + b], red[0] + red[1] + red[2] + red[3]);
+        }
+    }
+}
+
 __global__ void k_bump(int* counter) { atomicAdd(counter, 1); }
 
 // ------------------------------------------------------------------------------------------
@@ -706,7 +910,19 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
             case 32: launch_pow2<32>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             case 64: launch_pow2<64>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             case 128: launch_pow2<128>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
-            case 256: launch_pow2<256>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 256:
+                if (ctx->opt_radix16) {
+                    {
+                        ProfScope ps(ctx, KID_SPEC_COLS, s);
+                        hipLaunchKernelGGL(k_spec16_cols, dim3(16, batch), dim3(256), 0, s, wf, out, p, it_counter);
+                    }
+                    ProfScope ps(ctx, KID_SPEC_ROWS, s);
+                    hipLaunchKernelGGL(k_spec16_rows, dim3(16, batch), dim3(256), 0, s, wf, out, ksq, src, src_sb, p, 1 | (resid ? 2 : 0),
+                                       accum_sumsq, it_counter, sumsq_stride);
+                } else {
+                    launch_pow2<256>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride);
+                }
+                break;
             case 512: launch_pow2<512>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             case 1024: launch_pow2<1024>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             case 2048: launch_pow2<2048>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;

@@ -66,8 +66,10 @@ enum hn_option {
     HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
     HN_OPT_SIDE_STREAM = 1,  /* conv_state kernels: 0 in line; on a library side stream released 1 after the last `down`,
                               * 2 level by level behind conv_signal, 3 behind the fused deep level               */
-    HN_OPT_GRAPH = 2,        /* 0/1: replay one captured iteration as a HIP graph instead of ~25 launches (default 1) */
+    HN_OPT_GRAPH = 2,        /* 0: launch every kernel (default; measured faster); 1: replay one captured iteration per HIP graph
+                              * launch; even n <= 64: n iterations per graph                                          */
     HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
+    HN_OPT_SPECTRAL_RADIX16 = 5, /* 0/1: 256-point lines as two register-resident radix-16 passes (default 1; 0: radix-4 kernels) */
     HN_OPT_SPECTRAL_PFA = 4  /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k instead of the dense n x n operator (default 1;
                               * read by the next hn_set_domain)                                                     */
 };

@@ -393,3 +393,28 @@ def test_fused_deep_level_kernel_matches_the_layer_by_layer_path(weights):
     # level-3 slice of the new hidden state (written by the fused kernel) specifically
     L3 = slice(256 * 256 + 128 * 128 + 64 * 64, None)
     assert (outs[1][2][:, :, L3] - want[2][:, :, L3]).abs().max().item() <= 1e-5 * want[2][:, :, L3].abs().max().item()
+
+
+def test_graph_replay_is_bit_identical_to_kernel_by_kernel_launches(solver):
+    """HN_OPT_GRAPH: one captured iteration per graph, and 4 iterations per graph, against the default launches -- the
+    same kernels with the same arguments in the same order, so every output bit agrees (the RMSE history goes through
+    the device-side iteration counter in all three)."""
+    n, b, K = 128, 3, 21
+    solver.set_domain_size(n, source_location=[20, 64])
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=9)).to(DEV)
+    eng = solver.engine()
+    outs = {}
+    for g in (0, 1, 4):
+        eng.set_option("graph", g)
+        r0, c0 = eng.counter("graph_replays"), eng.counter("graphs_captured")
+        o = solver.forward(sos, num_iterations=K, residuals="norms")
+        outs[g] = (o["wavefields"][0].clone(), o["last_residual"].clone(), o["residual_norms"].clone(), solver.f.get_states(flatten=True).clone())
+        replays = eng.counter("graph_replays") - r0
+        assert replays == (0 if g == 0 else K if g == 1 else 20), (g, replays)
+    eng.set_option("graph", 0)
+    for g in (1, 4):
+        for a, bb in zip(outs[0], outs[g]):
+            if a.dim() == 2:   # per-sample sums are float atomics: not bit-reproducible even between two identical runs
+                assert torch.allclose(a, bb, rtol=1e-5)
+            else:
+                assert torch.equal(a, bb)
