@@ -1,8 +1,9 @@
+# Round-2 evidence: run on the GPU box as  gpurun -- 'bash tools/profile_r2.sh'  (writes gpurun_out/r2/, condensed by tools/summarize_profiles.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r2
-mkdir -p $O
-BENCH="python3 $R/bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-secondary"
+rm -rf $O; mkdir -p $O
+BENCH="python3 $R/bench.py --steps 40 --warmup 12 --no-cpu-baseline --no-secondary"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $BENCH > $O/kt.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- $BENCH > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- $BENCH > /dev/null 2>&1
@@ -12,5 +13,13 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS
 cd $R
 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_k20.json 2> $O/bench_k20.err
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-ls $O $O/kt/*/ | head -30
-du -sh $O
+python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary > $O/bench_k300.json 2>/dev/null
+python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --graph 1 > $O/bench_k300_graph1.json 2>/dev/null
+python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --opt deep=0 > $O/bench_k300_nodeep.json 2>/dev/null
+python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --size 512 --batch 16 > $O/bench_512.json 2>/dev/null
+python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --precision bf16x3 > $O/bench_bf16x3.json 2>/dev/null
+python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --precision fp16 > $O/bench_fp16.json 2>/dev/null
+python tools/graph_ab.py > $O/graph_ab.txt 2>/dev/null
+for a in "96 32" "96 32 --dense" "160 32" "160 32 --dense" "320 16" "320 16 --dense" "256 32"; do python tools/time_residual.py $a 2>/dev/null; done > $O/residual_times.txt
+python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.txt
+du -sh $O; cat $O/pytest_gpu.txt
