@@ -316,8 +316,23 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         };
         dc(kInCh, kFeat, kFeat);
         for (int d = 0; d < depth; ++d) { dc(kFeat + kState, kFeat, kFeat); k8(false); dc(kFeat + kState, kState, kState); }
+        const size_t pos_dec0 = pos;
         for (int d = 0; d <= depth; ++d) dc(d < depth ? 2 * kFeat : kFeat, kFeat, kFeat);
         for (int d = 0; d < depth; ++d) k8(true);
+        // final layer: decode[0]'s second convolution composed with the 1x1 out-conv (one linear map, composed in float64)
+        size_t off_comp = 0, off_comp_b = 0;
+        {
+            const float* w2 = blob + pos_dec0 + (size_t)kFeat * 2 * kFeat * 9 + kFeat + 1;   // decode.0.double_conv.2.weight [8][8][3][3]
+            const float* b2 = w2 + (size_t)kFeat * kFeat * 9;
+            const float* wo = blob + want - (2 * kFeat + 2);                                  // outc.conv.weight [2][8], bias [2]
+            const float* bo = wo + 2 * kFeat;
+            off_comp = fr.size();
+            fr.resize(fr.size() + (size_t)kFeat * 5 * 64);
+            pack_frag_outc3x3(w2, b2, wo, bo, fr.data() + off_comp, nullptr);
+            off_comp_b = fr.size();
+            fr.resize(fr.size() + 4);
+            pack_frag_outc3x3(w2, b2, wo, bo, nullptr, fr.data() + off_comp_b);
+        }
         (void)hipFree(ctx->fragdev);
         ctx->fragdev = nullptr;
         HN_HIP(ctx, hipMalloc((void**)&ctx->fragdev, fr.size() * sizeof(float)));
@@ -330,6 +345,8 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         }
         for (int d = 0; d <= depth; ++d) { ctx->f_dec[d][0] = nxt(); ctx->f_dec[d][1] = nxt(); }
         for (int d = 0; d < depth; ++d) ctx->f_up[d] = nxt();
+        ctx->f_dec0c = ctx->fragdev + off_comp;
+        ctx->dec0c_b = ctx->fragdev + off_comp_b;
     }
     if (ctx->have_weights && ctx->depth != depth) free_workspace(ctx);
     ctx->depth = depth;

@@ -96,6 +96,7 @@ struct hn_ctx {
     float* fragdev = nullptr;
     const float *f_inc[2]{}, *f_sig[hn::kMaxDepth][2]{}, *f_dec[hn::kMaxDepth + 1][2]{};
     const float *f_down[hn::kMaxDepth]{}, *f_up[hn::kMaxDepth]{};
+    const float *f_dec0c = nullptr, *dec0c_b = nullptr;   // decode[0] conv2 composed with the out-conv: [8][5][64] row-triple fragments, bias [2]
     const float* f_st[hn::kMaxDepth][2]{};   // conv_state (2 output channels in rows 0..3 of M): [10][3][64], [2][3][64] (hn_deep.hip)
     bool deep_attr_set = false, pfa_attr_set = false;
     // arithmetic of the UNet convolutions (hn_set_unet_precision; default from HN_UNET_IMPL at hn_create only)
@@ -221,6 +222,9 @@ size_t frag_3x3_split_floats(int cin);                          // storage of th
 void pack_frag_3x3_split(const float* w_oihw, int cin, float* dst);  // -> [ceil(cin/8)][3 dy][3 parts][64][8 bf16]
 size_t frag_3x3_half_floats(int cin);
 void pack_frag_3x3_half(const float* w_oihw, int cin, float* dst);   // -> [ceil(cin/8)][3 dy][64][8 half]
+// conv2 [8][8][3][3] (+ bias) composed with the 1x1 out-conv [2][8] (+ bias): fragments [8 cm][5 variants][64] of the row-triple
+// packing (frag != nullptr) and / or the composed bias [2] (bias != nullptr)
+void pack_frag_outc3x3(const float* w2, const float* b2, const float* wo, const float* bo, float* frag, float* bias);
 void pack_frag_down(const float* w_oihw, float* dst);          // -> [8][8][64]
 void pack_frag_up(const float* w_iohw, float* dst);            // -> [8][2][4][64]
 size_t k8_split_floats();

@@ -98,6 +98,8 @@ struct McEpi {
     const float* ob;  // [2]
     float* d_out;
     float* wf;
+    const float* a2c;  // conv2 composed with the 1x1 out-conv, row-triple fragments [8 cm][5][64] (k_dc_mfma_s<.., EPI = 1>)
+    const float* b2c;  // its bias [2]
 };
 
 template <int CA, int CB, int CC, int TW, int EPI, bool GEN = false>
@@ -476,9 +478,15 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    float a2[kFeat * 3];
+    float a2[EPI == 1 ? 1 : kFeat * 3];
+    float a2c[EPI == 1 ? kFeat * 5 : 1];
+    if (EPI == 1) {
 #pragma unroll
-    for (int j = 0; j < kFeat * 3; ++j) a2[j] = w.a2[j * 64 + lane];
+        for (int j = 0; j < kFeat * 5; ++j) a2c[EPI == 1 ? j : 0] = epi.a2c[j * 64 + lane];
+    } else {
+#pragma unroll
+        for (int j = 0; j < kFeat * 3; ++j) a2[EPI == 1 ? 0 : j] = w.a2[j * 64 + lane];
+    }
     __syncthreads();  // staged input is dead: the mid tensor takes its place
     {
         // PReLU (architectures.py:32-33) as median(x, s x, +-inf): max(x, s x) for s <= 1, min otherwise --
@@ -526,6 +534,73 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
     // ---- conv2: output rows 8*half .. +7, pairs 16*strip + n ----
     const int rb2 = C::NR2 * half;
     const int bs2 = rb2 * C::PM + 2 * (16 * strip + n) + q;
+    if constexpr (EPI == 1) {
+        // Final layer.  conv2 (3x3, 8 -> 8) followed by the 1x1 out-conv (8 -> 2, architectures.py:47-60) is ONE linear
+        // map: d = (W_out W_2) * mid + (W_out b_2 + b_out), a 3x3 convolution with TWO output channels (weights composed
+        // in float64 by hn_load_weights).  Two channels would fill 4 of the 16 rows of M, so M also carries the output ROW
+        // inside a triple: row m = (q: row 3T + q of triple T, channel, dxo).  Staged row r_in = 3T + jj (jj = -1 .. 3)
+        // feeds triple T with the fragment variant jj, whose row group q holds tap ky = jj + 1 - q (zero where no tap
+        // exists): 14 MFMAs per mid channel instead of 24 + the out-conv's, and the accumulators ARE d (no epilogue GEMM).
+        const int ox = x0 + 2 * (16 * strip + n);
+        const int yb = y0 + rb2;
+        const long plane = (long)H * W;
+        const float bre = epi.b2c[0], bim = epi.b2c[1];
+        f32x4 acc[3];
+#pragma unroll
+        for (int T = 0; T < 3; ++T) acc[T] = (f32x4){bre, bre, bim, bim};
+        // this lane's output rows: 3T + q of the wave's 8 (q = 3 and row 8 do not exist)
+        bool rok[3];
+        unsigned roff[3];
+        float2 wf_old[3][2];
+#pragma unroll
+        for (int T = 0; T < 3; ++T) {
+            const int r = 3 * T + q;
+            rok[T] = q < 3 && r < C::NR2 && yb + r < H && ox < W;
+            roff[T] = rok[T] ? 4u * (unsigned)((yb + r) * W + ox) : 0u;
+            if (epi.wf != nullptr) {
+                const char* base = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane);
+                wf_old[T][0] = *reinterpret_cast<const float2*>(base + roff[T]);
+                wf_old[T][1] = *reinterpret_cast<const float2*>(base + 4 * plane + roff[T]);
+            }
+        }
+        float br[2][C::NR2 + 2];
+#pragma unroll
+        for (int j = 0; j < C::NR2 + 2; ++j) br[0][j] = lds[bs2 + j * C::PM];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int cm = 0; cm < kFeat; ++cm) {
+            if (cm + 1 < kFeat) {
+#pragma unroll
+                for (int j = 0; j < C::NR2 + 2; ++j) br[(cm + 1) & 1][j] = lds[(cm + 1) * C::MPLANE + bs2 + j * C::PM];
+            }
+#pragma unroll
+            for (int jj = -1; jj <= 3; ++jj)
+#pragma unroll
+                for (int T = 0; T < 3; ++T) {
+                    const int j = 3 * T + jj + 1;   // staged row index of local input row 3T + jj
+                    if (j <= C::NR2 + 1) acc[T] = mfma4(a2c[cm * 5 + jj + 1], br[cm & 1][j], acc[T]);
+                }
+            if (cm + 1 < kFeat) interleave_mfma_dsread<C::NR2 + 2>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int T = 0; T < 3; ++T) {
+            if (rok[T]) {
+                const float re0 = acc[T][0], re1 = acc[T][1], im0 = acc[T][2], im1 = acc[T][3];
+                if (epi.d_out) {
+                    char* base = reinterpret_cast<char*>(epi.d_out + (long)b * 2 * plane);
+                    *reinterpret_cast<float2*>(base + roff[T]) = make_float2(re0, re1);
+                    *reinterpret_cast<float2*>(base + 4 * plane + roff[T]) = make_float2(im0, im1);
+                }
+                if (epi.wf) {  // wf <- d / 1e3 + wf (hybridnet.py:570)
+                    char* base = reinterpret_cast<char*>(epi.wf + (long)b * 2 * plane);
+                    *reinterpret_cast<float2*>(base + roff[T]) = make_float2(div1000(re0) + wf_old[T][0].x, div1000(re1) + wf_old[T][0].y);
+                    *reinterpret_cast<float2*>(base + 4 * plane + roff[T]) = make_float2(div1000(im0) + wf_old[T][1].x, div1000(im1) + wf_old[T][1].y);
+                }
+            }
+        }
+        return;
+    }
     const float bo0 = w.b2[2 * q], bo1 = w.b2[2 * q + 1];
     f32x4 acc2[C::NR2];
 #pragma unroll
@@ -1908,6 +1983,29 @@ void pack_frag_3x3_half(const float* w, int cin, float* dst_as_float) {
                     dst[((((size_t)g * 3 + dy)) * 64 + l) * 8 + e] = f16_rne(v);
                 }
 }
+// Final layer of the big levels: d = W_out (W_2 * mid + b_2) + b_out = (W_out W_2) * mid + (W_out b_2 + b_out), a 3x3 convolution with
+// two output channels.  Fragment variant v = jj + 1 (staged row 3T + jj of row triple T), lane l -> row m = l & 15 = 4 q + 2 co + dxo
+// (q: row 3T + q of the triple, q < 3), window position t = l >> 4: value W'[co][cm][ky = v - q][t - dxo] where that tap exists.
+void pack_frag_outc3x3(const float* w2, const float* b2, const float* wo, const float* bo, float* frag, float* bias) {
+    if (bias != nullptr) {
+        for (int co = 0; co < 2; ++co) {
+            double s = bo[co];
+            for (int c = 0; c < kFeat; ++c) s += (double)wo[co * kFeat + c] * (double)b2[c];
+            bias[co] = (float)s;
+        }
+    }
+    if (frag == nullptr) return;
+    for (int cm = 0; cm < kFeat; ++cm)
+        for (int v = 0; v < 5; ++v)
+            for (int l = 0; l < 64; ++l) {
+                const int m = l & 15, t = l >> 4, q = m >> 2, co = (m >> 1) & 1, dxo = m & 1;
+                const int ky = v - q, dx = t - dxo;
+                double s = 0.0;
+                if (q < 3 && ky >= 0 && ky <= 2 && dx >= 0 && dx <= 2)
+                    for (int c = 0; c < kFeat; ++c) s += (double)wo[co * kFeat + c] * (double)w2[((c * kFeat + cm) * 3 + ky) * 3 + dx];
+                frag[(cm * 5 + v) * 64 + l] = (float)s;
+            }
+}
 // down conv, weight [8][8][8][8] (co, ci, ky, kx) -> [ci][kx][64]: lane -> (co, h = l&1, k = l>>4): w[co][ci][4h+k][kx]
 void pack_frag_down(const float* w, float* dst) {
     for (int ci = 0; ci < kFeat; ++ci)
@@ -1964,7 +2062,7 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
     const float* s1 = frag1 + (size_t)cin * 3 * 64;      // split-bf16 twin, then the fp16 twin
     const float* s2 = frag2 + (size_t)kFeat * 3 * 64;
     const McW mw{frag1, w.b1, w.slope, frag2, w.b2, s1, s2, s1 + frag_3x3_split_floats(cin), s2 + frag_3x3_split_floats(kFeat), w.act};
-    const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf};
+    const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf, ctx->f_dec0c, ctx->dec0c_b};
     const int x16 = (ctx->precision >= HN_PREC_BF16X3 && ctx->precision <= HN_PREC_BF16X2) ? ctx->precision : 0;
     switch (kind) {
         case 0: launch_dc_mfma<2, 2, 2, 0>(x16, a, b, c, out, mw, e, H, W, batch, s); break;          // inc

@@ -105,7 +105,8 @@ def test_solver_construction_and_setup(g_setup, hparams):
     with pytest.raises(NotImplementedError):
         IterativeSolver(**{**hparams, "architecture": "resnet"})
     with pytest.raises(NotImplementedError):
-        IterativeSolver(**{**hparams, "activation_function": "gelu"})
+        IterativeSolver(**{**hparams, "activation_function": "relu_batchnorm"})
+    assert IterativeSolver(**{**hparams, "activation_function": "gelu"}).f.activation_function == "gelu"
     with pytest.raises(RuntimeError):     # no CPU compute path
         s.get_residual(wf, k_sq)
 
