@@ -455,6 +455,159 @@ __device__ __forceinline__ void axis_finish16(v2 (&d)[2][16], v2 (&acc)[16], int
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// N = 256 = 8 x 4 x 8 on 32 threads x 8 elements per line (row pass): a third of the radix-16 kernel's per-thread
+// instruction stream and twice the wavefronts, for the latency-bound regime of 32 samples (one kernel's critical path is
+// one wavefront's serial work).  x[t + 32 k] --DFT8 over k--> A_t[q] x W_256^(t q) --exchange--> thread (a = v % 8, q pair):
+// DFT4 over b of A_(a + 8 b)[q] --> B_a[c][q] x W_32^(a c) --exchange--> thread u = q + 8 c: DFT8 over a --> X[u + 32 d]:
+// again the layout of the input.  Both exchanges stay inside the half-wavefront that owns the line.
+// ------------------------------------------------------------------------------------------
+template <bool INV>
+__device__ __forceinline__ void dft8(v2 (&x)[8]) {
+    constexpr float H = 0.70710678118654752f;
+    v2 a[4], b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = x[j] + x[j + 4]; b[j] = x[j] - x[j + 4]; }
+    b[1] = cmulv(b[1], (v2){H, INV ? H : -H});      // W8^1
+    b[2] = rot<INV>(b[2]);                           // W8^2 = -+i
+    b[3] = cmulv(b[3], (v2){-H, INV ? H : -H});     // W8^3
+    bfly4<INV>(a[0], a[1], a[2], a[3]);
+    bfly4<INV>(b[0], b[1], b[2], b[3]);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) { x[2 * p] = a[p]; x[2 * p + 1] = b[p]; }
+}
+
+constexpr int kE1 = 36;            // exchange 1: slot q * 36 + t (reads a + 8 b of rows 2 qp, 2 qp + 1: four 8-lane groups on disjoint bank quarters)
+constexpr int kE2 = 9;             // exchange 2: slot (q + 8 c) * 9 + a (32 lanes, stride 18 dwords: conflict-free)
+constexpr int kReg8 = 8 * kE1;     // float2 per transform region (= 32 * kE2)
+
+struct Tw8 {
+    v2 w256[8], w32[4];
+    __device__ __forceinline__ void load(int t, const float2* __restrict__ tw) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const float2 f = tw[t * q]; w256[q] = (v2){f.x, f.y}; }
+#pragma unroll
+        for (int c = 1; c < 4; ++c) { const float2 f = tw[8 * (t & 7) * c]; w32[c] = (v2){f.x, f.y}; }
+    }
+};
+
+// NB lock-step transforms of one line held by 32 threads x 8 elements; v[nb][k] = x[t + 32 k] in, X[t + 32 k] out
+template <bool INV, int NB>
+__device__ __forceinline__ void fft256_t32(v2 (&v)[NB][8], v2* reg, int nbs, int t, const Tw8& tw) {
+    const int a = t & 7, qp = t >> 3;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        dft8<INV>(v[nb]);
+#pragma unroll
+        for (int q = 1; q < 8; ++q) v[nb][q] = INV ? cmulv_conj(v[nb][q], tw.w256[q]) : cmulv(v[nb][q], tw.w256[q]);
+    }
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) reg[nb * nbs + q * kE1 + t] = v[nb][q];
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) v[nb][4 * s2 + b] = reg[nb * nbs + (2 * qp + s2) * kE1 + a + 8 * b];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            bfly4<INV>(v[nb][4 * s2], v[nb][4 * s2 + 1], v[nb][4 * s2 + 2], v[nb][4 * s2 + 3]);   // index b -> c
+#pragma unroll
+            for (int c = 1; c < 4; ++c) v[nb][4 * s2 + c] = INV ? cmulv_conj(v[nb][4 * s2 + c], tw.w32[c]) : cmulv(v[nb][4 * s2 + c], tw.w32[c]);
+        }
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) reg[nb * nbs + (2 * qp + s2 + 8 * c) * kE2 + a] = v[nb][4 * s2 + c];
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[nb][k] = reg[nb * nbs + t * kE2 + k];   // thread t = q + 8 c reads a = 0 .. 7
+        dft8<INV>(v[nb]);
+    }
+}
+
+// row pass at N = 256: workgroup = 8 rows (4 wavefronts x 2 rows), lane = 32 r + t
+__global__ __launch_bounds__(256, 4) void k_spec8_rows(const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
+                                                    const float* __restrict__ src, long src_sb, SpecPtrs tab, int flags,
+                                                    float* __restrict__ sumsq, const int* __restrict__ it_counter, int sumsq_stride) {
+    constexpr int N = 256;
+    __shared__ v2 buf[4 * 2 * 2 * kReg8];
+    __shared__ float red[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = lane & 31, r = lane >> 5;
+    const int row = blockIdx.x * 8 + wave * 2 + r, b = blockIdx.y;
+    const long plane = (long)N * N, ro = (long)row * N;
+    const float* pre = wf + (long)b * 2 * plane + ro;
+    float* po = out + (long)b * 2 * plane + ro;
+    v2 u[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) u[k] = (v2){pre[t + 32 * k], pre[plane + t + 32 * k]};
+    Tw8 tw;
+    tw.load(t, tab.tw);
+    v2* reg = buf + (wave * 2 + r) * 2 * kReg8;
+    v2 f[1][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[0][k] = u[k];
+    fft256_t32<false, 1>(f, reg, kReg8, t, tw);
+    v2 d[2][8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float k1 = tab.k1[t + 32 * p], k2 = tab.k2[t + 32 * p];
+        const v2 U = f[0][p];
+        d[0][p] = (v2){-U.y, U.x} * k1;   // (0, k) * U     (spectral.py:50, 281)
+        d[1][p] = U * k2;                 // (-k^2, 0) * U  (spectral.py:52, 283)
+    }
+    fft256_t32<true, 2>(d, reg, kReg8, t, tw);
+    // the other operands of the row: requested after the transforms (registers: 4 wavefronts per SIMD cover the round trip)
+    v2 part[8], sv[8];
+    float kq[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = t + 32 * k;
+        part[k] = (flags & 1) ? (v2){po[x], po[plane + x]} : (v2){0.f, 0.f};
+        kq[k] = 0.f;
+        sv[k] = (v2){0.f, 0.f};
+        if (flags & 2) {
+            kq[k] = ksq[(long)b * plane + ro + x];
+            const float* ps = src + (long)b * src_sb + ro + x;
+            sv[k] = (v2){ps[0], ps[plane]};
+        }
+    }
+    constexpr float inv_n = 1.0f / 256.0f;
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = t + 32 * k;
+        const float2 ca = tab.a[x], cb = tab.b[x];
+        v2 o = (cmulv(d[0][k], (v2){ca.x, ca.y}) + cmulv(d[1][k], (v2){cb.x, cb.y})) * inv_n + part[k];
+        if (flags & 2) o = o + u[k] * kq[k] - sv[k];
+        po[x] = o.x;
+        po[plane + x] = o.y;
+        ss += o.x * o.x + o.y * o.y;
+    }
+    if (sumsq != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if (lane == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long hist_row = it_counter != nullptr ? (long)(*it_counter - 1) * sumsq_stride : 0;
+            atomicAdd(&sumsq[hist_row + b], red[0] + red[1] + red[2] + red[3]);
+        }
+    }
+}
+
 constexpr int kReg16Rows = 272;   // float2 per transform region: 16 x 17; 544 dwords = 32 (mod 64): the two transforms of a 32-lane group on disjoint banks
 constexpr int kReg16Cols = 280;   // 560 dwords = 48 (mod 64): the four transforms of a 32-lane group (lane = 4 t + c) on disjoint quarters
 
@@ -917,8 +1070,12 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
                         hipLaunchKernelGGL(k_spec16_cols, dim3(16, batch), dim3(256), 0, s, wf, out, p, it_counter);
                     }
                     ProfScope ps(ctx, KID_SPEC_ROWS, s);
-                    hipLaunchKernelGGL(k_spec16_rows, dim3(16, batch), dim3(256), 0, s, wf, out, ksq, src, src_sb, p, 1 | (resid ? 2 : 0),
-                                       accum_sumsq, it_counter, sumsq_stride);
+                    if (ctx->opt_radix16 == 2)
+                        hipLaunchKernelGGL(k_spec16_rows, dim3(16, batch), dim3(256), 0, s, wf, out, ksq, src, src_sb, p, 1 | (resid ? 2 : 0),
+                                           accum_sumsq, it_counter, sumsq_stride);
+                    else
+                        hipLaunchKernelGGL(k_spec8_rows, dim3(32, batch), dim3(256), 0, s, wf, out, ksq, src, src_sb, p, 1 | (resid ? 2 : 0),
+                                           accum_sumsq, it_counter, sumsq_stride);
                 } else {
                     launch_pow2<256>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride);
                 }
