@@ -427,13 +427,18 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
     // strip groups: mid rows 9*half .. 9*half+8, pairs 16*strip + n; operand row j of the wave = staged row 9*half + j
     const int rb1 = C::NR1 * half;
     const int bs1 = rb1 * C::PI + 2 * (16 * strip + n) + q;
-    // vertical group (waves 0, 1): pair column 32 (mid cols 64, 65), mid rows vrow0 + n
-    const bool has_v = wave < 2;
-    const int vrow0 = wave == 0 ? 0 : 2;
+    // vertical groups: pair column 32 (mid cols 64, 65), mid rows vrow0 + n -- group vg = 0: rows 0-15, vg = 1: rows 2-17 (only 16, 17
+    // are new).  Their 6 MFMAs per chunk are split over TWO wavefronts by input channel (vc = channel of each chunk this wave
+    // multiplies), so that every wave of the block issues 57 MFMAs per chunk instead of 60 / 60 / 54 / 54: the chunk barrier waits
+    // for the slowest.  Waves 0, 1 (vc = 0) hand their partial sums to waves 2, 3 (vc = 1, which hold the bias and write the mid
+    // tensor) through LDS words that nothing touches during conv1 and that the consumer itself overwrites later: mid channel 7,
+    // rows 9.., columns of the consumer's own strip.
+    const int vg = wave & 1, vc = wave >> 1;
+    const int vrow0 = vg == 0 ? 0 : 2;
     const int bsv = (vrow0 + n) * C::PI + 64 + q;
     // accumulators start at the bias (D rows of a lane: channel 2q for pixels 0/1, channel 2q+1 for pixels 0/1)
     const float bias0 = w.b1[2 * q], bias1 = w.b1[2 * q + 1];
-    f32x4 acc1[C::NR1], accv = (f32x4){bias0, bias0, bias1, bias1};
+    f32x4 acc1[C::NR1], accv = vc == 1 ? (f32x4){bias0, bias0, bias1, bias1} : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < C::NR1; ++r) acc1[r] = (f32x4){bias0, bias0, bias1, bias1};
 
@@ -448,34 +453,39 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
         __syncthreads();
         if (g + 1 < C::NG) fetch(g + 1);
         const float* t = lds + buf * 2 * C::PLANE_P;
-        float br[2][C::NR1 + 2], bvv[2][3];
+        float br[2][C::NR1 + 2], bvv[3];
 #pragma unroll
         for (int j = 0; j < C::NR1 + 2; ++j) br[0][j] = t[bs1 + j * C::PI];
-        if (has_v) {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) bvv[0][dy] = t[bsv + dy * C::PI];
-        }
+        for (int dy = 0; dy < 3; ++dy) bvv[dy] = t[vc * C::PLANE_P + bsv + dy * C::PI];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c == 0) {  // rows of the second channel are read behind the first channel's MFMAs
 #pragma unroll
                 for (int j = 0; j < C::NR1 + 2; ++j) br[1][j] = t[C::PLANE_P + bs1 + j * C::PI];
-                if (has_v) {
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) bvv[1][dy] = t[C::PLANE_P + bsv + dy * C::PI];
-                }
             }
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int r = 0; r < C::NR1; ++r) acc1[r] = mfma4(afrag[c * 3 + dy], br[c][r + dy], acc1[r]);
-            if (has_v) {
-#pragma unroll
-                for (int dy = 0; dy < 3; ++dy) accv = mfma4(afrag[c * 3 + dy], bvv[c][dy], accv);
-            }
             if (c == 0) interleave_mfma_dsread<C::NR1 + 2>();
             __builtin_amdgcn_sched_barrier(0);
+            if (c == vc) {   // wave-uniform: this wave's channel of the vertical group
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) accv = mfma4(afrag[c * 3 + dy], bvv[dy], accv);
+            }
+        }
+    }
+    // partial sums of the vertical groups: producer waves (vc = 0) -> consumer's own corner of the (still unused) mid region
+    float* const vx = lds + 7 * C::MPLANE + 9 * C::PM + 32 * vg;   // mid channel 7, row 9.., columns 32 vg ..: 32 floats per row
+    if (vc == 0) {
+        if (vg == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int k = lane * 4 + r; vx[(k >> 5) * C::PM + (k & 31)] = accv[r]; }
+        } else if (n >= 14) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vx[((n - 14) * 4 + q) * 4 + r] = accv[r];
         }
     }
     float a2[EPI == 1 ? 1 : kFeat * 3];
@@ -488,6 +498,15 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
         for (int j = 0; j < kFeat * 3; ++j) a2[EPI == 1 ? 0 : j] = w.a2[j * 64 + lane];
     }
     __syncthreads();  // staged input is dead: the mid tensor takes its place
+    if (vc == 1) {   // the producer's share of the vertical group, before this wave's own mid rows overwrite those words
+        if (vg == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int k = lane * 4 + r; accv[r] += vx[(k >> 5) * C::PM + (k & 31)]; }
+        } else if (n >= 14) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accv[r] += vx[((n - 14) * 4 + q) * 4 + r];
+        }
+    }
     {
         // PReLU (architectures.py:32-33) as median(x, s x, +-inf): max(x, s x) for s <= 1, min otherwise --
         // exactly x or s x -- and the zero padding of the MID tensor outside the image (conv2 pads it)
@@ -522,7 +541,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
                 else put_zero(rb1 + r, pc);
             }
         }
-        if (has_v && (wave == 0 || n >= 14)) {  // pair column 32: x is uniform, the row differs per lane
+        if (vc == 1 && (vg == 0 || n >= 14)) {  // pair column 32: x is uniform, the row differs per lane
             const int y = y0 - 1 + vrow0 + n, x = x0 + 63;
             const bool yin = y >= 0 && y < H;
             const float m0 = (yin && x < W) ? 1.f : 0.f, m1 = (yin && x + 1 < W) ? 1.f : 0.f;
