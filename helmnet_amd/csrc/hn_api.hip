@@ -66,6 +66,7 @@ struct Packer {
     DcW dc(int cin, int cm, int co) {
         DcW w;
         w.act = act;
+        w.w1q = nullptr;   // set by hn_load_weights for the 8-channel DoubleConvs
         repack_oihw(src + pos, dst.data() + pos, cm, cin, 9);
         w.w1 = dev + pos; pos += (size_t)cm * cin * 9;
         std::memcpy(dst.data() + pos, src + pos, sizeof(float) * cm);
@@ -196,6 +197,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             break;
         case HN_OPT_DEEP: ctx->opt_deep = value != 0; break;
         case HN_OPT_SPECTRAL_PFA: ctx->opt_pfa = value != 0; break;
+        case HN_OPT_DC_VALU: ctx->opt_dc_valu = value != 0; break;
         case HN_OPT_SPECTRAL_RADIX16: ctx->opt_radix16 = value < 0 ? 0 : value > 2 ? 2 : value; break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }
@@ -285,7 +287,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     HN_HIP(ctx, hipMemcpy(ctx->wdev, packed.data(), want * sizeof(float), hipMemcpyHostToDevice));
     {   // A-operand fragments for the matrix-core kernels, built from the original OIHW tensors
         std::vector<float> fr;
-        std::vector<size_t> off;
+        std::vector<size_t> off, offq;   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order
         size_t pos = 0;
         auto dc = [&](int cin, int cm, int co) {  // returns offsets of (frag1, frag2) or (npos, npos)
             const float* w1 = blob + pos; pos += (size_t)cm * cin * 9 + cm + 1;
@@ -295,6 +297,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
                 off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cm * 3 * 64); pack_frag_3x3_c2(w2, cm, fr.data() + off.back());
                 return;
             }
+            offq.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 72); pack_valu_q(w1, cin, fr.data() + offq.back());
             // each fp32 fragment block is followed by its split-bf16 and fp16 twins (launch_dc8 relies on this order)
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3(w1, cin, fr.data() + off.back());
             { const size_t o = fr.size(); fr.resize(o + frag_3x3_split_floats(cin)); pack_frag_3x3_split(w1, cin, fr.data() + o); }
@@ -320,7 +323,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         for (int d = 0; d <= depth; ++d) dc(d < depth ? 2 * kFeat : kFeat, kFeat, kFeat);
         for (int d = 0; d < depth; ++d) k8(true);
         // final layer: decode[0]'s second convolution composed with the 1x1 out-conv (one linear map, composed in float64)
-        size_t off_comp = 0, off_comp_b = 0;
+        size_t off_comp = 0, off_comp_b = 0, off_comp_v = 0;
         {
             const float* w2 = blob + pos_dec0 + (size_t)kFeat * 2 * kFeat * 9 + kFeat + 1;   // decode.0.double_conv.2.weight [8][8][3][3]
             const float* b2 = w2 + (size_t)kFeat * kFeat * 9;
@@ -332,6 +335,9 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             off_comp_b = fr.size();
             fr.resize(fr.size() + 4);
             pack_frag_outc3x3(w2, b2, wo, bo, nullptr, fr.data() + off_comp_b);
+            off_comp_v = fr.size();
+            fr.resize(fr.size() + (size_t)kFeat * 9 * 2);
+            pack_outc3x3_valu(w2, wo, fr.data() + off_comp_v);
         }
         (void)hipFree(ctx->fragdev);
         ctx->fragdev = nullptr;
@@ -345,8 +351,15 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         }
         for (int d = 0; d <= depth; ++d) { ctx->f_dec[d][0] = nxt(); ctx->f_dec[d][1] = nxt(); }
         for (int d = 0; d < depth; ++d) ctx->f_up[d] = nxt();
+        {
+            size_t iq = 0;
+            ctx->inc.w1q = ctx->fragdev + offq[iq++];
+            for (int d = 0; d < depth; ++d) ctx->sig[d].w1q = ctx->fragdev + offq[iq++];
+            for (int d = 0; d <= depth; ++d) ctx->dec[d].w1q = ctx->fragdev + offq[iq++];
+        }
         ctx->f_dec0c = ctx->fragdev + off_comp;
         ctx->dec0c_b = ctx->fragdev + off_comp_b;
+        ctx->v_dec0c = ctx->fragdev + off_comp_v;
     }
     if (ctx->have_weights && ctx->depth != depth) free_workspace(ctx);
     ctx->depth = depth;

@@ -39,6 +39,7 @@ struct DcW {
     const float* w2;
     const float* b2;
     int act;   // hn_act
+    const float* w1q;   // conv1 again as [cin][2 channel halves][3][3][4] (8-channel DoubleConvs only; hn_dcv.hip)
 };
 
 // The reference's smooth activations (architectures.py:22-39: nn.CELU(), nn.Tanh(), nn.GELU(), nn.Tanhshrink(),
@@ -97,6 +98,7 @@ struct hn_ctx {
     const float *f_inc[2]{}, *f_sig[hn::kMaxDepth][2]{}, *f_dec[hn::kMaxDepth + 1][2]{};
     const float *f_down[hn::kMaxDepth]{}, *f_up[hn::kMaxDepth]{};
     const float *f_dec0c = nullptr, *dec0c_b = nullptr;   // decode[0] conv2 composed with the out-conv: [8][5][64] row-triple fragments, bias [2]
+    const float* v_dec0c = nullptr;   // the same composed convolution for the vector-pipe kernel: [8 cm][3][3][2] (hn_dcv.hip)
     const float* f_st[hn::kMaxDepth][2]{};   // conv_state (2 output channels in rows 0..3 of M): [10][3][64], [2][3][64] (hn_deep.hip)
     bool deep_attr_set = false, pfa_attr_set = false;
     // arithmetic of the UNet convolutions (hn_set_unet_precision; default from HN_UNET_IMPL at hn_create only)
@@ -112,6 +114,7 @@ struct hn_ctx {
     int opt_pfa = 1;           // prime-factor FFT for n = 3 * 2^k, 5 * 2^k (0: dense operator, A/B; takes effect at hn_set_domain)
     int opt_radix16 = 1;       // 256-point transforms as two register-resident radix-16 passes (0: the radix-4 Stockham kernels)
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
+    int opt_dc_valu = 1;       // fp32 DoubleConvs of the big levels on the packed vector FMA (hn_dcv.hip) instead of the fp32 MFMA
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
     // domain
@@ -236,6 +239,13 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
 void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
 void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
+
+// ---- vector-pipe DoubleConv of the big levels (hn_dcv.hip) ----
+void pack_valu_q(const float* w_oihw, int cin, float* dst);            // conv1 [8][cin][3][3] -> [cin][2][9][4]
+void pack_outc3x3_valu(const float* w2, const float* wo, float* dst);   // conv2 composed with the out-conv -> [8 cm][3][3][2]
+bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
+void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
+                    int W, int batch, hipStream_t s);
 
 // ---- deep levels in one per-sample kernel (hn_deep.hip) ----
 void pack_frag_3x3_c2(const float* w_oihw, int cin, float* dst);  // 2 output channels -> [cin][3][64], rows 4..15 of M zero

@@ -2076,6 +2076,10 @@ void pack_frag_up(const float* w, float* dst) {
 
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s) {
+    if (dc_valu_applies(ctx, w.act, a, b, c, kind, H, W)) {
+        launch_dc_valu(ctx, kind, a, b, c, out, w, final_epi, d_out, wf, H, W, batch, s);
+        return HN_OK;
+    }
     const int cin = kind == 0 ? kInCh : kind == 1 ? kFeat + kState : kind == 2 ? kFeat : 2 * kFeat;
     // hn_load_weights stores the split-bf16 fragments right behind the fp32 ones
     const float* s1 = frag1 + (size_t)cin * 3 * 64;      // split-bf16 twin, then the fp16 twin

@@ -61,7 +61,8 @@ enum hn_act { HN_ACT_PRELU = 0, HN_ACT_RELU = 1, HN_ACT_LEAKYRELU = 2, HN_ACT_CE
  *   HN_PREC_FP32_VALU  fp32 on the vector ALU (direct convolution; A/B reference for the matrix-core kernels) */
 enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_PREC_BF16X2 = 3, HN_PREC_FP32_VALU = 4 };
 
-/* Tuning knobs of hn_step (hn_set_option); none changes a result bit. */
+/* Tuning knobs of hn_step (hn_set_option); none changes a result bit except HN_OPT_DC_VALU (same fp32 FMA arithmetic,
+ * another summation order: results agree to rounding, like two fp32 implementations of the reference do). */
 enum hn_option {
     HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
     HN_OPT_SIDE_STREAM = 1,  /* conv_state kernels: 0 in line; on a library side stream released 1 after the last `down`,
@@ -70,6 +71,8 @@ enum hn_option {
                               * launch; even n <= 64: n iterations per graph                                          */
     HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
     HN_OPT_SPECTRAL_RADIX16 = 5, /* 0/1: 256-point lines as two register-resident radix-16 passes (default 1; 0: radix-4 kernels) */
+    HN_OPT_DC_VALU = 6,      /* 0/1: fp32 DoubleConvs of the big levels on the packed vector FMA (default 1: every FMA useful, same
+                              * peak as the fp32 MFMA whose 3x3 packing fills 75 % of its slots); 0: the fp32 MFMA kernels     */
     HN_OPT_SPECTRAL_PFA = 4  /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k instead of the dense n x n operator (default 1;
                               * read by the next hn_set_domain)                                                     */
 };
