@@ -66,8 +66,9 @@ def kernel_bytes(n: int, depth: int = 4) -> dict:
 
 # rocprofv3 kernel names of the kernels that are launched once per step; used to look the dominant kernel's measured
 # HBM traffic up in profiles/*_traffic.json (FETCH_SIZE + WRITE_SIZE of the same command, tools/summarize_profiles.py)
-ROCPROF_NAME = {"decode0": "k_dc_mfma_s<8, 8, 0, 1>", "inc": "k_dc_mfma_s<2, 2, 2, 0>",
-                "spectral_rows": "k_spec_rows<256>", "spectral_cols": "k_spec_cols<256, 16>"}
+ROCPROF_NAME = {"decode0": ("k_dc_valu<8, 8, 0, 1, false>", "k_dc_mfma_s<8, 8, 0, 1, false>", "k_dc_mfma_s<8, 8, 0, 1>"),
+                "inc": ("k_dc_valu<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0>"),
+                "spectral_rows": ("k_spec8_rows", "k_spec_rows<256>"), "spectral_cols": ("k_spec16_cols", "k_spec_cols<256, 16>")}
 
 
 def measured_traffic(kernel: str, n: int, batch: int, precision: str):
@@ -78,8 +79,9 @@ def measured_traffic(kernel: str, n: int, batch: int, precision: str):
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
         with open(path) as f:
             t = json.load(f)
-        if ROCPROF_NAME[kernel] in t:
-            return t[ROCPROF_NAME[kernel]]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
+        for name in ROCPROF_NAME[kernel]:   # the newest summary that knows one of the kernel's names (newest name first)
+            if name in t:
+                return t[name]["hbm_bytes_per_launch"], os.path.relpath(path, ROOT)
     return None, None
 
 
@@ -252,22 +254,26 @@ def main():
     # a short run (--steps 20 is 12 ms) would otherwise be timed while the GPU's clocks are still settling (the same kernels
     # measure ~10 % slower in the first tens of milliseconds of a fresh process): keep the loop running, untimed, until
     # 0.3 s of it have passed -- reported as warmup_extra
-    extra, t_w = 0, time.perf_counter()
-    while time.perf_counter() - t_w < 0.3:
-        eng.step(wf, res, st, k_sq, src, 32, rmse_hist=rmse[:min(32, rmse.shape[0])] if rmse.shape[0] >= 32 else None)
-        torch.cuda.synchronize()
-        extra += 32
     allreduce_residual_norms(rmse[0], op="max")
-    eng.profile_enable([dom_id])
-    cap = 8 if K >= 64 else 2                         # at most 8 (short runs: 4) bracketed launches in the timed region: a bracket costs
+    cap = 8 if K >= 64 else 2                         # at most 8 (short runs: 2) bracketed launches in the timed region: a bracket costs
     stride = max(1, -(-K // cap))                     # ~6 us of stream gap and runs its iteration kernel by kernel instead of as a graph replay
-    eng.profile_stride(stride)
-    replays0, eager0 = eng.counter("graph_replays"), eng.counter("eager_iterations")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    # the settling loop comes LAST, straight in front of the barrier: a few hundred microseconds of idle GPU (the reduction above
+    # ends in a host read-back) are enough for the clocks to drop, and the first ~10 ms afterwards then run ~9 % slow --
+    # invisible at --steps 300, a tenth of a --steps 20 measurement
+    extra, t_w = 0, time.perf_counter()
+    while time.perf_counter() - t_w < 0.3:
+        eng.step(wf, res, st, k_sq, src, 32, rmse_hist=rmse[:min(32, rmse.shape[0])] if rmse.shape[0] >= 32 else None)
+        torch.cuda.synchronize()
+        extra += 32
+    eng.profile_enable([dom_id])                      # host-side state only
+    eng.profile_stride(stride)
+    replays0, eager0 = eng.counter("graph_replays"), eng.counter("eager_iterations")
 
     barrier()
     t0 = time.perf_counter()
@@ -303,6 +309,11 @@ def main():
                         "flops_per_launch": flops, "product_terms_per_flop": TERMS[prec],
                         "hbm_view": {"bytes_per_launch": hbm, "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(ach_b / HBM_PEAK_GBS, 4)}}
+                dc_valu = prec == "fp32" and n >= 256 and dict(kv.split("=", 1) for kv in args.opt).get("dc_valu", "1") != "0"
+                if dominant in ("decode0", "conv_signal0", "inc") and dc_valu:
+                    # hn_dcv.hip: the level-0 DoubleConvs run on the packed fp32 VECTOR FMA, whose peak on gfx950 equals the
+                    # fp32 matrix peak (157.3 TFLOP/s, 64 FLOP / clk / SIMD); "bound" keeps the schema's compute label
+                    roof["pipe"] = "v_pk_fma_f32 (fp32 vector FMA; peak = fp32 MFMA peak)"
                 if ach_b / HBM_PEAK_GBS > ach_f * TERMS[prec] / peak:   # 16-bit modes: the level-0 DoubleConvs become HBM-bound
                     roof.update({"bound": "hbm", "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(ach_b / HBM_PEAK_GBS, 4),

@@ -395,6 +395,35 @@ def test_fused_deep_level_kernel_matches_the_layer_by_layer_path(weights):
     assert (outs[1][2][:, :, L3] - want[2][:, :, L3]).abs().max().item() <= 1e-5 * want[2][:, :, L3].abs().max().item()
 
 
+@pytest.mark.parametrize("n,b", [(256, 2), (512, 1)])
+def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weights, n, b):
+    """hn_dcv.hip (level-0 DoubleConvs on v_pk_fma_f32, the default at W >= 256) against the fp32 matrix-core kernels
+    (HN_OPT_DC_VALU = 0) and against the oracle: the same fp32 FMAs in another order, so both sit within 1e-5 * max of the
+    oracle and within 4e-6 * max of each other; at 512 the option also covers level 1 (W = 256)."""
+    from helmnet_amd import IterativeSolver
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=777).items()}
+    outs = {}
+    for valu in (1, 0):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=SRC[n])
+        s.engine().set_option("dc_valu", valu)
+        g = {k: v.to(DEV) for k, v in ti.items()}
+        k_sq, _ = s.get_initials(g["sos"])
+        s.f.set_states(g["states"], flatten=True)
+        wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
+        outs[valu] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, SRC[n], 10.0), t)
+    want = (want[0], want[1], O.flatten_states(want[2]))
+    for a, bb, w in zip(outs[1], outs[0], want):
+        scale = w.abs().max().item()
+        assert (a - bb).abs().max().item() <= 4e-6 * scale
+        assert (a - w).abs().max().item() <= 1e-5 * scale
+        assert (bb - w).abs().max().item() <= 1e-5 * scale
+    assert not torch.equal(outs[1][0], outs[0][0])   # two different kernels did run
+
+
 def test_graph_replay_is_bit_identical_to_kernel_by_kernel_launches(solver):
     """HN_OPT_GRAPH: one captured iteration per graph, and 4 iterations per graph, against the default launches -- the
     same kernels with the same arguments in the same order, so every output bit agrees (the RMSE history goes through
