@@ -42,7 +42,7 @@ __device__ __forceinline__ void conv_rows(f32x2 (&acc)[R][NP], const float* xc, 
     }
 }
 
-template <int NP, int VAR>
+template <int NP, int VAR, int R = 9>
 __global__ __launch_bounds__(256, 4) void k(const float* w, float* out, int ncin) {
     __shared__ float lds[4 * PLANE_P];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -50,12 +50,12 @@ __global__ __launch_bounds__(256, 4) void k(const float* w, float* out, int ncin
     const int h = wave >> 1, q = wave & 1;
     for (int i = tid; i < 4 * PLANE_P; i += 256) lds[i] = 1e-3f * (i % 37);
     __syncthreads();
-    f32x2 acc[9][NP];
+    f32x2 acc[R][NP];
 #pragma unroll
-    for (int r = 0; r < 9; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int c = 0; c < NP; ++c) acc[r][c] = (f32x2){0.f, 0.f};
-    const int bs1 = 9 * h * PI + lane;
+    const int bs1 = (R == 9 ? 9 * h : 4 * wave) * PI + lane;
 #pragma unroll 1
     for (int ci = 0; ci < ncin; ci += 2) {
 #pragma unroll
@@ -63,18 +63,18 @@ __global__ __launch_bounds__(256, 4) void k(const float* w, float* out, int ncin
             const CwPtr wp = cw(w + (size_t)((((VAR & 1) ? 0 : (ci + j) & 15) * 2 + q) * 18 * NP));
             int off = ((ci & 2) + j) * PLANE_P + bs1;
             asm volatile("" : "+v"(off));
-            conv_rows<9, NP, VAR>(acc, lds + off, PI, wp, (float)lane);
+            conv_rows<R, NP, VAR>(acc, lds + off, PI, wp, (float)lane);
         }
     }
     float s = 0;
 #pragma unroll
-    for (int r = 0; r < 9; ++r)
+    for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int c = 0; c < NP; ++c) s += acc[r][c][0] + acc[r][c][1];
     out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int NP, int VAR>
+template <int NP, int VAR, int R = 9>
 void run(const float* w, float* out, const char* name) {
     hipEvent_t a, b;
     (void)hipEventCreate(&a);
@@ -85,13 +85,13 @@ void run(const float* w, float* out, const char* name) {
         float ms = 0;
         for (int rep = 0; rep < 3; ++rep) {
             (void)hipEventRecord(a);
-            hipLaunchKernelGGL((k<NP, VAR>), dim3(grid), dim3(256), 0, 0, w, out, ncin);
+            hipLaunchKernelGGL((k<NP, VAR, R>), dim3(grid), dim3(256), 0, 0, w, out, ncin);
             (void)hipEventRecord(b);
             (void)hipEventSynchronize(b);
             (void)hipEventElapsedTime(&ms, a, b);
         }
-        const double flops = 2.0 * 9 * 9 * NP * 2 * (double)ncin * 256.0 * grid;
-        printf("%s NP=%d  blocks/CU %d  %.3f ms  %.1f TFLOP/s (%.2f of 157.3)\n", name, NP, bpc, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3);
+        const double flops = 2.0 * R * 9 * NP * 2 * (double)ncin * 256.0 * grid;
+        printf("%s R=%d NP=%d  blocks/CU %d  %.3f ms  %.1f TFLOP/s (%.2f of 157.3)\n", name, R, NP, bpc, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3);
     }
 }
 
@@ -107,5 +107,8 @@ int main() {
     run<2, 3>(w, out, "neither         ");
     run<4, 0>(w, out, "kernel-like     ");
     run<4, 2>(w, out, "no LDS reads    ");
+    run<4, 0, 4>(w, out, "conv2-like      ");
+    run<4, 1, 4>(w, out, "weights once    ");
+    run<4, 2, 4>(w, out, "no LDS reads    ");
     return 0;
 }
