@@ -5,7 +5,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from helmnet_amd import IterativeSolver
 from helmnet_amd.phantoms import ring_sos_batch
-lib = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "libclock_probe.so"))
+SO = os.path.join(ROOT, "tools", "probe", "libclock_probe.so")
+if not os.path.exists(SO):   # git-ignored: build it here (hipcc cross-compiles, so this works before the file travels to the GPU box)
+    import subprocess
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO,
+                    os.path.join(ROOT, "tools", "probe", "clock_probe.hip")], check=True)
+lib = ctypes.CDLL(SO)
 lib.probe_launch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_ulonglong]
 s = IterativeSolver.from_exported_weights(); s.freeze(); s.to("cuda:0")
 if len(sys.argv) > 1: s.set_unet_precision(sys.argv[1])
