@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = wave >> 1, q = wave & 1;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();   // XCD-aware tile order (hn_internal.h)
+    const int b = tl.z;
+    const int x0 = tl.x * C::TW, y0 = tl.y * C::TH;
 
     // ---- staging plan (as k_dc_mfma_s): float2 positions of this thread; out-of-image positions are zeroed once in
     // every staged plane and their lanes commit to a private dummy slot, so the chunk loop carries no predicate ----

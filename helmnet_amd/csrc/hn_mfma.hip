@@ -111,8 +111,9 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = lane & 15, q = lane >> 4;  // q doubles as the K index t of the A/B operands
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int x0 = tl.x * TW, y0 = tl.y * C::TH;
 
     // ---- staging bookkeeping: unconditional loads from clamped addresses, masked at commit ----
     int goff[C::NL];
@@ -361,8 +362,9 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: branches on it are scalar
     const int n = lane & 15, q = lane >> 4;
     const int strip = wave & 1, half = wave >> 1;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int x0 = tl.x * C::TW, y0 = tl.y * C::TH;
 
     // ---- staging plan: float2 positions of this thread (W even: a pair never straddles the image edge) ----
     // Every non-MFMA instruction of the chunk loop is paid in matrix-pipe time, so the
@@ -847,8 +849,9 @@ __global__ __launch_bounds__(256, TH == 16 ? 2 : 3) void k_dc_x16(Src sa, Src sb
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int strip = wave & 1, half = wave >> 1;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * C::TW, y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int x0 = tl.x * C::TW, y0 = tl.y * C::TH;
 
     // ---- staging plan: pixel pairs (W even) ----
     unsigned gofb[C::NL];
@@ -1225,6 +1228,7 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
     }
     const float ob_im = EPI == 1 ? epi.ob[1] : 0.f;
     int tile = blockIdx.x;
+    if ((int)gridDim.x == ntiles && (ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);   // XCD-aware order (hn_internal.h)
     if (tile < ntiles) issue(tile);
     for (; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
@@ -1406,8 +1410,9 @@ __global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const flo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int wx = wave % WX, wy = wave / WX;
-    const int b = blockIdx.z;
-    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int X0 = tl.x * C::TW, Y0 = tl.y * C::TH;
     const int Hout = Hin / 2, Wout = Win / 2;
 
     unsigned gofb[C::NL];
@@ -1544,8 +1549,9 @@ __global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
     const int wx = wave % WX, wy = wave / WX;
-    const int b = blockIdx.z;
-    const int X0 = blockIdx.x * C::TW, Yb = blockIdx.y * C::TH - 1;  // first window row of the block
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int X0 = tl.x * C::TW, Yb = tl.y * C::TH - 1;  // first window row of the block
     const int Hout = 2 * Hin, Wout = 2 * Win;
 
     unsigned gofb[C::NL];
@@ -1692,8 +1698,9 @@ __global__ __launch_bounds__(256, 2) void k_down_x16(Src in, Dst out, const void
     const int tid = threadIdx.x, lane = tid & 63;
     const int wy = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z;
-    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int X0 = tl.x * C::TW, Y0 = tl.y * C::TH;
     const int Hout = Hin / 2, Wout = Win / 2;
     const float* const base = in.p + (long)b * in.sb;
     // ---- stage the whole 38 x 38 x 8 input window: one pixel (8 channel loads) per thread and step ----
@@ -1785,8 +1792,9 @@ __global__ __launch_bounds__(256, 2) void k_up_x16(Src in, Dst out, const void* 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wy = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
-    const int b = blockIdx.z;
-    const int X0 = blockIdx.x * C::TW, Yb = blockIdx.y * C::TH - 1;  // first window row of the block
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int X0 = tl.x * C::TW, Yb = tl.y * C::TH - 1;  // first window row of the block
     const int Hout = 2 * Hin, Wout = 2 * Win;
     const float* const base = in.p + (long)b * in.sb;
     float v[C::NL][kFeat];

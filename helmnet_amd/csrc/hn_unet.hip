@@ -77,8 +77,9 @@ __global__ __launch_bounds__((DcCfg<CA, CB, CC, CM, CO, TW>::NT)) void k_double_
     __shared__ __attribute__((aligned(16))) float s_mid[CM * C::MR * C::PM + 8];
 
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int b = tl.z;
+    const int x0 = tl.x * TW, y0 = tl.y * C::TH;
 
     // --- per-thread staging positions (identical for every channel pair) ---
     // Loads are issued unconditionally from a clamped address and masked when they are written to
@@ -257,8 +258,9 @@ struct DownCfg {
 __global__ __launch_bounds__(DownCfg::NT) void k_down8x8(Src in, Dst out, K8W w, int Hin, int Win) {
     using C = DownCfg;
     __shared__ __attribute__((aligned(16))) float s_in[2][2 * C::PLANE];
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int tid = threadIdx.x, b = tl.z;
+    const int X0 = tl.x * C::TW, Y0 = tl.y * C::TH;
     const int Hout = Hin / 2, Wout = Win / 2;
     int goff[C::NL];
     unsigned okmask = 0, inmask = 0;
@@ -349,8 +351,9 @@ struct UpCfg {
 __global__ __launch_bounds__(UpCfg::NT) void k_up8x8(Src in, Dst out, K8W w, int Hin, int Win) {
     using C = UpCfg;
     __shared__ __attribute__((aligned(16))) float s_in[kFeat * C::PLANE];
-    const int tid = threadIdx.x, b = blockIdx.z;
-    const int X0 = blockIdx.x * C::TW, Y0 = blockIdx.y * C::TH;
+    const TileId tl = xcd_tile();
+    const int tid = threadIdx.x, b = tl.z;
+    const int X0 = tl.x * C::TW, Y0 = tl.y * C::TH;
     const int Hout = 2 * Hin, Wout = 2 * Win;
     for (int e = tid; e < C::PLANE; e += C::NT) {
         const int ir = e / C::PI, ic = e - ir * C::PI;
