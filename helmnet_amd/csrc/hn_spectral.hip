@@ -221,10 +221,11 @@ __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict
     // one more iteration of the running hn_step: the row pass (next kernel on the stream) files its per-sample
     // sum of squares under row *it_counter - 1 of the RMSE history
     if (it_counter != nullptr && (blockIdx.x | blockIdx.y | c | j) == 0) atomicAdd(it_counter, 1);
-    const int col0 = blockIdx.x * (C * CPW) + c;
+    const TileId tl = xcd_tile();   // sample -> XCD as in the UNet kernels (hn_internal.h)
+    const int col0 = tl.x * (C * CPW) + c;
     const long plane = (long)N * N;
-    const float* pre = wf + (long)blockIdx.y * 2 * plane + col0;
-    float* po = out + (long)blockIdx.y * 2 * plane + col0;
+    const float* pre = wf + (long)tl.y * 2 * plane + col0;
+    float* po = out + (long)tl.y * 2 * plane + col0;
     float2 cur[4], nxt[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
     __shared__ float2 buf[2 * N * R];
     __shared__ float red[(T * R + 63) / 64];
     const int j = threadIdx.x, ry = threadIdx.y;
-    const int row0 = blockIdx.x * (R * RPW) + ry, b = blockIdx.y;
+    const TileId tl = xcd_tile();
+    const int row0 = tl.x * (R * RPW) + ry, b = tl.y;
     const long plane = (long)N * N;
     RowOperands<N> cur, nxt;
     cur.load(wf, out, ksq, src, src_sb, b, row0, j, flags);
@@ -546,7 +548,8 @@ __global__ __launch_bounds__(256, 4) void k_spec8_rows(const float* __restrict__
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = lane & 31, r = lane >> 5;
-    const int row = blockIdx.x * 8 + wave * 2 + r, b = blockIdx.y;
+    const TileId tl = xcd_tile();
+    const int row = tl.x * 8 + wave * 2 + r, b = tl.y;
     const long plane = (long)N * N, ro = (long)row * N;
     const float* pre = wf + (long)b * 2 * plane + ro;
     float* po = out + (long)b * 2 * plane + ro;
@@ -619,9 +622,10 @@ __global__ __launch_bounds__(256) void k_spec16_cols(const float* __restrict__ w
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = lane >> 2, c = lane & 3;
     if (it_counter != nullptr && (blockIdx.x | blockIdx.y | threadIdx.x) == 0) atomicAdd(it_counter, 1);
-    const int col = blockIdx.x * 16 + wave * 4 + c;
+    const TileId tl = xcd_tile();   // sample -> XCD as in the UNet kernels: the wavefield decode0 just wrote and the partial the row pass reads next stay in one L2
+    const int col = tl.x * 16 + wave * 4 + c;
     const long plane = (long)N * N;
-    const float* pre = wf + (long)blockIdx.y * 2 * plane + col;
+    const float* pre = wf + (long)tl.y * 2 * plane + col;
     v2 u[16], d[2][16], acc[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
@@ -632,7 +636,7 @@ __global__ __launch_bounds__(256) void k_spec16_cols(const float* __restrict__ w
     axis_forward16(u, d, reg, kReg16Cols, t, tab);
     xchg16<2>(d, reg, kReg16Cols, t);
     axis_finish16(d, acc, t, tab);
-    float* po = out + (long)blockIdx.y * 2 * plane + col;
+    float* po = out + (long)tl.y * 2 * plane + col;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const long o = (long)(t + 16 * k) * N;
@@ -650,7 +654,8 @@ __global__ __launch_bounds__(256) void k_spec16_rows(const float* __restrict__ w
     __shared__ float red[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int t = lane & 15, r = lane >> 4;
-    const int row = blockIdx.x * 16 + wave * 4 + r, b = blockIdx.y;
+    const TileId tl = xcd_tile();
+    const int row = tl.x * 16 + wave * 4 + r, b = tl.y;
     const long plane = (long)N * N, ro = (long)row * N;
     const float* pre = wf + (long)b * 2 * plane + ro;
     float* po = out + (long)b * 2 * plane + ro;
