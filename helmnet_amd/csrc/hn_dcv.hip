@@ -187,16 +187,24 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
             acce[c] = bv;
         }
     }
+#ifndef HN_EXP
+#define HN_EXP 0
+#endif
+    // timing-only ablations (tools/build_variant.sh <name> hn_dcv.hip -DHN_EXP=<bits>; wrong results by construction):
+    // 1 no staging / barriers after the first chunk, 2 no edge columns, 4 no conv2, 32 no global loads after the first two chunks
+    constexpr int kExp = HN_EXP;
     auto step = [&](int g, int buf, float2 (&stage)[C::CK][C::NL]) {   // chunk g: its loads were issued two chunks ago into `stage`
-        commit(g * C::CK, buf, stage);
-        __syncthreads();
-        if (g + 2 < C::NG) fetch((g + 2) * C::CK, stage);
+        if (!(kExp & 1) || g == 0) {
+            commit(g * C::CK, buf, stage);
+            __syncthreads();
+            if (g + 2 < C::NG && !(kExp & 32)) fetch((g + 2) * C::CK, stage);
+        }
         const float* t = lds + buf * C::CK * C::PLANE_P;
 #pragma unroll
         for (int j = 0; j < C::CK; ++j) {
             const CwPtr wp = cw(w.w1q + (size_t)((g * C::CK + j) * 2 + q) * 36);
             conv_rows<C::NR1, 2>(acc1, t + j * C::PLANE_P + bs1, C::PI, wp);
-            {   // edge part of this wave's 9 rows (18 lanes): same weights, already in SGPRs
+            if (!(kExp & 2)) {   // edge part of this wave's 9 rows (18 lanes): same weights, already in SGPRs
                 const float* xe = t + j * C::PLANE_P + bse;
                 float xv[9];
 #pragma unroll
@@ -251,6 +259,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
             for (int c = 0; c < 2; ++c) put(acce[c], 2 * q + c, mrow, mcol, mk);
         }
     }
+    if (kExp & 4) return;
     // ---- conv2: output rows 4 wave .. 4 wave + 3, column x0 + lane ----
     const int yb = y0 + C::NR2 * wave, ox = x0 + lane;
     const long plane = (long)H * W;
