@@ -33,13 +33,27 @@ def weight_names(depth: int = 4) -> list:
     return names + ["outc.conv.weight", "outc.conv.bias"]
 
 
-def pack_weights(state: dict, depth: int = 4, activation: str = "prelu") -> np.ndarray:
+def pack_weights(state: dict, depth: int = 4, activation: str = "prelu", state_depth: Optional[int] = None) -> np.ndarray:
     """Flatten a HybridNet state_dict (tensors or arrays) into the fp32 blob of hn_load_weights.
     Parameter-free activations (relu / leakyrelu) get their constant slope written where the
-    PReLU weight would be, so the blob layout never changes."""
+    PReLU weight would be, so the blob layout never changes.
+
+    ``state_depth < depth`` (architectures.py:353, ``use_state = d < state_depth``): the kernels always run the stateful
+    layout, so an encoder level WITHOUT state is packed as its exact stateful equivalent -- conv_signal's first
+    convolution [8, 8, 3, 3] gets two all-zero input channels where the state would be concatenated (their products are
+    exact zeros), and the missing conv_state becomes an all-zero DoubleConv; the host leaves that level's state slice
+    untouched (HybridNet.adopt_states)."""
     const_slope = {"relu": 0.0, "leakyrelu": 0.01, "celu": 0.0, "tanh": 0.0, "gelu": 0.0, "tanhshrink": 0.0, "softplus": 0.0}
+    state_depth = depth if state_depth is None else state_depth
+    stateless = {f"enc.{d}." for d in range(state_depth, depth)}
+    zero_state_dc = {"0.weight": (2, 10, 3, 3), "0.bias": (2,), "2.weight": (2, 2, 3, 3), "2.bias": (2,)}
     parts = []
     for name in weight_names(depth):
+        level = name[: name.index(".", 4) + 1] if name.startswith("enc.") else None
+        if level in stateless and ".conv_state." in name:
+            tail = name.split(".double_conv.")[1]
+            parts.append(np.full(1, 0.25, np.float32) if tail == "1.weight" else np.zeros(int(np.prod(zero_state_dc[tail])), np.float32))
+            continue
         if name.endswith(".double_conv.1.weight") and name not in state:
             if activation.lower() not in const_slope:
                 raise KeyError(f"missing {name} for activation {activation!r}")
@@ -48,7 +62,11 @@ def pack_weights(state: dict, depth: int = 4, activation: str = "prelu") -> np.n
         v = state[name]
         if isinstance(v, torch.Tensor):
             v = v.detach().to("cpu", torch.float32).numpy()
-        parts.append(np.ascontiguousarray(v, dtype=np.float32).reshape(-1))
+        v = np.ascontiguousarray(v, dtype=np.float32)
+        if level in stateless and name.endswith(".conv_signal.double_conv.0.weight"):
+            assert v.shape[1] == 8, v.shape
+            v = np.concatenate([v, np.zeros((v.shape[0], 2, 3, 3), np.float32)], 1)
+        parts.append(v.reshape(-1))
     return np.concatenate(parts)
 
 

@@ -254,7 +254,7 @@ class IterativeSolver(nn.Module):
         res = residual.detach().float().clone().contiguous()
         st = self.f.get_states(flatten=True).float().contiguous().clone()
         eng.step(wf, res, st, k_sq.float().contiguous(), self._src(), 1)
-        self.f.set_states(st, flatten=True)
+        self.f.adopt_states(st)
         return (wf, res) if get_residual else wf
 
     # ------------------------------------------------------------------ loops ------------
@@ -278,7 +278,7 @@ class IterativeSolver(nn.Module):
         rmse = torch.empty((K, b), device=dev, dtype=torch.float32) if K > 0 else None
         if K > 0:
             eng.step(wf, res, st, k_sq, self._src(), K, res_hist, wf_hist, st_hist, rmse)
-        self.f.set_states(st, flatten=True)
+        self.f.adopt_states(st)
         out = {
             "wavefields": list(wf_hist.unbind(0)) if wf_hist is not None else [wf],
             "residuals": list(res_hist.unbind(0)) if res_hist is not None else ([res] if residuals == "last" else []),

@@ -75,12 +75,12 @@ class DoubleConv(_ContainerOnly):
 class EncoderBlock(_ContainerOnly):
     def __init__(self, num_features: int, state_size=2, activation_function="prelu", use_state=True, domain_size=0):
         super().__init__()
-        if not use_state:
-            raise NotImplementedError("state_depth < depth is not implemented by the HIP kernels")
         self.state_size, self.use_state, self.domain_size, self.num_features = state_size, use_state, domain_size, num_features
-        self.conv_signal = DoubleConv(num_features + state_size, num_features, activation_fun=activation_function)
+        # architectures.py:202-218: without state conv_signal sees the features only and there is no conv_state
+        self.conv_signal = DoubleConv(num_features + state_size * use_state, num_features, activation_fun=activation_function)
         self.down = nn.Conv2d(num_features, num_features, kernel_size=8, padding=3, stride=2)
-        self.conv_state = DoubleConv(num_features + state_size, state_size, activation_fun=activation_function)
+        if use_state:
+            self.conv_state = DoubleConv(num_features + state_size, state_size, activation_fun=activation_function)
         self.state: Optional[torch.Tensor] = None
 
     def set_state(self, state):
@@ -99,8 +99,8 @@ class HybridNet(nn.Module):
         super().__init__()
         if features != 8 or state_channels != 2 or inchannels != 6:
             raise NotImplementedError("HIP kernels are built for features=8, state_channels=2, inchannels=6")
-        if state_depth != depth:
-            raise NotImplementedError("HIP kernels require state_depth == depth")
+        if not 0 <= state_depth <= depth:
+            raise ValueError(f"state_depth {state_depth} outside [0, depth = {depth}]")
         self.activation_function, self.depth, self.domain_size = activation_function, depth, domain_size
         self.features, self.inchannels = features, inchannels
         self.state_channels, self.state_depth = state_channels, state_depth
@@ -142,6 +142,14 @@ class HybridNet(nn.Module):
         for enc, state in zip(self.enc[: len(h)], h):
             enc.set_state(state)
 
+    def adopt_states(self, new_flat):
+        """Store the flat hidden state the library returned.  Levels without state (d >= state_depth) keep what they had:
+        the reference never touches them (EncoderBlock.forward, architectures.py:250-251)."""
+        h = self.unflatten_state(new_flat)
+        for d, enc in enumerate(self.enc):
+            if enc.use_state:
+                enc.set_state(h[d])
+
     def flatten_state(self, h_list):
         return torch.cat([x.reshape(x.shape[0], x.shape[1], -1) for x in h_list], 2)
 
@@ -169,7 +177,7 @@ class HybridNet(nn.Module):
         key = self.weights_key()
         if engine.weights_key != key:
             sd = {k: v for k, v in self.state_dict().items()}
-            engine.load_weights(pack_weights(sd, self.depth, self.activation_function), self.features, self.depth,
+            engine.load_weights(pack_weights(sd, self.depth, self.activation_function, self.state_depth), self.features, self.depth,
                                 self.state_channels, self.activation_function)
             engine.weights_key = key
 
@@ -193,5 +201,5 @@ class HybridNet(nn.Module):
         eng = self._get_engine(x.device)
         flat = self.get_states(flatten=True).contiguous()
         d, new_flat = eng.unet(x.contiguous(), flat)
-        self.set_states(new_flat, flatten=True)
+        self.adopt_states(new_flat)
         return d

@@ -268,12 +268,21 @@ def unflatten_states(flat: Tensor, n: int, depth: int) -> List[Tensor]:
     return out
 
 
-def unet_forward(x6: Tensor, states: List[Tensor], w: Dict[str, Tensor], depth: int = 4, act: str = "prelu") -> Tuple[Tensor, List[Tensor]]:
+def unet_forward(x6: Tensor, states: List[Tensor], w: Dict[str, Tensor], depth: int = 4, act: str = "prelu",
+                 state_depth: int = None) -> Tuple[Tensor, List[Tensor]]:
     """helmnet/architectures.py:439-465 (HybridNet.forward) with
-    EncoderBlock.forward (:240-252) inlined.  Returns (d, new_states)."""
+    EncoderBlock.forward (:240-252) inlined; levels d >= state_depth run without state (:250-251) and keep
+    whatever their state slot held.  Returns (d, new_states)."""
+    state_depth = depth if state_depth is None else state_depth
     x = double_conv(x6, w, "inc", act)
     skips, new_states = [], []
     for d in range(depth):
+        if d >= state_depth:
+            out = double_conv(x, w, f"enc.{d}.conv_signal", act)
+            new_states.append(states[d])
+            skips.append(out)
+            x = F.conv2d(out, w[f"enc.{d}.down.weight"], w[f"enc.{d}.down.bias"], stride=2, padding=3)
+            continue
         out = double_conv(torch.cat([x, states[d]], 1), w, f"enc.{d}.conv_signal", act)
         new_states.append(double_conv(torch.cat([out, states[d]], 1), w, f"enc.{d}.conv_state", act))
         skips.append(out)

@@ -76,6 +76,52 @@ def test_oracle_parameter_free_activations_vs_reference_fixture(g_r2, weights, a
     assert (O.flatten_states(st) - torch.from_numpy(g_r2[f"{act}_states"])).abs().max().item() <= 1e-5 * np.abs(g_r2[f"{act}_states"]).max()
 
 
+@pytest.fixture(scope="module")
+def g_sd():
+    with np.load(os.path.join(REPO, "tests", "golden", "r2_state_depth.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _sd_weights(g_sd):
+    return {k[3:]: torch.from_numpy(v) for k, v in g_sd.items() if k.startswith("sd_")}
+
+
+def _sd_bounds(n=64, depth=4):
+    o, b = 0, []
+    for d in range(depth):
+        b.append((o, o + (n >> d) ** 2))
+        o += (n >> d) ** 2
+    return b
+
+
+def test_oracle_state_depth_below_depth_vs_reference_fixture(g_sd):
+    """architectures.py:203,212,250-251 (EncoderBlock without state) on a random depth-4 / state_depth-2 network: two
+    consecutive reference passes; levels 2, 3 keep the (non-zero) values their slots were preset to."""
+    w = _sd_weights(g_sd)
+    assert w["enc.2.conv_signal.double_conv.0.weight"].shape[1] == 8 and "enc.2.conv_state.double_conv.0.weight" not in w
+    st = O.unflatten_states(torch.from_numpy(g_sd["st0"]), 64, 4)
+    for x, want_d, want_s in ((g_sd["x1"], g_sd["d1"], g_sd["s1"]), (g_sd["x2"], g_sd["d2"], g_sd["s2"])):
+        d, st = O.unet_forward(torch.from_numpy(x), st, w, state_depth=2)
+        assert (d - torch.from_numpy(want_d)).abs().max().item() <= 1e-5 * np.abs(want_d).max()
+        assert (O.flatten_states(st) - torch.from_numpy(want_s)).abs().max().item() <= 1e-5 * np.abs(want_s).max()
+    a = _sd_bounds()[2][0]
+    assert np.array_equal(g_sd["s2"][:, :, a:], g_sd["st0"][:, :, a:])   # the reference never touched the stateless slots
+
+
+def test_stateless_levels_are_packed_as_their_exact_stateful_equivalent(g_sd):
+    from helmnet_amd.engine import pack_weights, weight_names
+    w = _sd_weights(g_sd)
+    blob = pack_weights(w, 4, "prelu", state_depth=2)
+    full = pack_weights({**{k: torch.zeros(s) for k, s in (("enc.%d.conv_state.double_conv.%s" % (d, t), sh) for d in (2, 3) for t, sh in
+                                                          (("0.weight", (2, 10, 3, 3)), ("0.bias", (2,)), ("1.weight", (1,)), ("2.weight", (2, 2, 3, 3)), ("2.bias", (2,))))},
+                         **{k: (torch.cat([v, torch.zeros(8, 2, 3, 3)], 1) if k in ("enc.2.conv_signal.double_conv.0.weight", "enc.3.conv_signal.double_conv.0.weight") else v)
+                            for k, v in w.items()}}, 4, "prelu")
+    assert blob.shape == full.shape
+    assert len(weight_names(4)) == 88
+    diff = np.flatnonzero(blob != full)
+    assert diff.size == 2   # only the two (irrelevant) PReLU slopes of the all-zero conv_state stand-ins differ (0.25 vs 0)
+
+
 def test_explicit_operator_is_the_oracle_operator():
     """The assembled float64 system matrix (matlab/spectral_gmres_solver.m:50-90 construction) applies the same
     operator as the FFT formulation of spectral.py:31-79."""
@@ -112,6 +158,25 @@ def test_gpu_parameter_free_activations_vs_reference_fixture(g_r2, weights, act)
     d = net(torch.from_numpy(g_r2["act_input"]).to(DEV)).cpu().numpy()
     assert np.abs(d - g_r2[f"{act}_d"]).max() <= 1e-5 * np.abs(g_r2[f"{act}_d"]).max()
     assert np.abs(net.get_states(flatten=True).cpu().numpy() - g_r2[f"{act}_states"]).max() <= 1e-5 * np.abs(g_r2[f"{act}_states"]).max()
+
+
+@pytest.mark.gpu
+def test_gpu_state_depth_below_depth_vs_reference_fixture(g_sd):
+    """HybridNet(state_depth=2) through the C ABI (the stateless levels run as their zero-padded stateful equivalent,
+    engine.pack_weights) against the reference's two passes."""
+    from helmnet_amd import HybridNet
+    net = HybridNet("prelu", 4, 64, 8, 6, 2, 2)
+    res = net.load_state_dict(_sd_weights(g_sd), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys and not hasattr(net.enc[2], "conv_state")
+    net.to(DEV)
+    net.set_states(torch.from_numpy(g_sd["st0"]).to(DEV), flatten=True)
+    for x, want_d, want_s in ((g_sd["x1"], g_sd["d1"], g_sd["s1"]), (g_sd["x2"], g_sd["d2"], g_sd["s2"])):
+        d = net(torch.from_numpy(x).to(DEV)).cpu().numpy()
+        assert np.abs(d - want_d).max() <= 1e-5 * np.abs(want_d).max()
+        got_s = net.get_states(flatten=True).cpu().numpy()
+        assert np.abs(got_s - want_s).max() <= 1e-5 * np.abs(want_s).max()
+    a = _sd_bounds()[2][0]
+    assert np.array_equal(got_s[:, :, a:], g_sd["st0"][:, :, a:])
 
 
 @pytest.mark.gpu
