@@ -22,7 +22,7 @@ HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2, "celu": 3, "tanh": 4, "gelu": 5
 HN_PRECISION = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16x2": 3, "valu": 4}
 HN_OPTION = {"lanes": 0, "side_stream": 1, "graph": 2, "deep": 3, "spectral_pfa": 4, "spectral_radix16": 5, "dc_valu": 6}
 HN_COUNTER = {"graph_replays": 0, "eager_iterations": 1, "graphs_captured": 2}
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); every symbol include/helmnet_hip.h declares
 SYMBOLS = {
@@ -44,6 +44,9 @@ SYMBOLS = {
     "hn_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "hn_rmse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "hn_unet": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "hn_double_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_float), c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "hn_conv8x8": (c_int, [c_void_p, c_void_p, POINTER(c_float), c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "hn_out_conv": (c_int, [c_void_p, c_void_p, POINTER(c_float), c_void_p, c_int, c_int, c_int, c_void_p]),
     "hn_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hn_profile_enable": (c_int, [c_void_p, ctypes.c_uint64]),

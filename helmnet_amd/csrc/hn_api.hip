@@ -90,6 +90,22 @@ struct Packer {
     }
 };
 
+// pack host weights (PyTorch layout) with `fill`, upload them, run `go` on the stream, wait, free
+template <typename Fill, typename Go>
+int with_temp_weights(hn_ctx* ctx, size_t n_floats, hipStream_t s, Fill fill, Go go) {
+    DeviceGuard guard(ctx);
+    float* dev = nullptr;
+    HN_HIP(ctx, hipMalloc((void**)&dev, n_floats * sizeof(float)));
+    std::vector<float> packed(n_floats);
+    fill(packed, dev);
+    int rc = HN_OK;
+    if (hipMemcpy(dev, packed.data(), n_floats * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, HN_ERR_HIP, "weight upload failed");
+    if (rc == HN_OK) rc = go();
+    (void)hipStreamSynchronize(s);   // the temporary weights must outlive the kernels
+    (void)hipFree(dev);
+    return rc;
+}
+
 void free_workspace(hn_ctx* c) {
     for (int d = 0; d <= kMaxDepth; ++d) {
         (void)hipFree(c->buf_a[d]); c->buf_a[d] = nullptr;
@@ -502,6 +518,42 @@ int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states
     const Src res{in6 + 2 * plane, kInCh * plane, plane, 1.f};
     const Src sig{in6 + 4 * plane, kInCh * plane, plane, 1.f};
     return unet_forward(ctx, wf, res, sig, states_in, states_out, d_out, nullptr, batch, (hipStream_t)stream);
+}
+
+int hn_double_conv(hn_ctx* ctx, const float* x, int cin, int cout, const float* weights_host, int act_kind, float* out,
+                   int batch, int h, int w, void* stream) {
+    if (!ctx || !x || !weights_host || !out) return fail(ctx, HN_ERR_ARG, "hn_double_conv: NULL argument");
+    if (batch < 1 || h < 1 || w < 1) return fail(ctx, HN_ERR_ARG, "hn_double_conv: batch, h, w must be positive");
+    if (act_kind < HN_ACT_PRELU || act_kind > HN_ACT_SOFTPLUS) return fail(ctx, HN_ERR_UNSUPPORTED, "activation kind %d is not implemented", act_kind);
+    const bool ok = (cout == kFeat && (cin == kInCh || cin == kFeat || cin == kFeat + kState || cin == 2 * kFeat)) || (cout == kState && cin == kFeat + kState);
+    if (!ok) return fail(ctx, HN_ERR_UNSUPPORTED, "hn_double_conv: (cin, cout) = (%d, %d) is not one of (6,8) (8,8) (10,8) (16,8) (10,2)", cin, cout);
+    DcW dw;
+    return with_temp_weights(ctx, dc_count(cin, cout, cout), (hipStream_t)stream,
+        [&](std::vector<float>& packed, float* dev) { Packer p{weights_host, packed, dev, act_kind}; dw = p.dc(cin, cout, cout); },
+        [&]() { return module_double_conv(ctx, x, cin, cout, dw, out, batch, h, w, (hipStream_t)stream); });
+}
+
+int hn_conv8x8(hn_ctx* ctx, const float* x, const float* weights_host, int transposed, float* out, int batch, int h, int w, void* stream) {
+    if (!ctx || !x || !weights_host || !out) return fail(ctx, HN_ERR_ARG, "hn_conv8x8: NULL argument");
+    if (batch < 1 || h < 1 || w < 1) return fail(ctx, HN_ERR_ARG, "hn_conv8x8: batch, h, w must be positive");
+    if (!transposed && ((h | w) & 1)) return fail(ctx, HN_ERR_UNSUPPORTED, "hn_conv8x8: the stride-2 convolution needs even h, w (got %d, %d)", h, w);
+    K8W kw;
+    return with_temp_weights(ctx, k8_count(), (hipStream_t)stream,
+        [&](std::vector<float>& packed, float* dev) { Packer p{weights_host, packed, dev, HN_ACT_PRELU}; kw = p.k8(transposed != 0); },
+        [&]() { return module_conv8x8(ctx, x, kw, transposed != 0, out, batch, h, w, (hipStream_t)stream); });
+}
+
+int hn_out_conv(hn_ctx* ctx, const float* x, const float* weights_host, float* out, int batch, int h, int w, void* stream) {
+    if (!ctx || !x || !weights_host || !out) return fail(ctx, HN_ERR_ARG, "hn_out_conv: NULL argument");
+    if (batch < 1 || h < 1 || w < 1) return fail(ctx, HN_ERR_ARG, "hn_out_conv: batch, h, w must be positive");
+    const float *dw = nullptr, *db = nullptr;
+    return with_temp_weights(ctx, 2 * kFeat + 2, (hipStream_t)stream,
+        [&](std::vector<float>& packed, float* dev) {
+            repack_oihw(weights_host, packed.data(), 2, kFeat, 1);   // [2][8] -> [8][2]
+            packed[2 * kFeat] = weights_host[2 * kFeat]; packed[2 * kFeat + 1] = weights_host[2 * kFeat + 1];
+            dw = dev; db = dev + 2 * kFeat;
+        },
+        [&]() { return module_out_conv(ctx, x, dw, db, out, batch, h, w, (hipStream_t)stream); });
 }
 
 }  // extern "C" (continued below)

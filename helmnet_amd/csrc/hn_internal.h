@@ -274,4 +274,9 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                  float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off = 0, hipEvent_t after_down0 = nullptr,
                  hn_ctx::SideLane* side_lane = nullptr);
 
+// standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv): fp32 vector kernels of hn_unet.hip on packed device weights
+int module_double_conv(hn_ctx* ctx, const float* x, int cin, int cout, const DcW& w, float* out, int batch, int H, int W, hipStream_t s);
+int module_conv8x8(hn_ctx* ctx, const float* x, const K8W& w, bool transposed, float* out, int batch, int H, int W, hipStream_t s);
+int module_out_conv(hn_ctx* ctx, const float* x, const float* w_io, const float* b, float* out, int batch, int H, int W, hipStream_t s);
+
 }  // namespace hn

@@ -553,4 +553,65 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     return HN_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv): the direct fp32 kernels above on one NCHW tensor.  The
+// input channels of x are handed to the DoubleConv kernel as the 2 or 3 channel groups its instances are built for.
+// ------------------------------------------------------------------------------------------
+namespace {
+__global__ void k_out_conv(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+                           long plane, long total) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;   // (b, pixel)
+    if (i >= total) return;
+    const long b = i / plane, p = i - b * plane;
+    const float* xp = x + b * kFeat * plane + p;
+    float a0 = bias[0], a1 = bias[1];
+#pragma unroll
+    for (int c = 0; c < kFeat; ++c) {
+        const float v = xp[c * plane];
+        a0 = fmaf(w[c * 2], v, a0);        // w re-packed [8][2]
+        a1 = fmaf(w[c * 2 + 1], v, a1);
+    }
+    out[b * 2 * plane + p] = a0;
+    out[(b * 2 + 1) * plane + p] = a1;
+}
+}  // namespace
+
+int module_double_conv(hn_ctx* ctx, const float* x, int cin, int cout, const DcW& w, float* out, int batch, int H, int W, hipStream_t s) {
+    const long plane = (long)H * W;
+    const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
+    const Src none{nullptr, 0, 0, 1.f};
+    auto view = [&](int c0) { return Src{x + c0 * plane, cin * plane, plane, 1.f}; };
+    const Dst o{out, cout * plane, plane};
+    if (cin == 6 && cout == kFeat) launch_dc<2, 2, 2, kFeat, kFeat, 0>(view(0), view(2), view(4), o, w, noepi, H, W, batch, s);
+    else if (cin == kFeat && cout == kFeat) launch_dc<kFeat, 0, 0, kFeat, kFeat, 0>(view(0), none, none, o, w, noepi, H, W, batch, s);
+    else if (cin == kFeat + kState && cout == kFeat) launch_dc<kFeat, kState, 0, kFeat, kFeat, 0>(view(0), view(kFeat), none, o, w, noepi, H, W, batch, s);
+    else if (cin == 2 * kFeat && cout == kFeat) launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 0>(view(0), view(kFeat), none, o, w, noepi, H, W, batch, s);
+    else if (cin == kFeat + kState && cout == kState) launch_dc<kFeat, kState, 0, kState, kState, 0>(view(0), view(kFeat), none, o, w, noepi, H, W, batch, s);
+    else return fail(ctx, HN_ERR_UNSUPPORTED, "hn_double_conv: (cin, cout) = (%d, %d) is not one of (6,8) (8,8) (10,8) (16,8) (10,2)", cin, cout);
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int module_conv8x8(hn_ctx* ctx, const float* x, const K8W& w, bool transposed, float* out, int batch, int H, int W, hipStream_t s) {
+    const long pin = (long)H * W;
+    const Src in{x, kFeat * pin, pin, 1.f};
+    if (!transposed) {
+        const long po = (long)(H / 2) * (W / 2);
+        hipLaunchKernelGGL(k_down8x8, dim3(cdiv(W / 2, DownCfg::TW), cdiv(H / 2, DownCfg::TH), batch), dim3(DownCfg::NT), 0, s, in,
+                           Dst{out, kFeat * po, po}, w, H, W);
+    } else {
+        const long po = 4 * pin;
+        hipLaunchKernelGGL(k_up8x8, dim3(cdiv(W, UpCfg::TW), cdiv(H, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s, in, Dst{out, kFeat * po, po}, w, H, W);
+    }
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int module_out_conv(hn_ctx* ctx, const float* x, const float* w_io, const float* b, float* out, int batch, int H, int W, hipStream_t s) {
+    const long plane = (long)H * W, total = plane * batch;
+    hipLaunchKernelGGL(k_out_conv, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w_io, b, out, plane, total);
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
 }  // namespace hn

@@ -70,6 +70,18 @@ def pack_weights(state: dict, depth: int = 4, activation: str = "prelu", state_d
     return np.concatenate(parts)
 
 
+_MODULE_ENGINES: dict = {}
+
+
+def module_engine(device) -> "Engine":
+    """One shared context per device for the standalone sub-module forwards (DoubleConv / OutConv / EncoderBlock called directly)."""
+    dev = torch.device(device)
+    dev = torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device()) if dev.type == "cuda" else dev
+    if dev not in _MODULE_ENGINES:
+        _MODULE_ENGINES[dev] = Engine(dev)
+    return _MODULE_ENGINES[dev]
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -204,6 +216,54 @@ class Engine:
         rc = self.lib.hn_unet(self.ctx, _ptr(in6), _ptr(states_in), _ptr(states_out), _ptr(d), b, self._stream())
         _lib.check(rc, self.ctx, "hn_unet")
         return d, states_out
+
+    # ---- standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv; utility paths, weights re-packed per call) ----
+    @staticmethod
+    def _host_blob(parts) -> np.ndarray:
+        return np.ascontiguousarray(np.concatenate([np.asarray(p.detach().cpu() if isinstance(p, torch.Tensor) else p, np.float32).reshape(-1)
+                                                    for p in parts]))
+
+    def _plain(self, x: torch.Tensor, channels: int, name: str) -> torch.Tensor:
+        if not isinstance(x, torch.Tensor) or x.dim() != 4 or x.shape[1] != channels:
+            raise ValueError(f"{name}: expected a [B, {channels}, H, W] tensor, got {tuple(getattr(x, 'shape', ()))}")
+        if x.device != self.device:
+            raise ValueError(f"{name}: tensor on {x.device}, engine on {self.device}")
+        return x.float().contiguous()
+
+    def double_conv(self, x, w1, b1, slope, w2, b2, activation: str = "prelu") -> torch.Tensor:
+        """DoubleConv.forward (architectures.py:83-84) for the channel shapes of the UNet."""
+        cout, cin = int(w1.shape[0]), int(w1.shape[1])
+        x = self._plain(x, cin, "double_conv")
+        blob = self._host_blob([w1, b1, np.float32([slope]) if np.isscalar(slope) else slope, w2, b2])
+        out = torch.empty(x.shape[0], cout, x.shape[2], x.shape[3], device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            rc = self.lib.hn_double_conv(self.ctx, _ptr(x), cin, cout, blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)),
+                                         _lib.HN_ACT[activation.lower()], _ptr(out), x.shape[0], x.shape[2], x.shape[3], self._stream())
+        _lib.check(rc, self.ctx, "hn_double_conv")
+        return out
+
+    def conv8x8(self, x, weight, bias, transposed: bool) -> torch.Tensor:
+        """nn.Conv2d(8, 8, 8, stride=2, padding=3) / nn.ConvTranspose2d(8, 8, 8, stride=2, padding=3) of the UNet."""
+        x = self._plain(x, 8, "conv8x8")
+        b, _, h, w = x.shape
+        out = torch.empty(b, 8, 2 * h if transposed else h // 2, 2 * w if transposed else w // 2, device=self.device, dtype=torch.float32)
+        blob = self._host_blob([weight, bias])
+        with torch.cuda.device(self.device):
+            rc = self.lib.hn_conv8x8(self.ctx, _ptr(x), blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), int(bool(transposed)), _ptr(out),
+                                     b, h, w, self._stream())
+        _lib.check(rc, self.ctx, "hn_conv8x8")
+        return out
+
+    def out_conv(self, x, weight, bias) -> torch.Tensor:
+        """OutConv.forward (architectures.py:57-60): Conv2d(8, 2, 1)."""
+        x = self._plain(x, 8, "out_conv")
+        out = torch.empty(x.shape[0], 2, x.shape[2], x.shape[3], device=self.device, dtype=torch.float32)
+        blob = self._host_blob([weight, bias])
+        with torch.cuda.device(self.device):
+            rc = self.lib.hn_out_conv(self.ctx, _ptr(x), blob.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), _ptr(out), x.shape[0], x.shape[2],
+                                      x.shape[3], self._stream())
+        _lib.check(rc, self.ctx, "hn_out_conv")
+        return out
 
     def step(self, wf, res, states, k_sq, src, n_iter: int, res_hist=None, wf_hist=None, st_hist=None, rmse_hist=None):
         """n_iter solver iterations; wf, res, states updated in place."""

@@ -6,10 +6,11 @@ sub-module / parameter names (so the shipped checkpoint's ``f.*`` state_dict loa
 same state bookkeeping API (``clear_states / get_states / set_states / flatten_state /
 unflatten_state / init_by_size``, ``enc[d].state``, ``enc[d].domain_size``).
 
-The torch ``nn.Conv2d`` / ``nn.PReLU`` / ``nn.ConvTranspose2d`` objects below are PARAMETER
-CONTAINERS ONLY: they are never called.  ``HybridNet.forward`` hands the packed weights and the
-flat hidden state to libhelmnet_hip.so (``hn_unet``), which runs the whole network as fused
-HIP kernels; the per-iteration solver loop bypasses even that and uses ``hn_step``.
+The torch ``nn.Conv2d`` / ``nn.PReLU`` / ``nn.ConvTranspose2d`` objects below are PARAMETER CONTAINERS: they are never
+called.  ``HybridNet.forward`` hands the packed weights and the flat hidden state to libhelmnet_hip.so (``hn_unet``),
+which runs the whole network as fused HIP kernels; the per-iteration solver loop bypasses even that and uses
+``hn_step``.  ``DoubleConv`` / ``OutConv`` / ``EncoderBlock`` called on their own go through the library's standalone
+entry points (``hn_double_conv`` / ``hn_out_conv`` / ``hn_conv8x8``) for the channel shapes the UNet is made of.
 """
 from __future__ import annotations
 
@@ -18,7 +19,7 @@ from typing import List, Optional
 import torch
 import torch.nn as nn
 
-from .engine import Engine, pack_weights
+from .engine import Engine, module_engine, pack_weights
 
 _IMPLEMENTED = ("prelu", "relu", "leakyrelu", "celu", "tanh", "gelu", "tanhshrink", "softplus")
 
@@ -47,32 +48,43 @@ def getActivationFunction(act_function_name: str, features=None, end=False) -> n
     raise NotImplementedError("Unknown activation function {} (implemented: {})".format(act_function_name, _IMPLEMENTED))
 
 
-class _ContainerOnly(nn.Module):
-    def forward(self, *a, **k):  # pragma: no cover
-        raise RuntimeError(
-            f"{type(self).__name__} only holds parameters; run the network through HybridNet.forward "
-            "(libhelmnet_hip.so) -- there is no PyTorch compute path in helmnet_amd"
-        )
+_ACT_CONST_SLOPE = {"relu": 0.0, "leakyrelu": 0.01}
 
 
-class OutConv(_ContainerOnly):
+class OutConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size=1)
 
+    def forward(self, x):
+        """architectures.py:57-60, through hn_out_conv (8 -> 2 channels, the shape the UNet uses)."""
+        if tuple(self.conv.weight.shape[:2]) != (2, 8):
+            raise NotImplementedError("OutConv runs on the HIP library for 8 -> 2 channels only")
+        return module_engine(x.device).out_conv(x, self.conv.weight, self.conv.bias)
 
-class DoubleConv(_ContainerOnly):
+
+class DoubleConv(nn.Module):
     def __init__(self, in_channels: int, out_channels: int, mid_channels=None, activation_fun="relu"):
         super().__init__()
         mid_channels = out_channels if mid_channels is None else mid_channels
+        self.activation_fun = activation_fun
         self.double_conv = nn.Sequential(
             nn.Conv2d(in_channels, mid_channels, kernel_size=3, padding=1),
             getActivationFunction(activation_fun, mid_channels),
             nn.Conv2d(mid_channels, out_channels, kernel_size=3, padding=1),
         )
 
+    def forward(self, x):
+        """architectures.py:83-84, through hn_double_conv (channel shapes of the UNet: 6/8/10/16 -> 8 -> 8 and 10 -> 2 -> 2)."""
+        c1, act, c2 = self.double_conv[0], self.double_conv[1], self.double_conv[2]
+        if c1.out_channels != c2.out_channels:
+            raise NotImplementedError("DoubleConv runs on the HIP library with mid_channels == out_channels only")
+        name = self.activation_fun.lower()
+        slope = act.weight if isinstance(act, nn.PReLU) else _ACT_CONST_SLOPE.get(name, 0.0)
+        return module_engine(x.device).double_conv(x, c1.weight, c1.bias, slope, c2.weight, c2.bias, name)
 
-class EncoderBlock(_ContainerOnly):
+
+class EncoderBlock(nn.Module):
     def __init__(self, num_features: int, state_size=2, activation_function="prelu", use_state=True, domain_size=0):
         super().__init__()
         self.state_size, self.use_state, self.domain_size, self.num_features = state_size, use_state, domain_size, num_features
@@ -91,6 +103,17 @@ class EncoderBlock(_ContainerOnly):
 
     def clear_state(self, x):
         self.state = torch.zeros([x.shape[0], 2, self.domain_size, self.domain_size], device=x.device)
+
+    def forward(self, x):
+        """architectures.py:240-252 on the library's standalone entry points (hn_double_conv, hn_conv8x8)."""
+        if self.use_state:
+            if self.state is None:
+                raise ValueError("You must set or clear the state before using this module")
+            output = self.conv_signal(torch.cat([x, self.state], 1))
+            self.state = self.conv_state(torch.cat([output, self.state], 1))
+        else:
+            output = self.conv_signal(x)
+        return output, module_engine(x.device).conv8x8(output, self.down.weight, self.down.bias, transposed=False)
 
 
 class HybridNet(nn.Module):

@@ -79,7 +79,7 @@ enum hn_option {
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };
 
-#define HN_ABI_VERSION 2
+#define HN_ABI_VERSION 3
 int hn_abi_version(void);
 
 /* Create / destroy a context on HIP device `device_id`. */
@@ -146,6 +146,25 @@ int hn_rmse(hn_ctx* ctx, const float* res, float* rmse, int batch, void* stream)
  * Replaces HybridNet.forward + EncoderBlock.forward (architectures.py:439-465, 240-252). */
 int hn_unet(hn_ctx* ctx, const float* in6, const float* states_in, float* states_out, float* d_out,
             int batch, void* stream);
+
+/* The UNet's sub-modules on their own -- what DoubleConv.forward (architectures.py:83-84), the 8x8 stride-2 convolution /
+ * transposed convolution of an EncoderBlock / the decoder (:209-211, :375-382, as called in EncoderBlock.forward :252 and
+ * HybridNet.forward :456) and OutConv.forward (:57-60) compute, for the channel shapes the UNet is made of.  Utility
+ * entry points: the weights come as HOST pointers in PyTorch layout and are re-packed and uploaded by every call (the
+ * solver never uses them; hn_unet / hn_step run the whole network from the blob of hn_load_weights).  Tensors are
+ * device pointers, NCHW fp32; no domain or network needs to be loaded.
+ *   hn_double_conv  x[B,cin,H,W] -> out[B,cout,H,W];  (cin, cout) in {(6,8), (8,8), (10,8), (16,8), (10,2)}, mid = cout channels;
+ *                   weights = conv1.weight [cout,cin,3,3], conv1.bias [cout], slope [1] (PReLU weight, or the constant slope of
+ *                   relu / leakyrelu; ignored by the smooth activations), conv2.weight [cout,cout,3,3], conv2.bias [cout], concatenated
+ *   hn_conv8x8      transposed = 0: Conv2d(8, 8, 8, stride 2, padding 3), x[B,8,H,W] -> out[B,8,H/2,W/2] (H, W even), weights =
+ *                   weight [8,8,8,8] (out, in, kh, kw), bias [8];  transposed = 1: ConvTranspose2d(8, 8, 8, stride 2, padding 3),
+ *                   x[B,8,H,W] -> out[B,8,2H,2W], weight [8,8,8,8] (in, out, kh, kw), bias [8]
+ *   hn_out_conv     Conv2d(8, 2, 1): x[B,8,H,W] -> out[B,2,H,W], weights = weight [2,8], bias [2]                                  */
+int hn_double_conv(hn_ctx* ctx, const float* x, int cin, int cout, const float* weights_host, int act_kind, float* out,
+                   int batch, int h, int w, void* stream);
+int hn_conv8x8(hn_ctx* ctx, const float* x, const float* weights_host, int transposed, float* out, int batch, int h, int w,
+               void* stream);
+int hn_out_conv(hn_ctx* ctx, const float* x, const float* weights_host, float* out, int batch, int h, int w, void* stream);
 
 /* n_iter fused solver iterations (hybridnet.py:558-584 single_step, looped as in
  * forward :654-697 / n_steps :586-623):

@@ -357,6 +357,50 @@ def test_standalone_hybridnet_matches_oracle(weights):
     assert (net.get_states(flatten=True).cpu() - O.flatten_states(st)).abs().max().item() <= 1e-5
 
 
+def test_sub_modules_called_directly_match_the_oracle(weights):
+    """DoubleConv.forward / OutConv.forward / EncoderBlock.forward (architectures.py:57-60, 83-84, 240-252) and the transposed
+    8x8 convolution on the library's standalone entry points (hn_double_conv, hn_conv8x8, hn_out_conv), against the oracle's
+    layer functions on the shipped weights; odd sizes included (the direct kernels take any H, W)."""
+    import torch.nn.functional as F
+    from helmnet_amd import HybridNet
+    from helmnet_amd.engine import module_engine
+    net = HybridNet("prelu", 4, 64, 8, 6, 2, 4)
+    net.load_state_dict(weights)
+    g = torch.Generator().manual_seed(5)
+
+    def close(a, b, tol=1e-5):
+        return (a.cpu() - b).abs().max().item() <= tol * b.abs().max().item()
+
+    for h, w_ in ((64, 64), (37, 50)):
+        x6 = torch.randn(2, 6, h, w_, generator=g)
+        assert close(net.inc(x6.to(DEV)), O.double_conv(x6, weights, "inc"))                                  # 6 -> 8 -> 8
+        x16 = torch.randn(2, 16, h, w_, generator=g)
+        assert close(net.decode[1](x16.to(DEV)), O.double_conv(x16, weights, "decode.1"))                     # 16 -> 8 -> 8
+        x8 = torch.randn(2, 8, h, w_, generator=g)
+        assert close(net.decode[4](x8.to(DEV)), O.double_conv(x8, weights, "decode.4"))                       # 8 -> 8 -> 8
+        assert close(net.outc(x8.to(DEV)), F.conv2d(x8, weights["outc.conv.weight"], weights["outc.conv.bias"]))
+        up = module_engine(DEV).conv8x8(x8.to(DEV), weights["up.2.weight"], weights["up.2.bias"], transposed=True)
+        assert close(up, F.conv_transpose2d(x8, weights["up.2.weight"], weights["up.2.bias"], stride=2, padding=3))
+    # EncoderBlock.forward: conv_signal(cat[x, state]), state <- conv_state(cat[out, state]), (out, down(out))
+    x8 = torch.randn(2, 8, 32, 32, generator=g)
+    st = 0.1 * torch.randn(2, 2, 32, 32, generator=g)
+    enc = net.enc[1]
+    with pytest.raises(ValueError):
+        enc(x8.to(DEV))
+    enc.set_state(st.to(DEV))
+    out, down = enc(x8.to(DEV))
+    want_out = O.double_conv(torch.cat([x8, st], 1), weights, "enc.1.conv_signal")
+    want_st = O.double_conv(torch.cat([want_out, st], 1), weights, "enc.1.conv_state")
+    want_down = F.conv2d(want_out, weights["enc.1.down.weight"], weights["enc.1.down.bias"], stride=2, padding=3)
+    assert close(out, want_out) and close(enc.get_state(), want_st) and close(down, want_down)
+    # shapes outside the UNet's are refused by the library, loudly
+    from helmnet_amd.unet import DoubleConv
+    with pytest.raises(RuntimeError):
+        DoubleConv(4, 8, activation_fun="relu").to(DEV)(torch.zeros(1, 4, 16, 16, device=DEV))
+    with pytest.raises(RuntimeError):     # no CPU path
+        net.inc(torch.zeros(1, 6, 16, 16))
+
+
 def test_fused_deep_level_kernel_matches_the_layer_by_layer_path(weights):
     """hn_deep.hip (conv_signal, conv_state, down, bottleneck, up, decoder of the 32 x 32 level in one per-sample LDS
     kernel) against the same layers launched one by one (HN_OPT_DEEP = 0) and against the oracle; N = 256 (depth 4) is
