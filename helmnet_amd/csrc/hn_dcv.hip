@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
 #define HN_EXP 0
 #endif
     // timing-only ablations (tools/build_variant.sh <name> hn_dcv.hip -DHN_EXP=<bits>; wrong results by construction):
-    // 1 no staging / barriers after the first chunk, 2 no edge columns, 4 no conv2, 32 no global loads after the first two chunks
+    // 1 no staging / barriers after the first chunk, 2 no edge columns, 4 no conv2, 8 no output stores, 32 no global loads after the first two chunks
     constexpr int kExp = HN_EXP;
     auto step = [&](int g, int buf, float2 (&stage)[C::CK][C::NL]) {   // chunk g: its loads were issued two chunks ago into `stage`
         if (!(kExp & 1) || g == 0) {
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
         __syncthreads();
 #pragma unroll 2
         for (int cm = 0; cm < kFeat; ++cm) conv_rows<C::NR2, 4>(acc2, mid + cm * C::MPLANE, C::PM, cw(w.w2 + cm * 72));
-        if (ox < W) {
+        if (ox < W && !((kExp & 8) && H > 0)) {   // (ablation 8: no output stores; a run-time condition, so that conv2 itself stays)
 #pragma unroll
             for (int r = 0; r < C::NR2; ++r) {
                 if (yb + r < H) {
