@@ -71,24 +71,28 @@ struct VcEpi {
 };
 
 // R output rows x 2 NP channels of a 3x3 convolution over one input channel: rows j = 0 .. R+1 at xc[j * pitch + 0..2]
-// (per-lane base); weights wp[t * NP + c] = channel pair c of tap t (wave-uniform -> SGPR pairs).  Two-stage pipeline
-// pinned with scheduling groups: the three dwords of row j + 1 are requested behind the first FMAs of row j (left
-// alone the compiler hoists all R + 2 row reads above the FMAs).
-struct NoHook { __device__ __forceinline__ void operator()() const {} };
-// `hook` runs together with the row reads of the middle step, i.e. behind an LDS wait and in front of 4 NP FMAs: scalar loads
-// issued there (next channel's weights) have a whole row of FMAs before the next wait -- LDS and scalar loads share one counter
-template <int R, int NP, typename WT, typename HK = NoHook>
-__device__ __forceinline__ void conv_rows(f32x2 (&acc)[R][NP], const float* xc, int pitch, const WT& wp, HK hook = HK()) {
-    float xn[3] = {xc[0], xc[1], xc[2]};
+// (per-lane base); weights wp[t * NP + c] = channel pair c of tap t (wave-uniform -> SGPR pairs).  Software pipeline pinned
+// with scheduling groups: the three dwords of row j + D are requested behind the first FMAs of row j (left alone the compiler
+// hoists all R + 2 row reads above the FMAs).
+#ifndef HN_ROWDEPTH
+#define HN_ROWDEPTH 1
+#endif
+template <int R, int NP>
+__device__ __forceinline__ void conv_rows(f32x2 (&acc)[R][NP], const float* xc, int pitch, CwPtr wp) {
+    constexpr int D = HN_ROWDEPTH < R + 2 ? HN_ROWDEPTH : 1;   // rows in flight ahead of the FMAs
+    float xq[D + 1][3];
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xq[d][i] = xc[d * pitch + i];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < R + 2; ++j) {
-        const float x0 = xn[0], x1 = xn[1], x2 = xn[2];
-        if (j + 1 < R + 2) {
+        const float x0 = xq[0][0], x1 = xq[0][1], x2 = xq[0][2];
+        if (j + D < R + 2) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) xn[i] = xc[(j + 1) * pitch + i];
+            for (int i = 0; i < 3; ++i) xq[D][i] = xc[(j + D) * pitch + i];
         }
-        if (j == R / 2) hook();
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int r = j - ky;
@@ -100,7 +104,11 @@ __device__ __forceinline__ void conv_rows(f32x2 (&acc)[R][NP], const float* xc, 
                 for (int c = 0; c < NP; ++c) acc[r][c] = __builtin_elementwise_fma(wp[(ky * 3 + kx) * NP + c], (f32x2){x, x}, acc[r][c]);
             }
         }
-        if (j + 1 < R + 2) {
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xq[d][i] = xq[d + 1][i];
+        if (j + D < R + 2) {
             __builtin_amdgcn_sched_group_barrier(0x002, NP, 0);  // VALU
             __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);   // DS read (ds_read2_b32 + ds_read_b32)
         }
