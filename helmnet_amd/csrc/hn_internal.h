@@ -51,7 +51,9 @@ struct TileId { int x, y, z; };
 __device__ __forceinline__ TileId xcd_tile() {
     const int gx = gridDim.x, gy = gridDim.y, total = gx * gy * (int)gridDim.z;
     int id = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+#ifndef HN_NO_XCD
     if ((total & 7) == 0) id = (id & 7) * (total >> 3) + (id >> 3);
+#endif
     const int q = id / gx;
     return TileId{id - q * gx, q % gy, q / gy};
 }
