@@ -309,8 +309,8 @@ def main():
                         "flops_per_launch": flops, "product_terms_per_flop": TERMS[prec],
                         "hbm_view": {"bytes_per_launch": hbm, "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(ach_b / HBM_PEAK_GBS, 4)}}
-                dc_valu = prec == "fp32" and n >= 256 and dict(kv.split("=", 1) for kv in args.opt).get("dc_valu", "1") != "0"
-                if dominant in ("decode0", "conv_signal0", "inc") and dc_valu:
+                dc_valu = int(dict(kv.split("=", 1) for kv in args.opt).get("dc_valu", "1")) if prec == "fp32" and n >= 256 else 0
+                if (dominant in ("decode0", "inc") and dc_valu >= 1) or (dominant == "conv_signal0" and dc_valu == 2):
                     # hn_dcv.hip: the level-0 DoubleConvs run on the packed fp32 VECTOR FMA, whose peak on gfx950 equals the
                     # fp32 matrix peak (157.3 TFLOP/s, 64 FLOP / clk / SIMD); "bound" keeps the schema's compute label
                     roof["pipe"] = "v_pk_fma_f32 (fp32 vector FMA; peak = fp32 MFMA peak)"

@@ -213,7 +213,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             break;
         case HN_OPT_DEEP: ctx->opt_deep = value != 0; break;
         case HN_OPT_SPECTRAL_PFA: ctx->opt_pfa = value != 0; break;
-        case HN_OPT_DC_VALU: ctx->opt_dc_valu = value != 0; break;
+        case HN_OPT_DC_VALU: ctx->opt_dc_valu = value < 0 ? 0 : value > 2 ? 2 : value; break;
         case HN_OPT_SPECTRAL_RADIX16: ctx->opt_radix16 = value < 0 ? 0 : value > 2 ? 2 : value; break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }

@@ -370,6 +370,14 @@ void pack_valu_q(const float* w, int cin, float* dst) {
 
 bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W) {
     if (ctx->precision != HN_PREC_FP32 || !ctx->opt_dc_valu) return false;
+    // HN_OPT_DC_VALU 1 (default): inc and the decoder on the vector pipe, conv_signal on the matrix core; 2: all three on the vector
+    // pipe.  [measured on four boxes, 3 x 300 steps each] all-vector 1808 / 1987 / 1873 / 1929 it/s, all-matrix 1884 / 1902 / 1904 /
+    // 1894, this mix 1887 / 1982 / 1925 / 1919: the packed-FMA kernels pull the shader clock down (median 2.22-2.30 GHz in the loop
+    // instead of a held 2.40, tools/clock_probe.py) by an amount that depends on the box, and every other kernel pays for it.
+    if (ctx->opt_dc_valu == 1 && kind == 1) return false;
+#ifdef HN_EXP_MFMA_KINDS
+    if ((HN_EXP_MFMA_KINDS >> kind) & 1) return false;   // A/B: these DoubleConv kinds stay on the matrix core
+#endif
     (void)act;
     const bool scaled = a.scale != 1.f || b.scale != 1.f || c.scale != 1.f;
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;

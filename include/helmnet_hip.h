@@ -71,8 +71,9 @@ enum hn_option {
                               * launch; even n <= 64: n iterations per graph                                          */
     HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
     HN_OPT_SPECTRAL_RADIX16 = 5, /* 0/1: 256-point lines as two register-resident radix-16 passes (default 1; 0: radix-4 kernels) */
-    HN_OPT_DC_VALU = 6,      /* 0/1: fp32 DoubleConvs of the big levels on the packed vector FMA (default 1: every FMA useful, same
-                              * peak as the fp32 MFMA whose 3x3 packing fills 75 % of its slots); 0: the fp32 MFMA kernels     */
+    HN_OPT_DC_VALU = 6,      /* fp32 DoubleConvs of the largest level (W >= 256) on the packed vector FMA (every FMA useful, same peak as the
+                              * fp32 MFMA, whose 3x3 packing fills 75 % of its slots): 0 none (matrix core), 1 inc and the decoder
+                              * (default; conv_signal stays on the matrix core: the vector kernels lower the sustained clock), 2 all three */
     HN_OPT_SPECTRAL_PFA = 4  /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k instead of the dense n x n operator (default 1;
                               * read by the next hn_set_domain)                                                     */
 };

@@ -447,7 +447,7 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
     from helmnet_amd import IterativeSolver
     ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=777).items()}
     outs = {}
-    for valu in (1, 0):
+    for valu in (2, 1, 0):   # all three level-0 DoubleConvs on the vector pipe / inc + decoder (the default) / none
         s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
         s.set_domain_size(n, source_location=SRC[n])
         s.engine().set_option("dc_valu", valu)
@@ -460,12 +460,13 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
     k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
     want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, SRC[n], 10.0), t)
     want = (want[0], want[1], O.flatten_states(want[2]))
-    for a, bb, w in zip(outs[1], outs[0], want):
+    for a2, a, bb, w in zip(outs[2], outs[1], outs[0], want):
         scale = w.abs().max().item()
-        assert (a - bb).abs().max().item() <= 4e-6 * scale
+        assert (a - bb).abs().max().item() <= 4e-6 * scale and (a2 - bb).abs().max().item() <= 4e-6 * scale
         assert (a - w).abs().max().item() <= 1e-5 * scale
+        assert (a2 - w).abs().max().item() <= 1e-5 * scale
         assert (bb - w).abs().max().item() <= 1e-5 * scale
-    assert not torch.equal(outs[1][0], outs[0][0])   # two different kernels did run
+    assert not torch.equal(outs[1][0], outs[0][0]) and not torch.equal(outs[2][0], outs[1][0])   # three different kernel sets did run
 
 
 def test_graph_replay_is_bit_identical_to_kernel_by_kernel_launches(solver):

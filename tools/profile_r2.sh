@@ -17,6 +17,7 @@ python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary > $O/be
 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --graph 1 > $O/bench_k300_graph1.json 2>/dev/null
 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --opt deep=0 > $O/bench_k300_nodeep.json 2>/dev/null
 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --opt dc_valu=0 > $O/bench_k300_mfma.json 2>/dev/null
+python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --opt dc_valu=2 > $O/bench_k300_allvalu.json 2>/dev/null
 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --size 512 --batch 16 --opt dc_valu=0 > $O/bench_512_mfma.json 2>/dev/null
 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-secondary --size 512 --batch 16 > $O/bench_512.json 2>/dev/null
 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-secondary --precision bf16x3 > $O/bench_bf16x3.json 2>/dev/null
