@@ -22,7 +22,7 @@ HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2, "celu": 3, "tanh": 4, "gelu": 5
 HN_PRECISION = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16x2": 3, "valu": 4}
 HN_OPTION = {"lanes": 0, "side_stream": 1, "graph": 2, "deep": 3, "spectral_pfa": 4, "spectral_radix16": 5, "dc_valu": 6}
 HN_COUNTER = {"graph_replays": 0, "eager_iterations": 1, "graphs_captured": 2}
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); every symbol include/helmnet_hip.h declares
 SYMBOLS = {
@@ -42,6 +42,7 @@ SYMBOLS = {
     "hn_reserve": (c_int, [c_void_p, c_int]),
     "hn_laplacian": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "hn_residual": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "hn_residual_vjp": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "hn_rmse": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "hn_unet": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "hn_double_conv": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_float), c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -49,6 +50,12 @@ SYMBOLS = {
     "hn_out_conv": (c_int, [c_void_p, c_void_p, POINTER(c_float), c_void_p, c_int, c_int, c_int, c_void_p]),
     "hn_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hn_train_reserve": (c_int, [c_void_p, c_int, c_int]),
+    "hn_train_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "hn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
+                             c_float, c_float, c_int64, c_void_p]),
+    "hn_train_peek": (c_int64, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "hn_profile_enable": (c_int, [c_void_p, ctypes.c_uint64]),
     "hn_profile_min": (c_int, [c_void_p, POINTER(ctypes.c_double), c_int]),
     "hn_profile_stride": (c_int, [c_void_p, c_int]),

@@ -239,6 +239,7 @@ void hn_destroy(hn_ctx* ctx) {
     if (ctx->cap_stream) (void)hipStreamDestroy(ctx->cap_stream);
     (void)hipFree(ctx->it_counter);
     free_workspace(ctx);
+    train_free(ctx);
     spec_free(ctx->tab);
     (void)hipFree(ctx->wdev);
     (void)hipFree(ctx->fragdev);
@@ -490,6 +491,13 @@ int hn_residual(hn_ctx* ctx, const float* wf, const float* k_sq, const float* sr
         return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
     DeviceGuard guard(ctx);
     return spec_apply(ctx, wf, res, k_sq, src, src_batch, batch, nullptr, (hipStream_t)stream);
+}
+
+int hn_residual_vjp(hn_ctx* ctx, const float* g, const float* k_sq, float* out, int batch, void* stream) {
+    if (!ctx || !g || !k_sq || !out) return fail(ctx, HN_ERR_ARG, "hn_residual_vjp: NULL argument");
+    if (batch <= 0) return fail(ctx, HN_ERR_ARG, "batch must be positive (got %d)", batch);
+    DeviceGuard guard(ctx);
+    return spec_adjoint(ctx, g, out, k_sq, nullptr, batch, (hipStream_t)stream);
 }
 
 int hn_rmse(hn_ctx* ctx, const float* res, float* rmse, int batch, void* stream) {

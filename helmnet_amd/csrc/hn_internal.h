@@ -94,6 +94,7 @@ struct SpecTables {
     float* k2_pfa = nullptr;
     // dense fallback (any other n): complex n x n operator, stored transposed
     float2* dense_t = nullptr; // dense_t[m*n + j] = M[j][m]
+    float2* dense_adj_t = nullptr; // the same for the adjoint operator M^H (training, hn_train.hip)
     float* sigmas = nullptr;   // [2, n, n]
 };
 
@@ -116,7 +117,7 @@ struct hn_ctx {
     const float *f_dec0c = nullptr, *dec0c_b = nullptr;   // decode[0] conv2 composed with the out-conv: [8][5][64] row-triple fragments, bias [2]
     const float* v_dec0c = nullptr;   // the same composed convolution for the vector-pipe kernel: [8 cm][3][3][2] (hn_dcv.hip)
     const float* f_st[hn::kMaxDepth][2]{};   // conv_state (2 output channels in rows 0..3 of M): [10][3][64], [2][3][64] (hn_deep.hip)
-    bool deep_attr_set = false, pfa_attr_set = false;
+    bool deep_attr_set = false, pfa_attr_set = false, pfa_adj_attr_set = false;
     // arithmetic of the UNet convolutions (hn_set_unet_precision; default from HN_UNET_IMPL at hn_create only)
     int precision = HN_PREC_FP32;
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
@@ -163,6 +164,22 @@ struct hn_ctx {
     long graph_clock = 0;
     hipStream_t cap_stream = nullptr;              // iterations are captured here (the caller's stream may be the legacy default stream)
     long graph_replays = 0, eager_iterations = 0, graphs_captured = 0;  // diagnostics (hn_get_counter)
+    // training workspace (hn_train.hip): activation tape of the unrolled iterations, gradient buffers, partial sums
+    struct TrainWs {
+        int batch = 0, n_unroll = 0, n = 0, depth = 0;
+        float* tape = nullptr;       // [n_unroll][step_floats]
+        size_t step_floats = 0;
+        size_t o_zinc = 0, o_x[hn::kMaxDepth + 1]{}, o_zsig[hn::kMaxDepth]{}, o_out[hn::kMaxDepth]{}, o_zst[hn::kMaxDepth]{},
+               o_u[hn::kMaxDepth]{}, o_zdec[hn::kMaxDepth + 1]{}, o_y[hn::kMaxDepth + 1]{};
+        float* gbuf = nullptr;       // gradient buffers, carved below
+        float *g_x[hn::kMaxDepth + 1]{}, *g_out[hn::kMaxDepth]{}, *g_u[hn::kMaxDepth]{}, *g_y[hn::kMaxDepth + 1]{};
+        float *gz = nullptr, *tmp8 = nullptr, *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
+        float* part = nullptr;       // per-block partial sums of the weight-gradient kernels
+        size_t part_floats = 0;
+        float* k8 = nullptr;         // 8x8 weights re-packed for the direct kernels: [depth][4][4096]
+        float* zero8 = nullptr;      // 8 zeros (bias of the backward-data convolutions)
+        float* sumsq = nullptr;      // [n_unroll][batch] per-sample sum of squared residuals
+    } tr;
     // optional per-kernel timing with HIP events on the caller's stream (hn_profile_*)
     uint64_t prof_mask = 0;
     int prof_stride = 1;          // bracket every prof_stride-th launch of a selected kernel
@@ -234,6 +251,10 @@ void spec_free(SpecTables& t);
 // captured iteration can then be replayed for every row of the RMSE history), else in row 0.
 int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, int src_batch,
                int batch, float* accum_sumsq, hipStream_t s, int* it_counter = nullptr, int sumsq_stride = 0);
+// out = L^H(g) + ksq * g [+ add]: the adjoint (conjugate transpose) of the residual operator, i.e. the vector-Jacobian product
+// of hn_residual with respect to the wavefield (training).  `add` may alias `out`.
+int spec_adjoint(hn_ctx* ctx, const float* g, float* out, const float* ksq, const float* add, int batch, hipStream_t s);
+void train_free(hn_ctx* ctx);   // hn_train.hip
 
 // ---- matrix-core kernels (hn_mfma.hip) ----
 void pack_frag_3x3(const float* w_oihw, int cin, float* dst);  // -> [cin][3][64]

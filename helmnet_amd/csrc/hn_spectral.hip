@@ -191,6 +191,30 @@ __device__ __forceinline__ void axis_operator(float2 (&v)[4], float2 (&acc)[4], 
     }
 }
 
+// The adjoint (conjugate transpose) of axis_operator, i.e. the vector-Jacobian product of the 1-D operator M = diag(a) D1 +
+// diag(b) D2 with D1 = F^-1 diag(i k) F, D2 = F^-1 diag(-k^2) F (training: hybridnet.py:385-413 backpropagates through
+// get_residual).  F^H = N F^-1, so D1^H = F^-1 diag(-i k) F and D2^H = D2:
+//     M^H g = F^-1 [ (-i k) F(conj(a) g) + (-k^2) F(conj(b) g) ]
+// two forward transforms in lock step, one inverse: the mirror image of the forward operator's pass structure.
+template <int N, int STRIDE>
+__device__ __forceinline__ void axis_adjoint(float2 (&v)[4], float2 (&acc)[4], float2* buf, int bstride, int j, const AxisTab<N>& t) {
+    float2 d[2][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        d[0][q] = cmul(make_float2(t.ca[q].x, -t.ca[q].y), v[q]);
+        d[1][q] = cmul(make_float2(t.cb[q].x, -t.cb[q].y), v[q]);
+    }
+    fft_pass<N, STRIDE, false, 2>(d, buf, bstride, j, t.tw);
+    float2 f[1][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)   // (-i k) (x + i y) = k y - i k x
+        f[0][q] = make_float2(t.k1[q] * d[0][q].y + t.k2[q] * d[1][q].x, -t.k1[q] * d[0][q].x + t.k2[q] * d[1][q].y);
+    fft_pass<N, STRIDE, true, 1>(f, buf, bstride, j, t.tw);
+    constexpr float inv_n = 1.0f / N;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = make_float2(f[0][q].x * inv_n, f[0][q].y * inv_n);
+}
+
 template <int N>
 struct RowCfg {
     static constexpr int T = N / 4;
@@ -212,9 +236,9 @@ struct ColCfg {
     static constexpr int CPW = (N >= 256 && N % (2 * C) == 0) ? 2 : 1;
 };
 
-template <int N, int C>
-__global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict__ wf, float* __restrict__ out,
-                                                          SpecPtrs t, int* __restrict__ it_counter) {
+template <int N, int C, bool ADJ = false>
+__global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict__ wf, float* out,
+                                                          SpecPtrs t, int* __restrict__ it_counter, const float* add = nullptr) {
     constexpr int T = N / 4, CPW = ColCfg<N, C>::CPW;
     __shared__ float2 buf[2 * N * C];
     const int c = threadIdx.x, j = threadIdx.y;
@@ -246,10 +270,16 @@ __global__ __launch_bounds__(C * N / 4) void k_spec_cols(const float* __restrict
         float2 v[4], acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = cur[q];
-        axis_operator<N, C>(v, acc, buf + c, N * C, j, tab);
+        if (ADJ) axis_adjoint<N, C>(v, acc, buf + c, N * C, j, tab);
+        else axis_operator<N, C>(v, acc, buf + c, N * C, j, tab);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long o = (long)(j + q * T) * N + i * C;
+            if (ADJ && add != nullptr) {   // `add` may alias `out`: each element is read and written by the same thread
+                const float* pa = add + (long)tl.y * 2 * plane + col0;
+                acc[q].x += pa[o];
+                acc[q].y += pa[o + plane];
+            }
             po[o] = acc[q].x;
             po[o + plane] = acc[q].y;
         }
@@ -282,14 +312,16 @@ struct RowOperands {  // everything one row still needs from HBM, requested in o
             if (flags & 1) part[q] = make_float2(po[x], po[plane + x]);
             if (flags & 2) {
                 kq[q] = ksq[(long)b * plane + ro + x];
-                const float* ps = src + (long)b * src_sb + ro + x;
-                sv[q] = make_float2(ps[0], ps[plane]);
+                if (src != nullptr) {
+                    const float* ps = src + (long)b * src_sb + ro + x;
+                    sv[q] = make_float2(ps[0], ps[plane]);
+                }
             }
         }
     }
 };
 
-template <int N>
+template <int N, bool ADJ = false>
 __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
     const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
     const float* __restrict__ src, long src_sb, SpecPtrs t, int flags, float* __restrict__ sumsq,
@@ -313,7 +345,8 @@ __global__ __launch_bounds__(RowCfg<N>::T* RowCfg<N>::R) void k_spec_rows(
         float2 v[4], acc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) v[q] = cur.u[q];
-        axis_operator<N, 1>(v, acc, buf + ry * N, N * R, j, tab);
+        if (ADJ) axis_adjoint<N, 1>(v, acc, buf + ry * N, N * R, j, tab);
+        else axis_operator<N, 1>(v, acc, buf + ry * N, N * R, j, tab);
         float* po = out + (long)b * 2 * plane + (long)row * N;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -721,12 +754,12 @@ struct PfaConst {
     float2 wp[P];       // exp(-2 pi i m / P); the output map k(k1, k2) is baked into the k tables on the host
 };
 
-template <int Q, int P, int AXIS>
-__global__ void k_spec_pfa(const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
+template <int Q, int P, int AXIS, bool ADJ = false>
+__global__ void k_spec_pfa(const float* __restrict__ wf, float* out, const float* __restrict__ ksq,
                            const float* __restrict__ src, long src_sb, const float2* __restrict__ tw_q,
                            const float* __restrict__ k1p, const float* __restrict__ k2p, const float2* __restrict__ ca,
                            const float2* __restrict__ cb, PfaConst<P> pc, int lines_per_block, int flags,
-                           float* __restrict__ sumsq, const int* __restrict__ it_counter, int sumsq_stride) {
+                           float* __restrict__ sumsq, const int* __restrict__ it_counter, int sumsq_stride, const float* add = nullptr) {
     constexpr int N = P * Q, T = Q / 4;
     extern __shared__ float2 pbuf[];                       // [line][2 P][Q]
     // AXIS 0: consecutive threads walk along the line; AXIS 1: consecutive threads own consecutive columns (coalescing)
@@ -751,34 +784,56 @@ __global__ void k_spec_pfa(const float* __restrict__ wf, float* __restrict__ out
             const long o = (long)pos[s][t] * lstride;
             u[s][t] = make_float2(pre[o], pre[o + plane]);
         }
+    float2 d[2 * P][4];   // forward operator: the two derivative spectra on their way back; adjoint: the two weighted inputs on their way in
     float2 f[P][4];
+    if (!ADJ) {
 #pragma unroll
-    for (int s = 0; s < P; ++s)
+        for (int s = 0; s < P; ++s)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) f[s][t] = u[s][t];
-    fft_pass<Q, 1, false, P, true>(f, buf, Q, j, tw);
+            for (int t = 0; t < 4; ++t) f[s][t] = u[s][t];
+        fft_pass<Q, 1, false, P, true>(f, buf, Q, j, tw);
+    } else {
+#pragma unroll
+        for (int s = 0; s < P; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float2 a = ca[pos[s][t]], bb = cb[pos[s][t]];
+                d[s][t] = cmul(make_float2(a.x, -a.y), u[s][t]);
+                d[P + s][t] = cmul(make_float2(bb.x, -bb.y), u[s][t]);
+            }
+        fft_pass<Q, 1, false, 2 * P, true>(d, buf, Q, j, tw);
+    }
     // P-point DFT across the sub-sequences, derivative multipliers, inverse P-point DFT
-    float2 d[2 * P][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        float2 z[P];
+        float2 z[P], z2[P];
 #pragma unroll
         for (int k1 = 0; k1 < P; ++k1) {
-            float2 acc = f[0][t];
+            float2 acc = ADJ ? d[0][t] : f[0][t], acc2 = ADJ ? d[P][t] : make_float2(0.f, 0.f);
 #pragma unroll
             for (int s = 1; s < P; ++s) {
                 const float2 w = pc.wp[(s * k1) % P];
-                const float2 m = cmul(f[s][t], w);
+                const float2 m = cmul(ADJ ? d[s][t] : f[s][t], w);
                 acc.x += m.x; acc.y += m.y;
+                if (ADJ) {
+                    const float2 m2 = cmul(d[P + s][t], w);
+                    acc2.x += m2.x; acc2.y += m2.y;
+                }
             }
             z[k1] = acc;
+            z2[k1] = acc2;
         }
         float2 g1[P], g2[P];
 #pragma unroll
         for (int k1 = 0; k1 < P; ++k1) {
             const float kk1 = k1p[k1 * Q + j + t * T], kk2 = k2p[k1 * Q + j + t * T];
-            g1[k1] = make_float2(-z[k1].y * kk1, z[k1].x * kk1);   // (0, k) * U     (spectral.py:50, 281)
-            g2[k1] = make_float2(kk2 * z[k1].x, kk2 * z[k1].y);    // (-k^2, 0) * U  (spectral.py:52, 283)
+            if (!ADJ) {
+                g1[k1] = make_float2(-z[k1].y * kk1, z[k1].x * kk1);   // (0, k) * U     (spectral.py:50, 281)
+                g2[k1] = make_float2(kk2 * z[k1].x, kk2 * z[k1].y);    // (-k^2, 0) * U  (spectral.py:52, 283)
+            } else {                                                   // (-i k) Z1 + (-k^2) Z2
+                g1[k1] = make_float2(kk1 * z[k1].y + kk2 * z2[k1].x, -kk1 * z[k1].x + kk2 * z2[k1].y);
+                g2[k1] = make_float2(0.f, 0.f);
+            }
         }
 #pragma unroll
         for (int s = 0; s < P; ++s) {
@@ -787,15 +842,23 @@ __global__ void k_spec_pfa(const float* __restrict__ wf, float* __restrict__ out
             for (int k1 = 1; k1 < P; ++k1) {
                 float2 w = pc.wp[(s * k1) % P];
                 w.y = -w.y;
-                const float2 m1 = cmul(g1[k1], w), m2 = cmul(g2[k1], w);
+                const float2 m1 = cmul(g1[k1], w);
                 a1.x += m1.x; a1.y += m1.y;
-                a2.x += m2.x; a2.y += m2.y;
+                if (!ADJ) {
+                    const float2 m2 = cmul(g2[k1], w);
+                    a2.x += m2.x; a2.y += m2.y;
+                }
             }
-            d[s][t] = a1;
-            d[P + s][t] = a2;
+            if (ADJ) {
+                f[s][t] = a1;
+            } else {
+                d[s][t] = a1;
+                d[P + s][t] = a2;
+            }
         }
     }
-    fft_pass<Q, 1, true, 2 * P, true>(d, buf, Q, j, tw);
+    if (ADJ) fft_pass<Q, 1, true, P, true>(f, buf, Q, j, tw);
+    else fft_pass<Q, 1, true, 2 * P, true>(d, buf, Q, j, tw);
     constexpr float inv_n = 1.0f / N;
     float ss = 0.f;
     float* po = out + (long)b * 2 * plane + lbase;
@@ -804,17 +867,32 @@ __global__ void k_spec_pfa(const float* __restrict__ wf, float* __restrict__ out
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const int n = pos[s][t];
-            const float2 p = cmul(ca[n], d[s][t]), r = cmul(cb[n], d[P + s][t]);
-            float re = (p.x + r.x) * inv_n, im = (p.y + r.y) * inv_n;
+            float re, im;
+            if (ADJ) {
+                re = f[s][t].x * inv_n;
+                im = f[s][t].y * inv_n;
+            } else {
+                const float2 p = cmul(ca[n], d[s][t]), r = cmul(cb[n], d[P + s][t]);
+                re = (p.x + r.x) * inv_n;
+                im = (p.y + r.y) * inv_n;
+            }
             const long o = (long)n * lstride;
             if (AXIS == 0) {
                 if (flags & 1) { re += po[o]; im += po[o + plane]; }
                 if (flags & 2) {
                     const float kq = ksq[(long)b * plane + lbase + o];
-                    const float* ps = src + (long)b * src_sb + lbase + o;
-                    re = re + kq * u[s][t].x - ps[0];
-                    im = im + kq * u[s][t].y - ps[plane];
+                    re = re + kq * u[s][t].x;
+                    im = im + kq * u[s][t].y;
+                    if (src != nullptr) {
+                        const float* ps = src + (long)b * src_sb + lbase + o;
+                        re -= ps[0];
+                        im -= ps[plane];
+                    }
                 }
+            } else if (ADJ && add != nullptr) {   // `add` may alias `out`: same thread reads and writes the element
+                const float* pa = add + (long)b * 2 * plane + lbase;
+                re += pa[o];
+                im += pa[o + plane];
             }
             if (live) {
                 po[o] = re;
@@ -833,9 +911,9 @@ __global__ void k_spec_pfa(const float* __restrict__ wf, float* __restrict__ out
     }
 }
 
-template <int Q, int P>
+template <int Q, int P, bool ADJ = false>
 int launch_pfa(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch, bool resid,
-               float* sumsq, hipStream_t s, int* it_counter, int sumsq_stride) {
+               float* sumsq, hipStream_t s, int* it_counter, int sumsq_stride, const float* add = nullptr) {
     constexpr int N = P * Q, T = Q / 4;
     const SpecTables& t = ctx->tab;
     PfaConst<P> pc;
@@ -848,20 +926,21 @@ int launch_pfa(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
     while (lpb * T > 64 && (long)((N + lpb - 1) / lpb) * batch < 512) lpb >>= 1;
     const size_t lds = (size_t)lpb * 2 * P * Q * sizeof(float2);
     const dim3 grid((N + lpb - 1) / lpb, batch);
-    if (lds > 48 * 1024 && !ctx->pfa_attr_set) {
-        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_pfa<Q, P, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_pfa<Q, P, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        ctx->pfa_attr_set = true;
+    bool& attr_set = ADJ ? ctx->pfa_adj_attr_set : ctx->pfa_attr_set;
+    if (lds > 48 * 1024 && !attr_set) {
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_pfa<Q, P, 0, ADJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_pfa<Q, P, 1, ADJ>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
     }
     if (it_counter != nullptr) hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, s, it_counter);
     {
         ProfScope ps(ctx, KID_SPEC_COLS, s);
-        hipLaunchKernelGGL((k_spec_pfa<Q, P, 1>), grid, dim3(lpb, T), lds, s, wf, out, nullptr, nullptr, 0L, t.tw_q, t.k1_pfa, t.k2_pfa,
-                           t.a, t.b, pc, lpb, 0, nullptr, nullptr, 0);
+        hipLaunchKernelGGL((k_spec_pfa<Q, P, 1, ADJ>), grid, dim3(lpb, T), lds, s, wf, out, nullptr, nullptr, 0L, t.tw_q, t.k1_pfa, t.k2_pfa,
+                           t.a, t.b, pc, lpb, 0, nullptr, nullptr, 0, add);
     }
     ProfScope ps(ctx, KID_SPEC_ROWS, s);
-    hipLaunchKernelGGL((k_spec_pfa<Q, P, 0>), grid, dim3(T, lpb), lds, s, wf, out, ksq, src, src_sb, t.tw_q, t.k1_pfa, t.k2_pfa, t.a, t.b,
-                       pc, lpb, 1 | (resid ? 2 : 0), sumsq, it_counter, sumsq_stride);
+    hipLaunchKernelGGL((k_spec_pfa<Q, P, 0, ADJ>), grid, dim3(T, lpb), lds, s, wf, out, ksq, src, src_sb, t.tw_q, t.k1_pfa, t.k2_pfa, t.a, t.b,
+                       pc, lpb, 1 | (resid ? 2 : 0), sumsq, it_counter, sumsq_stride, nullptr);
     return HN_OK;
 }
 
@@ -870,7 +949,7 @@ __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf
                                                     const float* __restrict__ ksq, const float* __restrict__ src,
                                                     long src_sb, const float2* __restrict__ mt, int n, int flags,
                                                     float* __restrict__ sumsq, const int* __restrict__ it_counter,
-                                                    int sumsq_stride) {
+                                                    int sumsq_stride, const float* __restrict__ add = nullptr) {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y, b = blockIdx.z;
     const long plane = (long)n * n;
@@ -889,8 +968,17 @@ __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf
         const long o = (long)y * n + x;
         if (flags & 2) {
             const float kq = ksq[(long)b * plane + o];
-            re = re + kq * pre[o] - src[(long)b * src_sb + o];
-            im = im + kq * pim[o] - src[(long)b * src_sb + plane + o];
+            if (src != nullptr) {
+                re = re + kq * pre[o] - src[(long)b * src_sb + o];
+                im = im + kq * pim[o] - src[(long)b * src_sb + plane + o];
+            } else {
+                re = re + kq * pre[o];
+                im = im + kq * pim[o];
+            }
+        }
+        if (add != nullptr) {   // adjoint call only; `add` never aliases `out` here (spec_adjoint stages it)
+            re += add[(long)b * 2 * plane + o];
+            im += add[(long)b * 2 * plane + plane + o];
         }
         out[(long)b * 2 * plane + o] = re;
         out[(long)b * 2 * plane + plane + o] = im;
@@ -904,18 +992,18 @@ __global__ __launch_bounds__(256) void k_spec_dense(const float* __restrict__ wf
     }
 }
 
-template <int N>
+template <int N, bool ADJ = false>
 void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const float* src, long src_sb, int batch,
-                 const SpecPtrs& p, bool resid, float* sumsq, hipStream_t s, int* it_counter, int sumsq_stride) {
+                 const SpecPtrs& p, bool resid, float* sumsq, hipStream_t s, int* it_counter, int sumsq_stride, const float* add = nullptr) {
     constexpr int T = N / 4;
     constexpr int C = (1024 / T) < 16 ? (1024 / T) : 16;
     {
         ProfScope ps(ctx, KID_SPEC_COLS, s);
-        hipLaunchKernelGGL((k_spec_cols<N, C>), dim3(N / (C * ColCfg<N, C>::CPW), batch), dim3(C, T), 0, s, wf, out, p, it_counter);
+        hipLaunchKernelGGL((k_spec_cols<N, C, ADJ>), dim3(N / (C * ColCfg<N, C>::CPW), batch), dim3(C, T), 0, s, wf, out, p, it_counter, add);
     }
     constexpr int R = RowCfg<N>::R;
     ProfScope ps(ctx, KID_SPEC_ROWS, s);
-    hipLaunchKernelGGL((k_spec_rows<N>), dim3(N / (R * RowCfg<N>::RPW), batch), dim3(T, R), 0, s, wf, out, ksq, src, src_sb, p,
+    hipLaunchKernelGGL((k_spec_rows<N, ADJ>), dim3(N / (R * RowCfg<N>::RPW), batch), dim3(T, R), 0, s, wf, out, ksq, src, src_sb, p,
                        1 | (resid ? 2 : 0), sumsq, it_counter, sumsq_stride);
 }
 
@@ -939,7 +1027,7 @@ int upload(hn_ctx* ctx, T** dst, const std::vector<T>& h) {
 }  // namespace
 
 void spec_free(SpecTables& t) {
-    for (void* p : {(void*)t.tw, (void*)t.k1, (void*)t.k2, (void*)t.a, (void*)t.b, (void*)t.dense_t, (void*)t.sigmas, (void*)t.tw_q,
+    for (void* p : {(void*)t.tw, (void*)t.k1, (void*)t.k2, (void*)t.a, (void*)t.b, (void*)t.dense_t, (void*)t.dense_adj_t, (void*)t.sigmas, (void*)t.tw_q,
                     (void*)t.k1_pfa, (void*)t.k2_pfa}) (void)hipFree(p);
     t = SpecTables{};
 }
@@ -950,7 +1038,7 @@ int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k) {
     if (n < 16 || n > 2048) return fail(ctx, HN_ERR_ARG, "domain size %d outside [16, 2048]", n);
     if (pml < 1 || 2 * pml > n) return fail(ctx, HN_ERR_ARG, "PML size %d does not fit domain %d", pml, n);
     spec_free(ctx->tab);
-    ctx->pfa_attr_set = false;   // another (P, Q) kernel instance from now on
+    ctx->pfa_attr_set = ctx->pfa_adj_attr_set = false;   // another (P, Q) kernel instance from now on
     SpecTables& t = ctx->tab;
     t.n = n;
     t.pow2 = (n & (n - 1)) == 0;
@@ -1049,6 +1137,14 @@ int spec_build(hn_ctx* ctx, int n, int pml, double sigma_max, double k) {
                 mt[(size_t)m * n + j] = make_float2((float)v.real(), (float)v.imag());
             }
         if ((rc = upload(ctx, &t.dense_t, mt)) != HN_OK) return rc;
+        // adjoint operator (training): M^H[j][m] = conj(M[m][j]), stored transposed like M
+        std::vector<float2> mh((size_t)n * n);
+        for (int j = 0; j < n; ++j)
+            for (int m = 0; m < n; ++m) {
+                const float2 v = mt[(size_t)j * n + m];   // M[m][j]
+                mh[(size_t)m * n + j] = make_float2(v.x, -v.y);
+            }
+        if ((rc = upload(ctx, &t.dense_adj_t, mh)) != HN_OK) return rc;
     }
     return HN_OK;
 }
@@ -1105,6 +1201,40 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
         ProfScope ps(ctx, KID_SPEC_ROWS, s);
         hipLaunchKernelGGL(k_spec_dense, dim3((t.n + 255) / 256, t.n, batch), dim3(256), 0, s, wf, out, ksq, src,
                            src_sb, t.dense_t, t.n, resid ? 2 : 0, accum_sumsq, it_counter, sumsq_stride);
+    }
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+// out = L^H(g) + ksq * g [+ add]  (vector-Jacobian product of the residual with respect to the wavefield; training).  The
+// 256-point lines use the radix-4 kernels here (the register-resident radix-16 / 8x4x8 kernels are forward-only).
+int spec_adjoint(hn_ctx* ctx, const float* g, float* out, const float* ksq, const float* add, int batch, hipStream_t s) {
+    const SpecTables& t = ctx->tab;
+    if (t.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
+    if (batch <= 0) return HN_OK;
+    if (g == out) return fail(ctx, HN_ERR_ARG, "spec_adjoint: input and output must not alias");
+    if (t.pow2) {
+        const SpecPtrs p{t.tw, t.k1, t.k2, t.a, t.b};
+        switch (t.n) {
+#define HN_ADJ(NN) case NN: launch_pow2<NN, true>(ctx, g, out, ksq, nullptr, 0, batch, p, true, nullptr, s, nullptr, 0, add); break;
+            HN_ADJ(16) HN_ADJ(32) HN_ADJ(64) HN_ADJ(128) HN_ADJ(256) HN_ADJ(512) HN_ADJ(1024) HN_ADJ(2048)
+#undef HN_ADJ
+            default: return fail(ctx, HN_ERR_ARG, "unsupported power-of-two size %d", t.n);
+        }
+    } else if (t.pfa_p != 0) {
+        int rc = HN_OK;
+#define HN_PFA(QQ, PP) case (PP) * 1024 + (QQ): rc = launch_pfa<QQ, PP, true>(ctx, g, out, ksq, nullptr, 0, batch, true, nullptr, s, nullptr, 0, add); break;
+        switch (t.pfa_p * 1024 + t.pfa_q) {
+            HN_PFA(16, 3) HN_PFA(32, 3) HN_PFA(64, 3) HN_PFA(128, 3) HN_PFA(256, 3) HN_PFA(512, 3)
+            HN_PFA(16, 5) HN_PFA(32, 5) HN_PFA(64, 5) HN_PFA(128, 5) HN_PFA(256, 5)
+            default: return fail(ctx, HN_ERR_ARG, "internal: no prime-factor kernel for %d x %d", t.pfa_p, t.pfa_q);
+        }
+#undef HN_PFA
+        if (rc != HN_OK) return rc;
+    } else {
+        if (add == out) return fail(ctx, HN_ERR_ARG, "spec_adjoint: the dense operator cannot accumulate in place");
+        hipLaunchKernelGGL(k_spec_dense, dim3((t.n + 255) / 256, t.n, batch), dim3(256), 0, s, g, out, ksq, nullptr, 0L, t.dense_adj_t, t.n,
+                           2, nullptr, nullptr, 0, add);
     }
     HN_HIP(ctx, hipGetLastError());
     return HN_OK;

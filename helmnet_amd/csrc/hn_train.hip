@@ -1,0 +1,910 @@
+// Training step of the helmnet IterativeSolver for gfx950: loss and weight gradients of n unrolled solver iterations
+// (back-propagation through time) and the Adam update.
+//
+// Reference: helmnet/hybridnet.py:385-413 (training_step: replay-buffer sample -> set_states -> n_steps(unrolling_steps = 10)
+// -> loss = 1e4 * mean(cat(residuals)^2)), :558-584 (single_step), :172-176 (on_after_backward: clip_grad_value_), :250-258
+// (Adam, betas (0.9, 0.95), weight decay); the network is helmnet/architectures.py:63-84 (DoubleConv), :240-252
+// (EncoderBlock.forward), :439-465 (HybridNet.forward).  PyTorch's autograd does the backward pass there; here it is written
+// out, layer by layer, as the vector-Jacobian products of those same functions.
+//
+// Design
+//   * Forward with a tape: every convolution runs as its own launch and stores its PRE-activation output, so a DoubleConv
+//     leaves (mid z, output) behind; the activation is applied when a consumer stages its input.  The tape of all unrolled
+//     iterations stays in HBM (2.8 MB per sample-iteration at 96^2, 20 MB at 256^2: 0.9 / 6.3 GB for the reference's batch of
+//     32 x 10 iterations -- nothing next to 288 GB, so nothing is recomputed).
+//   * Backward-data of a 3x3 convolution is the same direct kernel (k_conv3) reading the forward weights transposed and
+//     flipped; the activation derivative and the PReLU-slope gradient ride in its epilogue.  Backward-data of the 8x8
+//     stride-2 convolution is the transposed-convolution kernel of the inference path with the forward weights read as
+//     [in, out, kh, kw], and vice versa (hn_unet.hip's direct kernels, weights re-packed on the device once per call).
+//   * Weight gradients: one block per run of tiles accumulates its [cout, cin, kh, kw] (+ bias) partial sums in registers,
+//     writes them to a partials table, and one reduction kernel adds the table into the gradient blob in a fixed order -- no
+//     atomics, so gradients are bit-reproducible and a sharded batch sums to the same bits as its shards in rank order.
+//   * The spectral operator is linear: its backward is the adjoint pass spec_adjoint (hn_spectral.hip).
+//   * Everything is enqueued on the caller's stream; the only host synchronisation is none.
+#include <cmath>
+
+#include "hn_internal.h"
+
+namespace hn {
+namespace {
+
+constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- raw (PyTorch-layout) blob offsets, the order of hn_load_weights -------------------------------------------------
+struct RawDc { size_t w1, b1, slope, w2, b2; int cin, cm, co; };
+struct RawK8 { size_t w, b; };
+struct RawLayout {
+    RawDc inc, sig[kMaxDepth], st[kMaxDepth], dec[kMaxDepth + 1];
+    RawK8 down[kMaxDepth], up[kMaxDepth];
+    size_t outc_w, outc_b, total;
+};
+RawLayout raw_layout(int depth) {
+    RawLayout L{};
+    size_t pos = 0;
+    auto dc = [&](int cin, int cm, int co) {
+        RawDc d{};
+        d.cin = cin; d.cm = cm; d.co = co;
+        d.w1 = pos; pos += (size_t)cm * cin * 9;
+        d.b1 = pos; pos += cm;
+        d.slope = pos; pos += 1;
+        d.w2 = pos; pos += (size_t)co * cm * 9;
+        d.b2 = pos; pos += co;
+        return d;
+    };
+    auto k8 = [&]() { RawK8 k{}; k.w = pos; pos += (size_t)kFeat * kFeat * 64; k.b = pos; pos += kFeat; return k; };
+    L.inc = dc(kInCh, kFeat, kFeat);
+    for (int d = 0; d < depth; ++d) {
+        L.sig[d] = dc(kFeat + kState, kFeat, kFeat);
+        L.down[d] = k8();
+        L.st[d] = dc(kFeat + kState, kState, kState);
+    }
+    for (int d = 0; d <= depth; ++d) L.dec[d] = dc(d < depth ? 2 * kFeat : kFeat, kFeat, kFeat);
+    for (int d = 0; d < depth; ++d) L.up[d] = k8();
+    L.outc_w = pos; pos += 2 * kFeat;
+    L.outc_b = pos; pos += 2;
+    L.total = pos;
+    return L;
+}
+
+// ---- activations and their derivatives (architectures.py:5-44) ---------------------------------------------------------
+__device__ __forceinline__ float act_fwd(float x, int kind, float slope) {
+    if (kind <= HN_ACT_LEAKYRELU) return x > 0.f ? x : slope * x;
+    return act_general(x, kind);
+}
+__device__ __forceinline__ float act_grad(float x, int kind, float slope) {
+    switch (kind) {
+        case HN_ACT_CELU: return x > 0.f ? 1.f : expf(x);
+        case HN_ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
+        case HN_ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+        case HN_ACT_TANHSHRINK: { const float t = tanhf(x); return t * t; }
+        case HN_ACT_SOFTPLUS: return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+        default: return x > 0.f ? 1.f : slope;   // prelu / relu / leakyrelu (torch: the slope applies at x == 0)
+    }
+}
+
+// A channel group of an implicit concatenation: element (b, c, y, x) at p[b*sb + c*sc + y*W + x]
+struct TSrc { const float* p; long sb, sc; int nch; float scale; int act; };   // act: the activation is applied while staging (p holds pre-activations)
+struct TDst { float* p; long sb, sc; int nch; float scale; int accum; };      // p == nullptr: the group is discarded
+
+// ------------------------------------------------------------------------------------------------------------------
+// 3x3 convolution, padding 1, any (cin <= 16) -> CO channels, direct fp32, weights in LDS.
+//   wmode 0  forward:        out[co] = bias[co] + sum_ci sum_k w[co][ci][k] * in[ci](. + k - 1)
+//   wmode 1  backward-data:  out[ci] = sum_co sum_k w[co][ci][8 - k] * in[co](. + k - 1)      (w is the FORWARD weight, [w_o][w_i][3][3])
+//   EPI_ACT: out *= act'(z) (z: the pre-activation tensor the gradient flows back into) and, for PReLU, the partial sum of
+//            out_before * min(z, 0) per block (d loss / d slope).
+// Tile 32 x 32, thread = 1 x 4 strip x all CO channels; input staged 4 channels at a time with a 1-pixel halo.
+// ------------------------------------------------------------------------------------------------------------------
+struct Conv3Args {
+    TSrc src[3];
+    TDst dst[3];
+    const float* w;
+    const float* bias;
+    int w_o, w_i, wmode;
+    int H, W;
+    int act_kind;
+    const float* slope;
+    const float* z;
+    long z_sb, z_sc;
+    float* slope_part;
+};
+
+template <int CO, bool EPI_ACT>
+__global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
+    constexpr int TH = 32, TW = 32, PI = 36, IR = TH + 2, IC = TW + 2, CH = 4;
+    __shared__ __attribute__((aligned(16))) float s_in[CH * IR * PI + 8];
+    __shared__ __attribute__((aligned(16))) float s_w[16 * 9 * CO];
+    __shared__ float s_red[4];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    const int CI = a.src[0].nch + a.src[1].nch + a.src[2].nch;
+    for (int e = tid; e < CI * 9 * CO; e += 256) {
+        const int co = e % CO, r = e / CO, k = r % 9, ci = r / 9;
+        s_w[e] = a.wmode == 0 ? a.w[((long)co * a.w_i + ci) * 9 + k] : a.w[((long)ci * a.w_i + co) * 9 + (8 - k)];
+    }
+    const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
+    const int ry = tid >> 3, sx = tid & 7;   // output row y0 + ry, columns x0 + 4 sx .. + 3
+    float acc[4][CO];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+    for (int c0 = 0; c0 < CI; c0 += CH) {
+        __syncthreads();   // the previous chunk has been consumed (first round: orders the weight stores too)
+        for (int e = tid; e < CH * IR * IC; e += 256) {
+            const int cc = e / (IR * IC), r = e - cc * (IR * IC), ir = r / IC, ic = r - ir * IC;
+            const int c = c0 + cc, y = y0 - 1 + ir, x = x0 - 1 + ic;
+            float v = 0.f;
+            if (c < CI && y >= 0 && y < a.H && x >= 0 && x < a.W) {
+                int cs = c, si = 0;
+                if (cs >= a.src[0].nch) { cs -= a.src[0].nch; si = 1; if (cs >= a.src[1].nch) { cs -= a.src[1].nch; si = 2; } }
+                const TSrc& sr = a.src[si];
+                v = sr.p[(long)b * sr.sb + (long)cs * sr.sc + (long)y * a.W + x];
+                if (sr.act) v = act_fwd(v, a.act_kind, slope);
+                v *= sr.scale;
+            }
+            s_in[(cc * IR + ir) * PI + ic] = v;
+        }
+        __syncthreads();
+        const int nc = CI - c0 < CH ? CI - c0 : CH;
+        for (int cc = 0; cc < nc; ++cc) {
+            const float* t = &s_in[(cc * IR + ry) * PI + 4 * sx];
+            const float* wc = &s_w[(c0 + cc) * 9 * CO];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float4 lo = *reinterpret_cast<const float4*>(t + dy * PI);
+                const float2 hi = *reinterpret_cast<const float2*>(t + dy * PI + 4);
+                const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+                    for (int c = 0; c < CO; ++c) {
+                        const float wv = wc[(dy * 3 + dx) * CO + c];
+#pragma unroll
+                        for (int p = 0; p < 4; ++p) acc[p][c] = fmaf(wv, v[p + dx], acc[p][c]);
+                    }
+            }
+        }
+    }
+    const int y = y0 + ry;
+    float sp = 0.f;
+    if (y < a.H) {
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            const float bias = a.bias != nullptr ? a.bias[c] : 0.f;
+            int cd = c, di = 0;
+            if (cd >= a.dst[0].nch) { cd -= a.dst[0].nch; di = 1; if (cd >= a.dst[1].nch) { cd -= a.dst[1].nch; di = 2; } }
+            const TDst& ds = a.dst[di];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int x = x0 + 4 * sx + p;
+                if (x >= a.W) continue;
+                float v = acc[p][c] + bias;
+                if (EPI_ACT) {
+                    const float zz = a.z[(long)b * a.z_sb + (long)c * a.z_sc + (long)y * a.W + x];
+                    if (zz <= 0.f) sp = fmaf(v, zz, sp);
+                    v *= act_grad(zz, a.act_kind, slope);
+                }
+                if (ds.p != nullptr) {
+                    float* q = ds.p + (long)b * ds.sb + (long)cd * ds.sc + (long)y * a.W + x;
+                    v *= ds.scale;
+                    *q = ds.accum ? *q + v : v;
+                }
+            }
+        }
+    }
+    if (EPI_ACT && a.slope_part != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
+        if ((tid & 63) == 0) s_red[tid >> 6] = sp;
+        __syncthreads();
+        if (tid == 0) a.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight + bias gradient of a 3x3 convolution:  dW[co][ci][k] = sum_{b,y,x} g[co](y, x) * in[ci](y + ky - 1, x + kx - 1),
+// db[co] = sum g[co].  Thread = one (ci, k) pair (the bias is one more pair with in == 1) x all CO channels x a subset of the
+// tile rows; a block walks a strided run of 16 x 32 tiles and writes one row of the partials table
+// [gridDim.x][CO * CI * 9 + CO], laid out like the blob (weight [CO][CI][3][3], then bias [CO]).
+// ------------------------------------------------------------------------------------------------------------------
+struct Wg3Args {
+    TSrc src[3];
+    const float* g;
+    long g_sb, g_sc;
+    int H, W, tiles_x, tiles_y, batch;
+    int act_kind;
+    const float* slope;
+    float* part;
+};
+
+template <int CO>
+__global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
+    constexpr int TH = 16, TW = 32, IR = TH + 2, IC = TW + 2, PI = 35;
+    __shared__ float s_x[16 * IR * PI];
+    __shared__ __attribute__((aligned(16))) float s_g[TH * TW * CO];
+    const int tid = threadIdx.x;
+    const int CI = a.src[0].nch + a.src[1].nch + a.src[2].nch;
+    const int P = CI * 9 + 1, S = 256 / P;
+    const int pair = tid % P, split = tid / P;
+    const bool active = split < S, isb = pair == P - 1;
+    const int ci = pair / 9, k = pair - ci * 9, ky = k / 3, kx = k - ky * 3;
+    const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
+    float acc[CO];
+#pragma unroll
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    const int ntiles = a.tiles_x * a.tiles_y * a.batch;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, b = r0 / a.tiles_y;
+        const int x0 = tx * TW, y0 = ty * TH;
+        __syncthreads();
+        for (int e = tid; e < CI * IR * IC; e += 256) {
+            const int c = e / (IR * IC), r = e - c * (IR * IC), ir = r / IC, ic = r - ir * IC;
+            const int y = y0 - 1 + ir, x = x0 - 1 + ic;
+            float v = 0.f;
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+                int cs = c, si = 0;
+                if (cs >= a.src[0].nch) { cs -= a.src[0].nch; si = 1; if (cs >= a.src[1].nch) { cs -= a.src[1].nch; si = 2; } }
+                const TSrc& sr = a.src[si];
+                v = sr.p[(long)b * sr.sb + (long)cs * sr.sc + (long)y * a.W + x];
+                if (sr.act) v = act_fwd(v, a.act_kind, slope);
+                v *= sr.scale;
+            }
+            s_x[(c * IR + ir) * PI + ic] = v;
+        }
+        for (int e = tid; e < TH * TW * CO; e += 256) {
+            const int c = e / (TH * TW), r = e - c * (TH * TW), iy = r / TW, ix = r - iy * TW;   // consecutive threads: consecutive x
+            const int y = y0 + iy, x = x0 + ix;
+            float v = 0.f;
+            if (y < a.H && x < a.W) v = a.g[(long)b * a.g_sb + (long)c * a.g_sc + (long)y * a.W + x];
+            s_g[(iy * TW + ix) * CO + c] = v;
+        }
+        __syncthreads();
+        if (active) {
+            for (int r = split; r < TH; r += S) {
+                const float* xr = &s_x[(ci * IR + r + ky) * PI + kx];
+                const float* gr = &s_g[r * TW * CO];
+#pragma unroll 4
+                for (int c = 0; c < TW; ++c) {
+                    const float xv = isb ? 1.f : xr[c];
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) acc[o] = fmaf(gr[c * CO + o], xv, acc[o]);
+                }
+            }
+        }
+    }
+    // reduce over the row subsets (fixed order), then one thread per pair writes the block's row of the table
+    __syncthreads();
+    float* s_red = s_g;   // S * P * CO <= 256 * CO floats <= TH * TW * CO
+    if (active) {
+#pragma unroll
+        for (int o = 0; o < CO; ++o) s_red[(split * P + pair) * CO + o] = acc[o];
+    }
+    __syncthreads();
+    if (tid < P) {
+        float* row = a.part + (size_t)blockIdx.x * (CO * CI * 9 + CO);
+#pragma unroll
+        for (int o = 0; o < CO; ++o) {
+            float s = 0.f;
+            for (int q = 0; q < S; ++q) s += s_red[(q * P + tid) * CO + o];
+            const int pc = tid / 9, pk = tid - pc * 9;
+            row[tid == P - 1 ? CO * CI * 9 + o : (o * CI + pc) * 9 + pk] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 8x8 stride-2 (transposed) convolution, padding 3 (architectures.py:209-211, 375-382):
+//     dW[a][b][ky][kx] = sum_{n,Y,X} sm[a](Y, X) * bg[b](2Y + ky - 3, 2X + kx - 3)
+//   down  (Conv2d, weight [out, in, 8, 8]):           sm = grad of the output (a = out), bg = input (b = in)
+//   up    (ConvTranspose2d, weight [in, out, 8, 8]):  sm = input (a = in),               bg = grad of the output (b = out)
+// Thread = (b, ky, kx) x 8 values of a; block walks a run of 8 x 16 tiles of the small tensor; partials [gridDim.x][4096].
+// ------------------------------------------------------------------------------------------------------------------
+struct Wg8Args {
+    const float* sm; long sm_sb, sm_sc; int hs, ws;
+    const float* bg; long bg_sb, bg_sc;
+    int tiles_x, tiles_y, batch;
+    float* part;
+};
+
+__global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
+    constexpr int TY = 8, TX = 16, BR = 2 * TY + 6, BC = 2 * TX + 6, PB = 39;
+    __shared__ float s_b[kFeat * BR * PB];
+    __shared__ __attribute__((aligned(16))) float s_s[TY * TX * kFeat];
+    const int tid = threadIdx.x;
+    const int bch = tid >> 6, k = tid & 63, ky = k >> 3, kx = k & 7;
+    const int hb = 2 * a.hs, wb = 2 * a.ws;
+    float acc[kFeat];
+#pragma unroll
+    for (int c = 0; c < kFeat; ++c) acc[c] = 0.f;
+    const int ntiles = a.tiles_x * a.tiles_y * a.batch;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, n = r0 / a.tiles_y;
+        const int X0 = tx * TX, Y0 = ty * TY;
+        __syncthreads();
+        for (int e = tid; e < kFeat * BR * BC; e += 512) {
+            const int c = e / (BR * BC), r = e - c * (BR * BC), ir = r / BC, ic = r - ir * BC;
+            const int y = 2 * Y0 - 3 + ir, x = 2 * X0 - 3 + ic;
+            float v = 0.f;
+            if (y >= 0 && y < hb && x >= 0 && x < wb) v = a.bg[(long)n * a.bg_sb + (long)c * a.bg_sc + (long)y * wb + x];
+            s_b[(c * BR + ir) * PB + ic] = v;
+        }
+        for (int e = tid; e < TY * TX * kFeat; e += 512) {
+            const int c = e / (TY * TX), r = e - c * (TY * TX), iy = r / TX, ix = r - iy * TX;
+            const int y = Y0 + iy, x = X0 + ix;
+            float v = 0.f;
+            if (y < a.hs && x < a.ws) v = a.sm[(long)n * a.sm_sb + (long)c * a.sm_sc + (long)y * a.ws + x];
+            s_s[(iy * TX + ix) * kFeat + c] = v;
+        }
+        __syncthreads();
+        const float* bp = &s_b[(bch * BR + ky) * PB + kx];
+#pragma unroll 2
+        for (int Y = 0; Y < TY; ++Y)
+#pragma unroll 4
+            for (int X = 0; X < TX; ++X) {
+                const float xv = bp[2 * Y * PB + 2 * X];
+                const float* sp = &s_s[(Y * TX + X) * kFeat];
+#pragma unroll
+                for (int c = 0; c < kFeat; ++c) acc[c] = fmaf(sp[c], xv, acc[c]);
+            }
+    }
+    float* row = a.part + (size_t)blockIdx.x * (kFeat * kFeat * 64);
+#pragma unroll
+    for (int c = 0; c < kFeat; ++c) row[(c * kFeat + bch) * 64 + k] = acc[c];
+}
+
+// per-channel sums of a [B, C, plane] tensor (bias gradients of the 8x8 convolutions): partials [gridDim.x][C]
+__global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x, long sb, long sc, long plane, int batch, float* __restrict__ part, int C) {
+    __shared__ float s_red[4];
+    const int c = blockIdx.y;
+    float s = 0.f;
+    const long total = (long)batch * plane;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / plane, p = i - b * plane;
+        s += x[b * sb + (long)c * sc + p];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * C + c] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// out[j] += sum over rows of part[row][j], in a fixed order.  Wide tables: one thread per column; narrow ones (bias, slope,
+// the 1x1 layer): one block per column, threads strided over the rows.
+__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int rows, int count, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= count) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = 0;
+    for (; r + 4 <= rows; r += 4) {
+        s0 += part[(size_t)r * count + j];
+        s1 += part[(size_t)(r + 1) * count + j];
+        s2 += part[(size_t)(r + 2) * count + j];
+        s3 += part[(size_t)(r + 3) * count + j];
+    }
+    for (; r < rows; ++r) s0 += part[(size_t)r * count + j];
+    out[j] += (s0 + s1) + (s2 + s3);
+}
+__global__ __launch_bounds__(256) void k_reduce_col(const float* __restrict__ part, int rows, int count, float* __restrict__ out) {
+    __shared__ float s_red[4];
+    const int j = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < rows; r += 256) s += part[(size_t)r * count + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[j] += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+
+// ---- output layer: d = Conv1x1(8 -> 2)(y0); wf_next = wf + d / 1e3   (architectures.py:57-60, hybridnet.py:570) ----------
+__global__ __launch_bounds__(256) void k_outc_fwd(const float* __restrict__ y0, const float* __restrict__ w, const float* __restrict__ bias,
+                                                  const float* __restrict__ wf, float* __restrict__ wf_next, long plane, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const long b = i / plane, p = i - b * plane;
+    const float* yp = y0 + b * kFeat * plane + p;
+    float d0 = bias[0], d1 = bias[1];
+#pragma unroll
+    for (int c = 0; c < kFeat; ++c) {
+        const float v = yp[c * plane];
+        d0 = fmaf(w[c], v, d0);             // raw weight [2][8]
+        d1 = fmaf(w[kFeat + c], v, d1);
+    }
+    const long o = b * 2 * plane + p;
+    wf_next[o] = d0 / 1e3f + wf[o];
+    wf_next[o + plane] = d1 / 1e3f + wf[o + plane];
+}
+// backward: gd = g_wfnext / 1e3;  g_y0[c] = sum_o w[o][c] gd[o];  partials of dW[o][c] = sum gd[o] y0[c], db[o] = sum gd[o]  ([gridDim.x][18])
+__global__ __launch_bounds__(256) void k_outc_bwd(const float* __restrict__ g_wfn, const float* __restrict__ y0, const float* __restrict__ w,
+                                                  float* __restrict__ g_y0, float* __restrict__ part, long plane, long total) {
+    __shared__ float s_red[4][18];
+    float acc[18];
+#pragma unroll
+    for (int q = 0; q < 18; ++q) acc[q] = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long b = i / plane, p = i - b * plane;
+        const float g0 = g_wfn[b * 2 * plane + p] / 1e3f, g1 = g_wfn[b * 2 * plane + plane + p] / 1e3f;
+        const float* yp = y0 + b * kFeat * plane + p;
+        float* gp = g_y0 + b * kFeat * plane + p;
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c) {
+            const float v = yp[c * plane];
+            gp[c * plane] = fmaf(w[c], g0, w[kFeat + c] * g1);
+            acc[c] = fmaf(g0, v, acc[c]);
+            acc[kFeat + c] = fmaf(g1, v, acc[kFeat + c]);
+        }
+        acc[16] += g0;
+        acc[17] += g1;
+    }
+#pragma unroll
+    for (int q = 0; q < 18; ++q) {
+        float s = acc[q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][q] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 18) part[(size_t)blockIdx.x * 18 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// g = [g_in +] c * res   (the loss term of one unrolled iteration: d/d res of scale * mean(res^2))
+__global__ __launch_bounds__(256) void k_loss_seed(float* __restrict__ g, const float* __restrict__ res, float c, int has_in, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) g[i] = has_in ? fmaf(c, res[i], g[i]) : c * res[i];
+}
+__global__ __launch_bounds__(256) void k_add(float* __restrict__ y, const float* __restrict__ x, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < total) y[i] += x[i];
+}
+// loss = scale * sum(sumsq) / count, summed in a fixed order by one wavefront
+__global__ void k_loss_finalize(const float* __restrict__ sumsq, int n, float scale_over_count, float* __restrict__ loss) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 64) s += sumsq[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) loss[0] = s * scale_over_count;
+}
+// 8x8 weights -> [in][kh*kw][out] for the direct kernels of hn_unet.hip.  mode 0: raw is [out][in][64]; mode 1: raw is [in][out][64]
+__global__ __launch_bounds__(256) void k_repack8(const float* __restrict__ raw, float* __restrict__ dst, int mode) {
+    const int e = blockIdx.x * 256 + threadIdx.x;   // index into dst: (i * 64 + t) * 8 + o
+    if (e >= kFeat * kFeat * 64) return;
+    const int o = e & 7, t = (e >> 3) & 63, i = e >> 9;
+    dst[e] = mode == 0 ? raw[(o * kFeat + i) * 64 + t] : raw[(i * kFeat + o) * 64 + t];
+}
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
+                                              const unsigned char* __restrict__ trainable, size_t n, float step_size, float inv_sqrt_bc2, float b1,
+                                              float b2, float eps, float wd, float clip) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || (trainable != nullptr && trainable[i] == 0)) return;
+    float g = grad[i];
+    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    const float w = p[i];
+    if (wd != 0.f) g = fmaf(wd, w, g);
+    const float mi = m[i] + (g - m[i]) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
+    const float vi = fmaf(g * (1.f - b2), g, v[i] * b2);         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, value = 1 - beta2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] = w - step_size * (mi / denom);
+}
+
+// ---- host-side drivers -------------------------------------------------------------------------------------------------
+template <int CO>
+void launch_conv3_co(const Conv3Args& a, bool epi, dim3 grid, hipStream_t s) {
+    if (epi) hipLaunchKernelGGL((k_conv3<CO, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((k_conv3<CO, false>), grid, dim3(256), 0, s, a);
+}
+int launch_conv3(hn_ctx* ctx, int co, bool epi, const Conv3Args& a, int batch, hipStream_t s) {
+    const dim3 grid(cdiv(a.W, 32), cdiv(a.H, 32), batch);
+    switch (co) {
+        case 2: launch_conv3_co<2>(a, epi, grid, s); break;
+        case 6: launch_conv3_co<6>(a, epi, grid, s); break;
+        case 8: launch_conv3_co<8>(a, epi, grid, s); break;
+        case 10: launch_conv3_co<10>(a, epi, grid, s); break;
+        case 16: launch_conv3_co<16>(a, epi, grid, s); break;
+        default: return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no 3x3 kernel for %d output channels", co);
+    }
+    return HN_OK;
+}
+
+constexpr int kPartBlocks = 256;   // rows of the partials table a weight-gradient launch may write
+
+struct Trainer {
+    hn_ctx* ctx;
+    hipStream_t s;
+    const float* w;      // device blob (raw layouts)
+    float* grad;
+    RawLayout L;
+    int B, n, depth, act;
+    long Lst;            // flat state length per channel
+
+    int side(int d) const { return n >> d; }
+    long plane(int d) const { return (long)side(d) * side(d); }
+    hn_ctx::TrainWs& T() const { return ctx->tr; }
+    float* tape(int t, size_t off) const { return T().tape + (size_t)t * T().step_floats + off; }
+    TSrc feat(const float* p, int d, int nch = kFeat, int act_on_load = 0) const { return TSrc{p, nch * plane(d), plane(d), nch, 1.f, act_on_load}; }
+    TDst featdst(float* p, int d, int nch = kFeat, int accum = 0) const { return TDst{p, nch * plane(d), plane(d), nch, 1.f, accum}; }
+    static TSrc nosrc() { return TSrc{nullptr, 0, 0, 0, 1.f, 0}; }
+    static TDst nodst() { return TDst{nullptr, 0, 0, 0, 1.f, 0}; }
+    TSrc state_src(const float* flat, int d) const { return TSrc{flat + ctx->state_off[d], 2 * Lst, Lst, kState, 1.f, 0}; }
+    TDst state_dst(float* flat, int d, int accum = 0) const { return TDst{flat + ctx->state_off[d], 2 * Lst, Lst, kState, 1.f, accum}; }
+
+    // forward convolution of a DoubleConv half: out = conv(w_off) (srcs) + bias
+    int conv_fwd(const TSrc (&src)[3], size_t w_off, size_t b_off, int w_o, int w_i, size_t slope_off, TDst dst, int d) {
+        Conv3Args a{};
+        for (int i = 0; i < 3; ++i) a.src[i] = src[i];
+        a.dst[0] = dst; a.dst[1] = nodst(); a.dst[2] = nodst();
+        a.w = w + w_off; a.bias = w + b_off; a.w_o = w_o; a.w_i = w_i; a.wmode = 0;
+        a.H = a.W = side(d);
+        a.act_kind = act; a.slope = w + slope_off;
+        return launch_conv3(ctx, w_o, false, a, B, s);
+    }
+    // DoubleConv forward with tape: z = conv1(in) (stored), out = conv2(act(z))
+    int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d) {
+        int rc = conv_fwd(in, dc.w1, dc.b1, dc.cm, dc.cin, dc.slope, featdst(z, d, dc.cm), d);
+        if (rc != HN_OK) return rc;
+        const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
+        return conv_fwd(mid, dc.w2, dc.b2, dc.co, dc.cm, dc.slope, out, d);
+    }
+    int reduce(int rows, int count, size_t grad_off) {
+        if (count >= 64) hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(count, 256)), dim3(256), 0, s, T().part, rows, count, grad + grad_off);
+        else hipLaunchKernelGGL(k_reduce_col, dim3(count), dim3(256), 0, s, T().part, rows, count, grad + grad_off);
+        return HN_OK;
+    }
+    int wgrad3(const TSrc (&in)[3], TSrc g, int co, int cin, size_t grad_off, int d, size_t slope_off) {
+        Wg3Args a{};
+        for (int i = 0; i < 3; ++i) a.src[i] = in[i];
+        a.g = g.p; a.g_sb = g.sb; a.g_sc = g.sc;
+        a.H = a.W = side(d);
+        a.tiles_x = cdiv(a.W, 32); a.tiles_y = cdiv(a.H, 16); a.batch = B;
+        a.act_kind = act; a.slope = w + slope_off; a.part = T().part;
+        const int ntiles = a.tiles_x * a.tiles_y * B;
+        const int blocks = ntiles < kPartBlocks ? ntiles : kPartBlocks;
+        if (co == 8) hipLaunchKernelGGL(k_conv3_wgrad<8>, dim3(blocks), dim3(256), 0, s, a);
+        else if (co == 2) hipLaunchKernelGGL(k_conv3_wgrad<2>, dim3(blocks), dim3(256), 0, s, a);
+        else return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no weight-gradient kernel for %d output channels", co);
+        return reduce(blocks, co * cin * 9 + co, grad_off);
+    }
+    // DoubleConv backward: g_out (co channels) -> weight gradients, gradients of the inputs into `gin` (channel groups of the concatenation)
+    int dc_bwd(const RawDc& dc, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
+        int rc;
+        // conv2: dW2, db2 from (act(z), g_out)
+        {
+            const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
+            if ((rc = wgrad3(mid, g_out, dc.co, dc.cm, dc.w2, d, dc.slope)) != HN_OK) return rc;
+        }
+        // g_z = conv2^T(g_out) * act'(z);  d slope
+        {
+            Conv3Args a{};
+            a.src[0] = g_out; a.src[1] = nosrc(); a.src[2] = nosrc();
+            a.dst[0] = featdst(T().gz, d, dc.cm); a.dst[1] = nodst(); a.dst[2] = nodst();
+            a.w = w + dc.w2; a.bias = nullptr; a.w_o = dc.co; a.w_i = dc.cm; a.wmode = 1;
+            a.H = a.W = side(d);
+            a.act_kind = act; a.slope = w + dc.slope;
+            a.z = z; a.z_sb = dc.cm * plane(d); a.z_sc = plane(d);
+            a.slope_part = act == HN_ACT_PRELU ? T().part : nullptr;
+            if ((rc = launch_conv3(ctx, dc.cm, true, a, B, s)) != HN_OK) return rc;
+            if (act == HN_ACT_PRELU) reduce(cdiv(side(d), 32) * cdiv(side(d), 32) * B, 1, dc.slope);
+        }
+        // conv1: dW1, db1 from (in, g_z)
+        if ((rc = wgrad3(in, feat(T().gz, d, dc.cm), dc.cm, dc.cin, dc.w1, d, dc.slope)) != HN_OK) return rc;
+        // g_in = conv1^T(g_z)
+        {
+            Conv3Args a{};
+            a.src[0] = feat(T().gz, d, dc.cm); a.src[1] = nosrc(); a.src[2] = nosrc();
+            for (int i = 0; i < 3; ++i) a.dst[i] = gin[i];
+            a.w = w + dc.w1; a.bias = nullptr; a.w_o = dc.cm; a.w_i = dc.cin; a.wmode = 1;
+            a.H = a.W = side(d);
+            a.act_kind = act; a.slope = nullptr;
+            if ((rc = launch_conv3(ctx, dc.cin, false, a, B, s)) != HN_OK) return rc;
+        }
+        return HN_OK;
+    }
+    K8W k8(int d, int which, size_t bias_off, bool with_bias) const {   // which: 0 down fwd, 1 down bwd-data, 2 up fwd, 3 up bwd-data
+        return K8W{T().k8 + ((size_t)d * 4 + which) * 4096, with_bias ? w + bias_off : T().zero8};
+    }
+    int wgrad8(const float* sm, int d_small, const float* bg, size_t grad_off) {
+        Wg8Args a{};
+        a.sm = sm; a.sm_sb = kFeat * plane(d_small); a.sm_sc = plane(d_small); a.hs = a.ws = side(d_small);
+        a.bg = bg; a.bg_sb = kFeat * plane(d_small - 1); a.bg_sc = plane(d_small - 1);
+        a.tiles_x = cdiv(a.ws, 16); a.tiles_y = cdiv(a.hs, 8); a.batch = B;
+        a.part = T().part;
+        const int ntiles = a.tiles_x * a.tiles_y * B;
+        const int blocks = ntiles < kPartBlocks ? ntiles : kPartBlocks;
+        hipLaunchKernelGGL(k_conv8_wgrad, dim3(blocks), dim3(512), 0, s, a);
+        return reduce(blocks, kFeat * kFeat * 64, grad_off);
+    }
+    int bias8(const float* g, int d, size_t grad_off) {
+        const int blocks = 32;
+        hipLaunchKernelGGL(k_channel_sum, dim3(blocks, kFeat), dim3(256), 0, s, g, (long)kFeat * plane(d), plane(d), plane(d), B, T().part, kFeat);
+        return reduce(blocks, kFeat, grad_off);
+    }
+
+    // one unrolled iteration, forward (hybridnet.py:558-584), filling step t of the tape
+    int forward_step(int t, const float* wf, const float* res, const float* st_in, float* wf_next, float* res_next, float* st_next,
+                     const float* ksq, const float* src, int src_batch) {
+        auto& W = T();
+        int rc;
+        const long p0 = plane(0);
+        {
+            const TSrc in[3] = {TSrc{wf, 2 * p0, p0, 2, 1.f, 0}, TSrc{res, 2 * p0, p0, 2, 1e3f, 0}, TSrc{ctx->tab.sigmas, 0, p0, 2, 1.f, 0}};
+            if ((rc = dc_fwd(L.inc, in, tape(t, W.o_zinc), featdst(tape(t, W.o_x[0]), 0), 0)) != HN_OK) return rc;
+        }
+        for (int d = 0; d < depth; ++d) {
+            const TSrc in_sig[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
+            if ((rc = dc_fwd(L.sig[d], in_sig, tape(t, W.o_zsig[d]), featdst(tape(t, W.o_out[d]), d), d)) != HN_OK) return rc;
+            const TSrc in_st[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
+            if ((rc = dc_fwd(L.st[d], in_st, tape(t, W.o_zst[d]), state_dst(st_next, d), d)) != HN_OK) return rc;
+            if ((rc = module_conv8x8(ctx, tape(t, W.o_out[d]), k8(d, 0, L.down[d].b, true), false, tape(t, W.o_x[d + 1]), B, side(d), side(d), s)) != HN_OK) return rc;
+        }
+        {
+            const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
+            if ((rc = dc_fwd(L.dec[depth], in, tape(t, W.o_zdec[depth]), featdst(tape(t, W.o_y[depth]), depth), depth)) != HN_OK) return rc;
+        }
+        for (int d = depth - 1; d >= 0; --d) {
+            if ((rc = module_conv8x8(ctx, tape(t, W.o_y[d + 1]), k8(d, 2, L.up[d].b, true), true, tape(t, W.o_u[d]), B, side(d + 1), side(d + 1), s)) != HN_OK) return rc;
+            const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
+            if ((rc = dc_fwd(L.dec[d], in, tape(t, W.o_zdec[d]), featdst(tape(t, W.o_y[d]), d), d)) != HN_OK) return rc;
+        }
+        const long total = (long)B * p0;
+        hipLaunchKernelGGL(k_outc_fwd, dim3((unsigned)cdiv((int)total, 256)), dim3(256), 0, s, tape(t, W.o_y[0]), w + L.outc_w, w + L.outc_b, wf, wf_next, p0, total);
+        return spec_apply(ctx, wf_next, res_next, ksq, src, src_batch, B, W.sumsq + (size_t)t * B, s);
+    }
+
+    // backward of iteration t.  On entry g_wf[cur_wf] / g_res / g_st[cur_st] hold d loss / d (wf, res, states) AFTER iteration t without
+    // this iteration's own loss term (zeros for the last iteration); on exit they hold the gradients with respect to the
+    // iteration's inputs (the buffer indices flip).
+    int backward_step(int t, const float* wf_in, const float* res_in, const float* st_in, const float* res_out, const float* ksq,
+                      float loss_c, int& cur_wf, int& cur_st) {
+        auto& W = T();
+        int rc;
+        const long p0 = plane(0), tot2 = (long)B * 2 * p0;
+        // this iteration's loss term, then the adjoint of the residual operator: G = g_wf + L^H(g_res) + ksq * g_res
+        hipLaunchKernelGGL(k_loss_seed, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, s, W.g_res, res_out, loss_c, 1, tot2);
+        if ((rc = spec_adjoint(ctx, W.g_res, W.g_wf[cur_wf ^ 1], ksq, W.g_wf[cur_wf], B, s)) != HN_OK) return rc;
+        cur_wf ^= 1;
+        float* G = W.g_wf[cur_wf];   // d loss / d wf_next; wf_next = wf + d / 1e3, so it is also the direct part of d loss / d wf
+        {
+            const long total = (long)B * p0;
+            const int blocks = (int)((total + 255) / 256) < kPartBlocks ? (int)((total + 255) / 256) : kPartBlocks;
+            hipLaunchKernelGGL(k_outc_bwd, dim3(blocks), dim3(256), 0, s, G, tape(t, W.o_y[0]), w + L.outc_w, W.g_y[0], W.part, p0, total);
+            reduce(blocks, 18, L.outc_w);
+        }
+        for (int d = 0; d < depth; ++d) {   // decoder, top down
+            const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
+            const TDst gin[3] = {featdst(W.g_u[d], d), featdst(W.g_out[d], d), nodst()};
+            if ((rc = dc_bwd(L.dec[d], in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d)) != HN_OK) return rc;
+            // up[d]: backward-data = the stride-2 convolution kernel on the transposed-convolution weights
+            if ((rc = module_conv8x8(ctx, W.g_u[d], k8(d, 3, 0, false), false, W.g_y[d + 1], B, side(d), side(d), s)) != HN_OK) return rc;
+            wgrad8(tape(t, W.o_y[d + 1]), d + 1, W.g_u[d], L.up[d].w);
+            bias8(W.g_u[d], d, L.up[d].b);
+        }
+        {
+            const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
+            const TDst gin[3] = {featdst(W.g_x[depth], depth), nodst(), nodst()};
+            if ((rc = dc_bwd(L.dec[depth], in, tape(t, W.o_zdec[depth]), feat(W.g_y[depth], depth), gin, depth)) != HN_OK) return rc;
+        }
+        for (int d = depth - 1; d >= 0; --d) {   // encoder, bottom up
+            // down[d]: backward-data = the transposed-convolution kernel on the convolution weights; added to the skip gradient
+            if ((rc = module_conv8x8(ctx, W.g_x[d + 1], k8(d, 1, 0, false), true, W.tmp8, B, side(d + 1), side(d + 1), s)) != HN_OK) return rc;
+            const long tot8 = (long)B * kFeat * plane(d);
+            hipLaunchKernelGGL(k_add, dim3((unsigned)((tot8 + 255) / 256)), dim3(256), 0, s, W.g_out[d], W.tmp8, tot8);
+            wgrad8(W.g_x[d + 1], d + 1, tape(t, W.o_out[d]), L.down[d].w);
+            bias8(W.g_x[d + 1], d + 1, L.down[d].b);
+            {   // conv_state: new_state = DC(cat[out, state])
+                const TSrc in[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
+                const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 1), state_dst(W.g_st[cur_st ^ 1], d, 0), nodst()};
+                if ((rc = dc_bwd(L.st[d], in, tape(t, W.o_zst[d]), state_src(W.g_st[cur_st], d), gin, d)) != HN_OK) return rc;
+            }
+            {   // conv_signal: out = DC(cat[x, state])
+                const TSrc in[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
+                const TDst gin[3] = {featdst(W.g_x[d], d), state_dst(W.g_st[cur_st ^ 1], d, 1), nodst()};
+                if ((rc = dc_bwd(L.sig[d], in, tape(t, W.o_zsig[d]), feat(W.g_out[d], d), gin, d)) != HN_OK) return rc;
+            }
+        }
+        {   // inc: DC(cat[wf, 1e3 * res, sigmas]); the sigma channels need no gradient
+            const TSrc in[3] = {TSrc{wf_in, 2 * p0, p0, 2, 1.f, 0}, TSrc{res_in, 2 * p0, p0, 2, 1e3f, 0}, TSrc{ctx->tab.sigmas, 0, p0, 2, 1.f, 0}};
+            const TDst gin[3] = {TDst{G, 2 * p0, p0, 2, 1.f, 1}, TDst{W.g_res, 2 * p0, p0, 2, 1e3f, 0}, nodst()};
+            if ((rc = dc_bwd(L.inc, in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0)) != HN_OK) return rc;
+        }
+        cur_st ^= 1;
+        HN_HIP(ctx, hipGetLastError());
+        return HN_OK;
+    }
+};
+
+int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
+    auto& W = ctx->tr;
+    const int n = ctx->tab.n, depth = ctx->depth;
+    if (W.tape != nullptr && W.n == n && W.depth == depth && batch <= W.batch && n_unroll <= W.n_unroll) return HN_OK;
+    HN_HIP(ctx, hipDeviceSynchronize());
+    const int nb = batch > W.batch || W.n != n || W.depth != depth ? batch : W.batch;
+    const int nu = n_unroll > W.n_unroll ? n_unroll : W.n_unroll;
+    train_free(ctx);
+    auto plane = [&](int d) { return (size_t)(n >> d) * (n >> d); };
+    size_t pos = 0;
+    auto take = [&](size_t ch, int d) { const size_t o = pos; pos += (size_t)nb * ch * plane(d); return o; };
+    W.o_zinc = take(kFeat, 0);
+    for (int d = 0; d <= depth; ++d) {
+        W.o_x[d] = take(kFeat, d);
+        W.o_zdec[d] = take(kFeat, d);
+        W.o_y[d] = take(kFeat, d);
+        if (d < depth) {
+            W.o_zsig[d] = take(kFeat, d);
+            W.o_out[d] = take(kFeat, d);
+            W.o_zst[d] = take(kState, d);
+            W.o_u[d] = take(kFeat, d);
+        }
+    }
+    W.step_floats = pos;
+    HN_HIP(ctx, hipMalloc((void**)&W.tape, sizeof(float) * W.step_floats * nu));
+    size_t g = 0;
+    auto gtake = [&](size_t floats) { const size_t o = g; g += floats; return o; };
+    size_t o_gx[kMaxDepth + 1], o_gy[kMaxDepth + 1], o_go[kMaxDepth], o_gu[kMaxDepth];
+    for (int d = 0; d <= depth; ++d) {
+        o_gx[d] = gtake((size_t)nb * kFeat * plane(d));
+        o_gy[d] = gtake((size_t)nb * kFeat * plane(d));
+        if (d < depth) { o_go[d] = gtake((size_t)nb * kFeat * plane(d)); o_gu[d] = gtake((size_t)nb * kFeat * plane(d)); }
+    }
+    const size_t o_gz = gtake((size_t)nb * kFeat * plane(0)), o_tmp = gtake((size_t)nb * kFeat * plane(0));
+    const size_t o_wf0 = gtake((size_t)nb * 2 * plane(0)), o_wf1 = gtake((size_t)nb * 2 * plane(0)), o_res = gtake((size_t)nb * 2 * plane(0));
+    const size_t o_st0 = gtake((size_t)nb * kState * ctx->state_len), o_st1 = gtake((size_t)nb * kState * ctx->state_len);
+    HN_HIP(ctx, hipMalloc((void**)&W.gbuf, sizeof(float) * g));
+    for (int d = 0; d <= depth; ++d) {
+        W.g_x[d] = W.gbuf + o_gx[d];
+        W.g_y[d] = W.gbuf + o_gy[d];
+        if (d < depth) { W.g_out[d] = W.gbuf + o_go[d]; W.g_u[d] = W.gbuf + o_gu[d]; }
+    }
+    W.gz = W.gbuf + o_gz; W.tmp8 = W.gbuf + o_tmp;
+    W.g_wf[0] = W.gbuf + o_wf0; W.g_wf[1] = W.gbuf + o_wf1; W.g_res = W.gbuf + o_res;
+    W.g_st[0] = W.gbuf + o_st0; W.g_st[1] = W.gbuf + o_st1;
+    W.part_floats = (size_t)kPartBlocks * kFeat * kFeat * 64;
+    const size_t slope_rows = (size_t)nb * cdiv(n, 32) * cdiv(n, 32);
+    if (slope_rows > W.part_floats) W.part_floats = slope_rows;
+    HN_HIP(ctx, hipMalloc((void**)&W.part, sizeof(float) * W.part_floats));
+    HN_HIP(ctx, hipMalloc((void**)&W.k8, sizeof(float) * (size_t)depth * 4 * 4096));
+    HN_HIP(ctx, hipMalloc((void**)&W.zero8, sizeof(float) * 8));
+    HN_HIP(ctx, hipMemset(W.zero8, 0, sizeof(float) * 8));
+    HN_HIP(ctx, hipMalloc((void**)&W.sumsq, sizeof(float) * (size_t)nu * nb));
+    W.batch = nb; W.n_unroll = nu; W.n = n; W.depth = depth;
+    return HN_OK;
+}
+
+int train_ready(hn_ctx* ctx, int batch, int n_unroll) {
+    if (!ctx) return HN_ERR_ARG;
+    if (!ctx->have_weights) return fail(ctx, HN_ERR_STATE, "hn_load_weights has not been called (it defines depth and activation)");
+    if (ctx->tab.n == 0) return fail(ctx, HN_ERR_STATE, "hn_set_domain has not been called");
+    if (batch <= 0 || n_unroll <= 0) return fail(ctx, HN_ERR_ARG, "batch and n_unroll must be positive (got %d, %d)", batch, n_unroll);
+    if (ctx->tab.n % (1 << ctx->depth) != 0)
+        return fail(ctx, HN_ERR_ARG, "domain size %d is not divisible by 2^depth = %d", ctx->tab.n, 1 << ctx->depth);
+    return HN_OK;
+}
+
+}  // namespace
+
+void train_free(hn_ctx* ctx) {
+    auto& W = ctx->tr;
+    for (float* p : {W.tape, W.gbuf, W.part, W.k8, W.zero8, W.sumsq}) (void)hipFree(p);
+    W = hn_ctx::TrainWs{};
+}
+
+}  // namespace hn
+
+using namespace hn;
+
+extern "C" {
+
+int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
+    int rc = train_ready(ctx, batch, n_unroll);
+    if (rc != HN_OK) return rc;
+    DeviceGuard guard(ctx);
+    return train_reserve(ctx, batch, n_unroll);
+}
+
+int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const float* res, const float* states, const float* k_sq,
+                  const float* src, int src_batch, int batch, int n_unroll, float loss_scale, float* wf_hist, float* res_hist,
+                  float* st_hist, float* loss, float* grad, float* grad_wf0, float* grad_res0, float* grad_st0, void* stream) {
+    if (!ctx || !weights || !wf || !res || !states || !k_sq || !src || !wf_hist || !res_hist || !st_hist || !loss || !grad)
+        return fail(ctx, HN_ERR_ARG, "hn_train_grad: NULL argument");
+    int rc = train_ready(ctx, batch, n_unroll);
+    if (rc != HN_OK) return rc;
+    if (src_batch != 1 && src_batch != batch) return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
+    DeviceGuard guard(ctx);
+    if ((rc = train_reserve(ctx, batch, n_unroll)) != HN_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    auto& W = ctx->tr;
+    const int n = ctx->tab.n, depth = ctx->depth;
+    Trainer tr{ctx, s, weights, grad, raw_layout(depth), batch, n, depth, ctx->act_kind, (long)ctx->state_len};
+    const size_t fwf = (size_t)batch * 2 * n * n, fst = (size_t)batch * kState * ctx->state_len;
+    // 8x8 weights in the layout of the direct kernels: forward and backward-data of every down / up convolution
+    for (int d = 0; d < depth; ++d) {
+        const float* wd = weights + tr.L.down[d].w;
+        const float* wu = weights + tr.L.up[d].w;
+        float* k = W.k8 + (size_t)d * 4 * 4096;
+        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wd, k, 0);
+        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wd, k + 4096, 1);
+        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wu, k + 2 * 4096, 1);
+        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wu, k + 3 * 4096, 0);
+    }
+    HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));
+    HN_HIP(ctx, hipMemsetAsync(grad, 0, sizeof(float) * tr.L.total, s));
+    for (int t = 0; t < n_unroll; ++t) {
+        const float* wf_in = t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf;
+        const float* res_in = t == 0 ? res : res_hist + (size_t)(t - 1) * fwf;
+        const float* st_in = t == 0 ? states : st_hist + (size_t)(t - 1) * fst;
+        if ((rc = tr.forward_step(t, wf_in, res_in, st_in, wf_hist + (size_t)t * fwf, res_hist + (size_t)t * fwf, st_hist + (size_t)t * fst, k_sq, src, src_batch)) != HN_OK) return rc;
+    }
+    const double count = (double)n_unroll * batch * 2.0 * n * n;
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, s, W.sumsq, n_unroll * batch, (float)((double)loss_scale / count), loss);
+    // backward sweep
+    HN_HIP(ctx, hipMemsetAsync(W.g_wf[0], 0, sizeof(float) * fwf, s));
+    HN_HIP(ctx, hipMemsetAsync(W.g_res, 0, sizeof(float) * fwf, s));
+    HN_HIP(ctx, hipMemsetAsync(W.g_st[0], 0, sizeof(float) * fst, s));
+    int cur_wf = 0, cur_st = 0;
+    const float loss_c = (float)(2.0 * (double)loss_scale / count);
+    for (int t = n_unroll - 1; t >= 0; --t) {
+        const float* wf_in = t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf;
+        const float* res_in = t == 0 ? res : res_hist + (size_t)(t - 1) * fwf;
+        const float* st_in = t == 0 ? states : st_hist + (size_t)(t - 1) * fst;
+        if ((rc = tr.backward_step(t, wf_in, res_in, st_in, res_hist + (size_t)t * fwf, k_sq, loss_c, cur_wf, cur_st)) != HN_OK) return rc;
+    }
+    if (grad_wf0) HN_HIP(ctx, hipMemcpyAsync(grad_wf0, W.g_wf[cur_wf], sizeof(float) * fwf, hipMemcpyDeviceToDevice, s));
+    if (grad_res0) HN_HIP(ctx, hipMemcpyAsync(grad_res0, W.g_res, sizeof(float) * fwf, hipMemcpyDeviceToDevice, s));
+    if (grad_st0) HN_HIP(ctx, hipMemcpyAsync(grad_st0, W.g_st[cur_st], sizeof(float) * fst, hipMemcpyDeviceToDevice, s));
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int hn_adam_step(hn_ctx* ctx, float* weights, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* trainable,
+                 size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value, int64_t step,
+                 void* stream) {
+    if (!ctx || !weights || !grad || !exp_avg || !exp_avg_sq) return fail(ctx, HN_ERR_ARG, "hn_adam_step: NULL argument");
+    if (n == 0) return HN_OK;
+    if (step < 1) return fail(ctx, HN_ERR_ARG, "hn_adam_step: step counts from 1 (got %lld)", (long long)step);
+    if (!(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f)) return fail(ctx, HN_ERR_ARG, "hn_adam_step: betas must lie in [0, 1)");
+    DeviceGuard guard(ctx);
+    const double bc1 = 1.0 - std::pow((double)beta1, (double)step), bc2 = 1.0 - std::pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, weights, grad, exp_avg, exp_avg_sq, trainable, n,
+                       (float)((double)lr / bc1), (float)(1.0 / std::sqrt(bc2)), beta1, beta2, eps, weight_decay, clip_value);
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_floats, void* stream) {
+    if (!ctx || !out) return fail(ctx, HN_ERR_ARG, "hn_train_peek: NULL argument");
+    auto& W = ctx->tr;
+    if (W.tape == nullptr) return fail(ctx, HN_ERR_STATE, "hn_train_peek: hn_train_grad has not run");
+    const int depth = W.depth;
+    if (level < 0 || level > depth) return fail(ctx, HN_ERR_ARG, "hn_train_peek: level %d outside [0, %d]", level, depth);
+    const size_t plane = (size_t)(W.n >> level) * (W.n >> level);
+    const float* p = nullptr;
+    size_t ch = kFeat;
+    const bool enc = level < depth;
+    switch (kind) {
+        case 0: p = W.tape + W.o_x[level]; break;
+        case 1: if (enc) p = W.tape + W.o_zsig[level]; break;
+        case 2: if (enc) p = W.tape + W.o_out[level]; break;
+        case 3: if (enc) { p = W.tape + W.o_zst[level]; ch = kState; } break;
+        case 4: if (enc) p = W.tape + W.o_u[level]; break;
+        case 5: p = W.tape + W.o_zdec[level]; break;
+        case 6: p = W.tape + W.o_y[level]; break;
+        case 7: if (level == 0) p = W.tape + W.o_zinc; break;
+        case 16: p = W.g_x[level]; break;
+        case 18: if (enc) p = W.g_out[level]; break;
+        case 20: if (enc) p = W.g_u[level]; break;
+        case 22: p = W.g_y[level]; break;
+        default: break;
+    }
+    if (p == nullptr) return fail(ctx, HN_ERR_ARG, "hn_train_peek: no tensor of kind %d at level %d", kind, level);
+    // NOTE: the workspace may have been reserved for a larger batch than the last call used; tensors are dense for the
+    // RESERVED batch only in their leading `batch` samples, which is what callers compare.
+    const int64_t count = (int64_t)((size_t)W.batch * ch * plane);
+    const int64_t ncopy = count < max_floats ? count : max_floats;
+    DeviceGuard guard(ctx);
+    if (hipMemcpyAsync(out, p, sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+        return fail(ctx, HN_ERR_HIP, "hn_train_peek: copy failed");
+    return count;
+}
+
+}  // extern "C"

@@ -70,6 +70,41 @@ def pack_weights(state: dict, depth: int = 4, activation: str = "prelu", state_d
     return np.concatenate(parts)
 
 
+def weight_shapes(depth: int = 4, features: int = 8, state_channels: int = 2, inchannels: int = 6) -> dict:
+    """name -> shape of every tensor of the blob, in blob order (architectures.py:63-84, 209-211, 340-388)."""
+    f, s = features, state_channels
+
+    def dc(prefix, cin, cm, co):
+        p = prefix + ".double_conv."
+        return {p + "0.weight": (cm, cin, 3, 3), p + "0.bias": (cm,), p + "1.weight": (1,), p + "2.weight": (co, cm, 3, 3), p + "2.bias": (co,)}
+
+    shapes = dc("inc", inchannels, f, f)
+    for d in range(depth):
+        shapes.update(dc(f"enc.{d}.conv_signal", f + s, f, f))
+        shapes.update({f"enc.{d}.down.weight": (f, f, 8, 8), f"enc.{d}.down.bias": (f,)})
+        shapes.update(dc(f"enc.{d}.conv_state", f + s, s, s))
+    for d in range(depth + 1):
+        shapes.update(dc(f"decode.{d}", 2 * f if d < depth else f, f, f))
+    for d in range(depth):
+        shapes.update({f"up.{d}.weight": (f, f, 8, 8), f"up.{d}.bias": (f,)})
+    shapes.update({"outc.conv.weight": (2, f, 1, 1), "outc.conv.bias": (2,)})
+    assert list(shapes) == weight_names(depth)
+    return shapes
+
+
+def unpack_weights(blob, depth: int = 4) -> dict:
+    """Inverse of pack_weights for state_depth == depth: flat fp32 blob (array or tensor) -> {name: array in PyTorch layout}."""
+    if isinstance(blob, torch.Tensor):
+        blob = blob.detach().to("cpu", torch.float32).numpy()
+    out, pos = {}, 0
+    for name, shape in weight_shapes(depth).items():
+        n = int(np.prod(shape))
+        out[name] = np.array(blob[pos:pos + n], np.float32).reshape(shape)
+        pos += n
+    assert pos == blob.size, (pos, blob.size)
+    return out
+
+
 _MODULE_ENGINES: dict = {}
 
 
@@ -200,6 +235,15 @@ class Engine:
         _lib.check(rc, self.ctx, "hn_residual")
         return out
 
+    def residual_vjp(self, g: torch.Tensor, k_sq: torch.Tensor) -> torch.Tensor:
+        """J^T g of ``residual`` with respect to the wavefield: L^H(g) + k_sq * g."""
+        b = g.shape[0]
+        self._chk(g, (b, 2, self.n, self.n), "cotangent")
+        self._chk(k_sq, (b, 1, self.n, self.n), "k_sq")
+        out = torch.empty_like(g)
+        _lib.check(self.lib.hn_residual_vjp(self.ctx, _ptr(g), _ptr(k_sq), _ptr(out), b, self._stream()), self.ctx, "hn_residual_vjp")
+        return out
+
     def rmse(self, res: torch.Tensor) -> torch.Tensor:
         b = res.shape[0]
         self._chk(res, (b, 2, self.n, self.n), "residual")
@@ -284,6 +328,60 @@ class Engine:
         rc = self.lib.hn_step(self.ctx, _ptr(wf), _ptr(res), _ptr(states), _ptr(k_sq), _ptr(src), src.shape[0], b,
                               int(n_iter), _ptr(res_hist), _ptr(wf_hist), _ptr(st_hist), _ptr(rmse_hist), self._stream())
         _lib.check(rc, self.ctx, "hn_step")
+
+    # ---- training step (hn_train_grad / hn_adam_step) -------------------------------------------------
+    def train_reserve(self, batch: int, n_unroll: int):
+        _lib.check(self.lib.hn_train_reserve(self.ctx, int(batch), int(n_unroll)), self.ctx, "hn_train_reserve")
+
+    def train_grad(self, weights, wf, res, states, k_sq, src, n_unroll: int, loss_scale: float = 1e4, input_grads: bool = False,
+                   grad: Optional[torch.Tensor] = None) -> dict:
+        """Loss and gradients of ``n_unroll`` unrolled solver iterations (hybridnet.py:399-409).  ``weights``: flat device blob
+        (pack_weights order).  Returns loss [1], grad (same shape as weights), the wavefield / residual / state lists of
+        ``n_steps(..., True, True)`` as stacked tensors, and with ``input_grads`` the gradients of the three inputs."""
+        b, n_w = wf.shape[0], int(self.lib.hn_weight_count(8, self.depth, 2))
+        self._chk(weights, (n_w,), "weights")
+        self._chk(wf, (b, 2, self.n, self.n), "wavefield")
+        self._chk(res, (b, 2, self.n, self.n), "residual")
+        self._chk(states, (b, 2, self.state_len), "hidden state")
+        self._chk(k_sq, (b, 1, self.n, self.n), "k_sq")
+        self._chk(src, (src.shape[0], 2, self.n, self.n), "source")
+        T = int(n_unroll)
+        new = lambda *shape: torch.empty(shape, device=self.device, dtype=torch.float32)  # noqa: E731
+        out = {"wavefields": new(T, b, 2, self.n, self.n), "residuals": new(T, b, 2, self.n, self.n), "states": new(T, b, 2, self.state_len),
+               "loss": new(1), "grad": grad if grad is not None else new(n_w)}
+        self._chk(out["grad"], (n_w,), "grad")
+        g_in = [new(*wf.shape), new(*res.shape), new(*states.shape)] if input_grads else [None, None, None]
+        rc = self.lib.hn_train_grad(self.ctx, _ptr(weights), _ptr(wf), _ptr(res), _ptr(states), _ptr(k_sq), _ptr(src), src.shape[0], b, T,
+                                    float(loss_scale), _ptr(out["wavefields"]), _ptr(out["residuals"]), _ptr(out["states"]), _ptr(out["loss"]),
+                                    _ptr(out["grad"]), _ptr(g_in[0]), _ptr(g_in[1]), _ptr(g_in[2]), self._stream())
+        _lib.check(rc, self.ctx, "hn_train_grad")
+        if input_grads:
+            out.update(grad_wf=g_in[0], grad_res=g_in[1], grad_states=g_in[2])
+        return out
+
+    def adam_step(self, weights, grad, exp_avg, exp_avg_sq, step: int, lr: float, betas=(0.9, 0.95), eps: float = 1e-8,
+                  weight_decay: float = 0.0, clip_value: float = 0.0, trainable: Optional[torch.Tensor] = None):
+        """clip_grad_value_ + torch.optim.Adam step (hybridnet.py:172-176, 250-258) on caller-owned flat device tensors, in place."""
+        n = weights.numel()
+        for t, name in ((weights, "weights"), (grad, "grad"), (exp_avg, "exp_avg"), (exp_avg_sq, "exp_avg_sq")):
+            self._chk(t, (n,), name)
+        if trainable is not None and (trainable.dtype != torch.uint8 or trainable.numel() != n or trainable.device != self.device):
+            raise ValueError("trainable must be a uint8 device tensor with one entry per weight")
+        rc = self.lib.hn_adam_step(self.ctx, _ptr(weights), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq), _ptr(trainable), n, float(lr),
+                                   float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(clip_value), int(step), self._stream())
+        _lib.check(rc, self.ctx, "hn_adam_step")
+
+    PEEK = {"x": 0, "sig_mid": 1, "out": 2, "st_mid": 3, "u": 4, "dec_mid": 5, "y": 6, "inc_mid": 7, "g_x": 16, "g_out": 18, "g_u": 20, "g_y": 22}
+
+    def train_peek(self, kind: str, level: int, batch: int) -> torch.Tensor:
+        """Debug / test aid: one tape tensor or activation gradient of iteration 0 of the last train_grad call."""
+        ch = 2 if kind == "st_mid" else 8
+        m = self.n >> level
+        out = torch.empty(batch, ch, m, m, device=self.device, dtype=torch.float32)
+        got = self.lib.hn_train_peek(self.ctx, self.PEEK[kind], int(level), _ptr(out), out.numel(), self._stream())
+        if got < 0:
+            _lib.check(int(got), self.ctx, "hn_train_peek")
+        return out
 
     # ---- measurement hooks ---------------------------------------------------------------
     KERNEL_IDS = 35

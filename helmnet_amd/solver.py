@@ -6,8 +6,9 @@ classmethod, re-implemented without Lightning), ``hparams``, ``freeze``, ``devic
 set_source_maps / set_multiple_sources / reset_source`` (:133-170), ``get_initials``
 (:522-538), ``apply_laplacian`` (:540-542), ``get_residual`` (:544-556), ``single_step``
 (:558-584), ``n_steps`` (:586-623), ``forward`` (:654-697), ``forward_variable_src``
-(:699-754), ``test_loss_function`` (:295-297).  The training half (replay buffer, optimisers,
-Lightning hooks) is out of scope.
+(:699-754), ``test_loss_function`` (:295-297), ``loss_function`` (:285-293).  The training half (replay buffer,
+``training_step``, optimiser, scheduler) lives in ``helmnet_amd.training`` (``solver.trainer()``), on ``hn_train_grad`` /
+``hn_adam_step``; Lightning's hooks and TensorBoard logging have no counterpart.
 
 All per-iteration arithmetic runs in libhelmnet_hip.so: ``forward`` / ``n_steps`` hand the whole
 loop to ``hn_step`` (fused HIP kernels), ``get_residual`` to ``hn_residual``, ``f`` to ``hn_unet``.
@@ -229,6 +230,17 @@ class IterativeSolver(nn.Module):
         """Per-sample residual RMSE (hybridnet.py:295-297); plain tensor reduction for callers
         that hold a residual tensor -- the solver loop itself uses the fused hn_step norms."""
         return x.pow(2).mean((1, 2, 3)).sqrt()
+
+    def loss_function(self, x):
+        """hybridnet.py:285-293: mean square over every element ('mse' is the only loss the reference implements)."""
+        if self.hparams.loss == "mse":
+            return x.pow(2).mean()
+        raise NotImplementedError("The loss function {} is not implemented".format(self.hparams.loss))
+
+    def trainer(self, **kwargs):
+        """The training half of the reference class (replay buffer, training_step, Adam + ReduceLROnPlateau) for this solver."""
+        from .training import Trainer
+        return Trainer(self, **kwargs)
 
     def get_initials(self, sos_maps: torch.Tensor):
         k_sq = (self.hparams.omega / sos_maps) ** 2

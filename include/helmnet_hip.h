@@ -80,7 +80,7 @@ enum hn_option {
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };
 
-#define HN_ABI_VERSION 3
+#define HN_ABI_VERSION 4
 int hn_abi_version(void);
 
 /* Create / destroy a context on HIP device `device_id`. */
@@ -138,6 +138,12 @@ int hn_laplacian(hn_ctx* ctx, const float* wf, float* out, int batch, void* stre
 int hn_residual(hn_ctx* ctx, const float* wf, const float* k_sq, const float* src, int src_batch,
                 float* res, int batch, void* stream);
 
+/* out[B,2,n,n] = J^T g: the vector-Jacobian product of hn_residual with respect to the wavefield, i.e. the adjoint operator
+ * L^H(g) + k_sq * g (real k_sq; L^H is the conjugate transpose of the spectral Laplacian with PML).  What torch.autograd
+ * computes when the reference back-propagates through get_residual (hybridnet.py:544-556) in training_step (:385-413); also
+ * the building block of adjoint-state / normal-equation solvers.  g must not alias out. */
+int hn_residual_vjp(hn_ctx* ctx, const float* g, const float* k_sq, float* out, int batch, void* stream);
+
 /* rmse[B] = sqrt(mean_{c,h,w} res^2).  Replaces test_loss_function (hybridnet.py:295-297). */
 int hn_rmse(hn_ctx* ctx, const float* res, float* rmse, int batch, void* stream);
 
@@ -179,6 +185,47 @@ int hn_out_conv(hn_ctx* ctx, const float* x, const float* weights_host, float* o
 int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq, const float* src,
             int src_batch, int batch, int n_iter, float* res_hist, float* wf_hist, float* st_hist,
             float* rmse_hist, void* stream);
+
+/* ---- training step (hybridnet.py:385-413 training_step, :250-283 configure_optimizers, :172-176
+ * on_after_backward).  The caller owns every training tensor: the weights as ONE flat device blob in the order of
+ * hn_load_weights (PyTorch layouts inside: conv [out,in,kh,kw], transposed conv [in,out,kh,kw]), its gradient, and the
+ * Adam moments -- so a data-parallel job all-reduces `grad` as a single 193 KB bucket (RCCL) between the two calls and a
+ * checkpoint is those tensors.  The context supplies the architecture (depth / activation of the last hn_load_weights),
+ * the spectral tables of hn_set_domain and the activation tape (grown on demand; hn_train_reserve pre-allocates).
+ * fp32 throughout; gradients are accumulated in a fixed order (per-block partial sums + one reduction, no atomics):
+ * bit-reproducible.  state_depth must equal depth. */
+
+/* Pre-allocate the tape for `batch` samples x `n_unroll` unrolled iterations (optional). */
+int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll);
+
+/* Loss and gradients of n_unroll unrolled solver iterations started from (wf, res, states):
+ *     for t < n_unroll: d = HybridNet_w(cat[wf, 1e3*res, sigmas]); wf += d/1e3; res = L(wf) + k_sq*wf - src   (single_step :558-584)
+ *     loss = loss_scale * mean over (n_unroll, B, 2, n, n) of res_t^2        (training_step :403-409, loss_scale = 1e4)
+ * Inputs (device, not modified): weights [hn_weight_count], wf / res [B,2,n,n], states [B,2,L], k_sq [B,1,n,n],
+ * src [src_batch,2,n,n].  Outputs (device): wf_hist / res_hist [n_unroll,B,2,n,n] and st_hist [n_unroll,B,2,L] (required: the
+ * lists n_steps(..., True, True) returns, :586-623 -- they are also the tape of the backward pass); loss [1];
+ * grad [hn_weight_count] = d loss / d weights (overwritten); grad_wf0 / grad_res0 [B,2,n,n], grad_st0 [B,2,L] =
+ * d loss / d (wf, res, states) (optional, NULL to skip). */
+int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const float* res, const float* states, const float* k_sq,
+                  const float* src, int src_batch, int batch, int n_unroll, float loss_scale, float* wf_hist, float* res_hist,
+                  float* st_hist, float* loss, float* grad, float* grad_wf0, float* grad_res0, float* grad_st0, void* stream);
+
+/* One optimiser step on caller-owned device arrays of n floats: gradient value clipping to [-clip_value, clip_value]
+ * (clip_value <= 0: none; torch.nn.utils.clip_grad_value_, hybridnet.py:172-176), then torch.optim.Adam as configured by the
+ * reference (hybridnet.py:250-258: betas (0.9, 0.95), L2 weight decay added to the gradient, no amsgrad):
+ *     g += weight_decay * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
+ * `step` counts from 1.  `trainable` (nullable, n bytes on the device): entries with 0 are left untouched (constant slopes of
+ * relu / leakyrelu, zero padding). */
+int hn_adam_step(hn_ctx* ctx, float* weights, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* trainable,
+                 size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value, int64_t step,
+                 void* stream);
+
+/* Test / debugging aid: copy one tensor of the LAST unrolled iteration processed by hn_train_grad's backward sweep (i.e.
+ * iteration 0 of the call) out of the library's workspace into `out` (device, at most max_floats; returns the number of floats
+ * the tensor has, or a negative hn_status).  kind: 0 x_d (level input), 1 conv_signal mid, 2 out_d (skip), 3 conv_state mid,
+ * 4 upsampled u_d, 5 decoder mid (level == depth: bottleneck), 6 decoder output y_d, 7 inc mid; 16 + k: the gradient of the
+ * loss with respect to tensor kind k in {0, 2, 4, 6}. */
+int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_floats, void* stream);
 
 /* Optional per-kernel timing (measurement only; bench.py's roofline block uses it).  While a
  * kernel id's bit is set in `kernel_mask`, every launch of that kernel inside hn_step / hn_unet /

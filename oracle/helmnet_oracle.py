@@ -241,10 +241,21 @@ def activation(h: Tensor, name: str, slope: Optional[Tensor]) -> Tensor:
     raise NotImplementedError(name)
 
 
-def double_conv(x: Tensor, w: Dict[str, Tensor], prefix: str, act: str = "prelu") -> Tensor:
+def _keep(tape: Optional[dict], name: str, x: Tensor) -> Tensor:
+    """Record an intermediate tensor (and ask autograd to keep its gradient) -- used by the training parity tests to
+    localise a mismatch; no effect when ``tape`` is None."""
+    if tape is not None:
+        if x.requires_grad:
+            x.retain_grad()
+        tape[name] = x
+    return x
+
+
+def double_conv(x: Tensor, w: Dict[str, Tensor], prefix: str, act: str = "prelu", tape: Optional[dict] = None) -> Tensor:
     """helmnet/architectures.py:63-84: conv3x3(pad 1) -> activation -> conv3x3(pad 1)."""
     p = prefix + ".double_conv."
     h = F.conv2d(x, w[p + "0.weight"], w[p + "0.bias"], padding=1)
+    _keep(tape, prefix + ".mid", h)
     h = activation(h, act, w.get(p + "1.weight"))
     return F.conv2d(h, w[p + "2.weight"], w[p + "2.bias"], padding=1)
 
@@ -269,12 +280,12 @@ def unflatten_states(flat: Tensor, n: int, depth: int) -> List[Tensor]:
 
 
 def unet_forward(x6: Tensor, states: List[Tensor], w: Dict[str, Tensor], depth: int = 4, act: str = "prelu",
-                 state_depth: int = None) -> Tuple[Tensor, List[Tensor]]:
+                 state_depth: int = None, tape: Optional[dict] = None) -> Tuple[Tensor, List[Tensor]]:
     """helmnet/architectures.py:439-465 (HybridNet.forward) with
     EncoderBlock.forward (:240-252) inlined; levels d >= state_depth run without state (:250-251) and keep
     whatever their state slot held.  Returns (d, new_states)."""
     state_depth = depth if state_depth is None else state_depth
-    x = double_conv(x6, w, "inc", act)
+    x = _keep(tape, "x0", double_conv(x6, w, "inc", act, tape))
     skips, new_states = [], []
     for d in range(depth):
         if d >= state_depth:
@@ -283,25 +294,25 @@ def unet_forward(x6: Tensor, states: List[Tensor], w: Dict[str, Tensor], depth: 
             skips.append(out)
             x = F.conv2d(out, w[f"enc.{d}.down.weight"], w[f"enc.{d}.down.bias"], stride=2, padding=3)
             continue
-        out = double_conv(torch.cat([x, states[d]], 1), w, f"enc.{d}.conv_signal", act)
-        new_states.append(double_conv(torch.cat([out, states[d]], 1), w, f"enc.{d}.conv_state", act))
+        out = _keep(tape, f"out{d}", double_conv(torch.cat([x, states[d]], 1), w, f"enc.{d}.conv_signal", act, tape))
+        new_states.append(double_conv(torch.cat([out, states[d]], 1), w, f"enc.{d}.conv_state", act, tape))
         skips.append(out)
-        x = F.conv2d(out, w[f"enc.{d}.down.weight"], w[f"enc.{d}.down.bias"], stride=2, padding=3)
-    x = double_conv(x, w, f"decode.{depth}", act)
+        x = _keep(tape, f"x{d + 1}", F.conv2d(out, w[f"enc.{d}.down.weight"], w[f"enc.{d}.down.bias"], stride=2, padding=3))
+    x = _keep(tape, f"y{depth}", double_conv(x, w, f"decode.{depth}", act, tape))
     for d in range(depth - 1, -1, -1):
-        x = F.conv_transpose2d(x, w[f"up.{d}.weight"], w[f"up.{d}.bias"], stride=2, padding=3)
-        x = double_conv(torch.cat([x, skips[d]], 1), w, f"decode.{d}", act)
+        x = _keep(tape, f"u{d}", F.conv_transpose2d(x, w[f"up.{d}.weight"], w[f"up.{d}.bias"], stride=2, padding=3))
+        x = _keep(tape, f"y{d}", double_conv(torch.cat([x, skips[d]], 1), w, f"decode.{d}", act, tape))
     return F.conv2d(x, w["outc.conv.weight"], w["outc.conv.bias"]), new_states
 
 
 # --------------------------------------------------------------------------
 # Solver loop
 # --------------------------------------------------------------------------
-def single_step(wf, k_sq, res, states, w, source, t: SpectralTables, depth: int = 4):
+def single_step(wf, k_sq, res, states, w, source, t: SpectralTables, depth: int = 4, act: str = "prelu", tape: Optional[dict] = None):
     """helmnet/hybridnet.py:558-584."""
     sig = t.sigmas.to(wf.dtype).unsqueeze(0).repeat(wf.shape[0], 1, 1, 1)
     inp = torch.cat([wf, 1e3 * res, sig], dim=1)
-    d, new_states = unet_forward(inp, states, w, depth)
+    d, new_states = unet_forward(inp, states, w, depth, act, tape=tape)
     up = d / 1e3 + wf
     return up, get_residual(up, k_sq, source, t), new_states
 
@@ -322,3 +333,40 @@ def solve(sos: Tensor, w: Dict[str, Tensor], source: Tensor, t: SpectralTables, 
         wf, res, states = single_step(wf, k_sq, res, states, w, source, t, depth)
         trace.append(test_loss_function(res) if keep == "rmse" else res)
     return {"wavefield": wf, "residual": res, "states": states, "trace": trace}
+
+
+# --------------------------------------------------------------------------
+# Training step
+# --------------------------------------------------------------------------
+def training_loss(wf: Tensor, res: Tensor, states_flat: Tensor, k_sq: Tensor, source: Tensor, w: Dict[str, Tensor],
+                  t: SpectralTables, n_unroll: int = 10, depth: int = 4, act: str = "prelu", loss_scale: float = 1e4,
+                  tape: Optional[dict] = None):
+    """helmnet/hybridnet.py:399-409 (the differentiable core of ``training_step``): ``f.set_states(h_states, flatten=True)``
+    -> ``n_steps(wavefields, k_sqs, residual, unrolling_steps, True, True)`` (:586-623) -> ``loss = 1e4 * cat(residuals).pow(2).mean()``.
+    Every argument may require grad; gradients come from ``torch.autograd`` exactly as in the reference.  ``tape`` (optional
+    dict) receives the intermediate tensors of the FIRST unrolled iteration.  Returns (loss, wavefields, residuals, flat states)."""
+    n = wf.shape[-1]
+    states = unflatten_states(states_flat, n, depth)
+    wfs, ress, sts = [], [], []
+    for it in range(n_unroll):
+        wf, res, states = single_step(wf, k_sq, res, states, w, source, t, depth, act, tape if it == 0 else None)
+        wfs.append(wf)
+        ress.append(res)
+        sts.append(flatten_states(states))
+    loss = loss_scale * torch.cat(ress).pow(2).mean()
+    return loss, wfs, ress, sts
+
+
+def adam_reference(weights: Tensor, grads: Sequence[Tensor], lr: float, betas=(0.9, 0.95), eps: float = 1e-8,
+                   weight_decay: float = 0.0, clip_value: float = 0.0) -> Tensor:
+    """helmnet/hybridnet.py:172-176 + :250-258 on ONE flat parameter vector: for every gradient in ``grads`` (one optimiser step
+    each) ``clip_grad_value_`` then ``torch.optim.Adam(lr, betas, weight_decay).step()``.  Returns the updated copy."""
+    p = torch.nn.Parameter(weights.clone())
+    opt = torch.optim.Adam([p], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+    for g in grads:
+        opt.zero_grad()
+        p.grad = g.clone()
+        if clip_value > 0:
+            torch.nn.utils.clip_grad_value_([p], clip_value)
+        opt.step()
+    return p.detach()
