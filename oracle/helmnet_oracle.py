@@ -245,6 +245,12 @@ def _keep(tape: Optional[dict], name: str, x: Tensor) -> Tensor:
     """Record an intermediate tensor (and ask autograd to keep its gradient) -- used by the training parity tests to
     localise a mismatch; no effect when ``tape`` is None."""
     if tape is not None:
+        force = tape.get("__force__")
+        if force is not None and name in force:
+            # evaluate the graph AT the given value (straight-through: the gradient passes unchanged).  The HIP path's
+            # pre-activations differ from these by fp32 rounding; a PReLU input within rounding of zero then takes the other
+            # branch, and a comparison of gradients would measure that coin flip instead of the kernels
+            x = force[name].to(x.dtype).detach() + (x - x.detach())   # value: exactly the forced one; gradient: identity
         if x.requires_grad:
             x.retain_grad()
         tape[name] = x
@@ -255,7 +261,7 @@ def double_conv(x: Tensor, w: Dict[str, Tensor], prefix: str, act: str = "prelu"
     """helmnet/architectures.py:63-84: conv3x3(pad 1) -> activation -> conv3x3(pad 1)."""
     p = prefix + ".double_conv."
     h = F.conv2d(x, w[p + "0.weight"], w[p + "0.bias"], padding=1)
-    _keep(tape, prefix + ".mid", h)
+    h = _keep(tape, prefix + ".mid", h)
     h = activation(h, act, w.get(p + "1.weight"))
     return F.conv2d(h, w[p + "2.weight"], w[p + "2.bias"], padding=1)
 
