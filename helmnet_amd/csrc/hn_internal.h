@@ -174,9 +174,12 @@ struct hn_ctx {
         float* gbuf = nullptr;       // gradient buffers, carved below
         float *g_x[hn::kMaxDepth + 1]{}, *g_out[hn::kMaxDepth]{}, *g_u[hn::kMaxDepth]{}, *g_y[hn::kMaxDepth + 1]{};
         float *gz = nullptr, *tmp8 = nullptr, *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
-        float* part = nullptr;       // per-block partial sums of the weight-gradient kernels
+        float* part = nullptr;       // [256 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
         size_t part_floats = 0;
-        float* k8 = nullptr;         // 8x8 weights re-packed for the direct kernels: [depth][4][4096]
+        double* slope_part = nullptr; // [3 depth + 2 DoubleConvs][slope_stride]: per-block sums of the PReLU-slope gradients (float64)
+        size_t slope_stride = 0;
+        float* w3 = nullptr;         // 3x3 weights packed [cin][9][cout]: forward arrangement, then backward-data
+        float* k8 = nullptr;         // 8x8 weights as fp32 matrix-core fragments: [depth][4][4096]
         float* zero8 = nullptr;      // 8 zeros (bias of the backward-data convolutions)
         float* sumsq = nullptr;      // [n_unroll][batch] per-sample sum of squared residuals
     } tr;

@@ -12,13 +12,15 @@
 //     leaves (mid z, output) behind; the activation is applied when a consumer stages its input.  The tape of all unrolled
 //     iterations stays in HBM (2.8 MB per sample-iteration at 96^2, 20 MB at 256^2: 0.9 / 6.3 GB for the reference's batch of
 //     32 x 10 iterations -- nothing next to 288 GB, so nothing is recomputed).
-//   * Backward-data of a 3x3 convolution is the same direct kernel (k_conv3) reading the forward weights transposed and
-//     flipped; the activation derivative and the PReLU-slope gradient ride in its epilogue.  Backward-data of the 8x8
-//     stride-2 convolution is the transposed-convolution kernel of the inference path with the forward weights read as
-//     [in, out, kh, kw], and vice versa (hn_unet.hip's direct kernels, weights re-packed on the device once per call).
-//   * Weight gradients: one block per run of tiles accumulates its [cout, cin, kh, kw] (+ bias) partial sums in registers,
-//     writes them to a partials table, and one reduction kernel adds the table into the gradient blob in a fixed order -- no
-//     atomics, so gradients are bit-reproducible and a sharded batch sums to the same bits as its shards in rank order.
+//   * Backward-data of a 3x3 convolution is the same direct kernel (k_conv3) on the forward weights transposed and flipped
+//     (both arrangements are packed on the device once per call and read as wave-uniform scalar loads); the activation
+//     derivative and the PReLU-slope gradient ride in its epilogue.  Backward-data of the 8x8 stride-2 convolution is the
+//     transposed-convolution matrix-core kernel of the inference path (hn_mfma.hip) with the forward weights read as
+//     [in, out, kh, kw], and vice versa; their A-operand fragments are packed on the device too.
+//   * Weight gradients: a block accumulates the [cout, cin, kh, kw] (+ bias) sums of its run of tiles in registers and adds
+//     them to ITS row of a [256 rows][blob] table that collects all layers and all unrolled iterations; ONE reduction kernel
+//     at the end of the call sums the rows in a fixed order into the gradient blob -- no atomics: gradients are
+//     bit-reproducible.
 //   * The spectral operator is linear: its backward is the adjoint pass spec_adjoint (hn_spectral.hip).
 //   * Everything is enqueued on the caller's stream; the only host synchronisation is none.
 #include <cmath>
@@ -86,87 +88,121 @@ __device__ __forceinline__ float act_grad(float x, int kind, float slope) {
 struct TSrc { const float* p; long sb, sc; int nch; float scale; int act; };   // act: the activation is applied while staging (p holds pre-activations)
 struct TDst { float* p; long sb, sc; int nch; float scale; int accum; };      // p == nullptr: the group is discarded
 
+// Stage one [rows x cols] window (top-left corner (y0, x0) in image coordinates, zero outside the H x W image) of every channel
+// of an implicit concatenation into LDS, channel c at dst + c * cstride, row pitch `pitch`.  The window positions of a thread
+// are the same for every channel, so their offsets and masks are computed once; per channel the loads are issued
+// unconditionally from clamped addresses (all in flight together, several channels deep) and masked when they are stored.
+template <int ROWS, int COLS, int NT>
+struct WindowStager {
+    static constexpr int NE = (ROWS * COLS + NT - 1) / NT;
+    int goff[NE], lidx[NE];
+    unsigned okmask = 0, inmask = 0;
+    __device__ __forceinline__ void setup(int tid, int y0, int x0, int H, int W, int pitch) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int e = tid + i * NT, ir = e / COLS, ic = e - ir * COLS;
+            const int y = y0 + ir, x = x0 + ic;
+            const bool in = e < ROWS * COLS, ok = in && y >= 0 && y < H && x >= 0 && x < W;
+            goff[i] = ok ? y * W + x : 0;
+            lidx[i] = ir * pitch + ic;
+            okmask |= (ok ? 1u : 0u) << i;
+            inmask |= (in ? 1u : 0u) << i;
+        }
+    }
+    // channels [0, nch) of the concatenation src[0..2]; `slope` / `act_kind` for groups staged through the activation
+    __device__ __forceinline__ void stage(const TSrc (&src)[3], int nch, int b, float* dst, int cstride, int act_kind, float slope) const {
+#pragma unroll 4
+        for (int c = 0; c < nch; ++c) {
+            int cs = c, si = 0;
+            if (cs >= src[0].nch) { cs -= src[0].nch; si = 1; if (cs >= src[1].nch) { cs -= src[1].nch; si = 2; } }
+            const TSrc& sr = src[si];
+            const float* p = sr.p + (long)b * sr.sb + (long)cs * sr.sc;
+            float v[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) v[i] = p[goff[i]];
+#pragma unroll
+            for (int i = 0; i < NE; ++i)
+                if (inmask >> i & 1u) {
+                    float x = v[i];
+                    if (sr.act) x = act_fwd(x, act_kind, slope);
+                    dst[c * cstride + lidx[i]] = (okmask >> i & 1u) ? x * sr.scale : 0.f;
+                }
+        }
+    }
+};
+
+// Wave-uniform reads through the constant address space become scalar loads (SGPR operands of the FMAs).
+typedef const float __attribute__((address_space(4))) * CfPtr;
+__device__ __forceinline__ CfPtr cf(const float* p) { return (CfPtr)(uintptr_t)p; }
+
 // ------------------------------------------------------------------------------------------------------------------
-// 3x3 convolution, padding 1, any (cin <= 16) -> CO channels, direct fp32, weights in LDS.
-//   wmode 0  forward:        out[co] = bias[co] + sum_ci sum_k w[co][ci][k] * in[ci](. + k - 1)
-//   wmode 1  backward-data:  out[ci] = sum_co sum_k w[co][ci][8 - k] * in[co](. + k - 1)      (w is the FORWARD weight, [w_o][w_i][3][3])
-//   EPI_ACT: out *= act'(z) (z: the pre-activation tensor the gradient flows back into) and, for PReLU, the partial sum of
-//            out_before * min(z, 0) per block (d loss / d slope).
-// Tile 32 x 32, thread = 1 x 4 strip x all CO channels; input staged 4 channels at a time with a 1-pixel halo.
+// 3x3 convolution, padding 1, any (cin <= 16) -> CO channels, direct fp32 on the vector ALU.
+//   out[co] = bias[co] + sum_ci sum_k wpk[ci][k][co] * in[ci](. + k - 1)
+// wpk is the arrangement k_pack3 wrote: the forward weights as they are (forward pass) or transposed and flipped
+// (backward-data: out = gradient of the input).
+//   EPI_ACT: out *= act'(z) (z: the pre-activation tensor the gradient flows back into) and, for PReLU, this block's partial sum
+//            of out_before * min(z, 0) (d loss / d slope) is added to slope_part[block].
+// Tile 16 x 32, 128 threads, thread = 1 x 4 strip x all CO channels; ALL input channels staged at once (one load phase, one
+// barrier: at the reference's training size a launch is ~2 wavefronts per SIMD, so the serial load -> barrier -> compute
+// chain of a block is what its time is made of).
 // ------------------------------------------------------------------------------------------------------------------
 struct Conv3Args {
     TSrc src[3];
     TDst dst[3];
-    const float* w;
+    const float* wpk;
     const float* bias;
-    int w_o, w_i, wmode;
     int H, W;
     int act_kind;
     const float* slope;
     const float* z;
     long z_sb, z_sc;
-    float* slope_part;
+    double* slope_part;
 };
+constexpr int kC3TH = 16, kC3TW = 32, kC3PI = 36;
 
 template <int CO, bool EPI_ACT>
-__global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
-    constexpr int TH = 32, TW = 32, PI = 36, IR = TH + 2, IC = TW + 2, CH = 4;
-    __shared__ __attribute__((aligned(16))) float s_in[CH * IR * PI + 8];
-    __shared__ __attribute__((aligned(16))) float s_w[16 * 9 * CO];
-    __shared__ float s_red[4];
+__global__ __launch_bounds__(128) void k_conv3(Conv3Args a) {
+    constexpr int TH = kC3TH, TW = kC3TW, PI = kC3PI, IR = TH + 2, IC = TW + 2;
+    extern __shared__ __attribute__((aligned(16))) float s_in[];   // [CI][IR][PI] + 8
+    __shared__ double s_red[2];
     const int tid = threadIdx.x;
     const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int CI = a.src[0].nch + a.src[1].nch + a.src[2].nch;
-    for (int e = tid; e < CI * 9 * CO; e += 256) {
-        const int co = e % CO, r = e / CO, k = r % 9, ci = r / 9;
-        s_w[e] = a.wmode == 0 ? a.w[((long)co * a.w_i + ci) * 9 + k] : a.w[((long)ci * a.w_i + co) * 9 + (8 - k)];
-    }
     const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
+    {
+        WindowStager<IR, IC, 128> st;
+        st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
+        st.stage(a.src, CI, b, s_in, IR * PI, a.act_kind, slope);
+    }
+    __syncthreads();
     const int ry = tid >> 3, sx = tid & 7;   // output row y0 + ry, columns x0 + 4 sx .. + 3
     float acc[4][CO];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
-    for (int c0 = 0; c0 < CI; c0 += CH) {
-        __syncthreads();   // the previous chunk has been consumed (first round: orders the weight stores too)
-        for (int e = tid; e < CH * IR * IC; e += 256) {
-            const int cc = e / (IR * IC), r = e - cc * (IR * IC), ir = r / IC, ic = r - ir * IC;
-            const int c = c0 + cc, y = y0 - 1 + ir, x = x0 - 1 + ic;
-            float v = 0.f;
-            if (c < CI && y >= 0 && y < a.H && x >= 0 && x < a.W) {
-                int cs = c, si = 0;
-                if (cs >= a.src[0].nch) { cs -= a.src[0].nch; si = 1; if (cs >= a.src[1].nch) { cs -= a.src[1].nch; si = 2; } }
-                const TSrc& sr = a.src[si];
-                v = sr.p[(long)b * sr.sb + (long)cs * sr.sc + (long)y * a.W + x];
-                if (sr.act) v = act_fwd(v, a.act_kind, slope);
-                v *= sr.scale;
-            }
-            s_in[(cc * IR + ir) * PI + ic] = v;
-        }
-        __syncthreads();
-        const int nc = CI - c0 < CH ? CI - c0 : CH;
-        for (int cc = 0; cc < nc; ++cc) {
-            const float* t = &s_in[(cc * IR + ry) * PI + 4 * sx];
-            const float* wc = &s_w[(c0 + cc) * 9 * CO];
+    const CfPtr wc = cf(a.wpk);
+#pragma unroll 1
+    for (int ci = 0; ci < CI; ++ci) {
+        const float* t = &s_in[(ci * IR + ry) * PI + 4 * sx];
+        const CfPtr wq = wc + ci * 9 * CO;
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const float4 lo = *reinterpret_cast<const float4*>(t + dy * PI);
-                const float2 hi = *reinterpret_cast<const float2*>(t + dy * PI + 4);
-                const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+        for (int dy = 0; dy < 3; ++dy) {
+            const float4 lo = *reinterpret_cast<const float4*>(t + dy * PI);
+            const float2 hi = *reinterpret_cast<const float2*>(t + dy * PI + 4);
+            const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx)
+            for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-                    for (int c = 0; c < CO; ++c) {
-                        const float wv = wc[(dy * 3 + dx) * CO + c];
+                for (int c = 0; c < CO; ++c) {
+                    const float wv = wq[(dy * 3 + dx) * CO + c];
 #pragma unroll
-                        for (int p = 0; p < 4; ++p) acc[p][c] = fmaf(wv, v[p + dx], acc[p][c]);
-                    }
-            }
+                    for (int p = 0; p < 4; ++p) acc[p][c] = fmaf(wv, v[p + dx], acc[p][c]);
+                }
         }
     }
     const int y = y0 + ry;
-    float sp = 0.f;
+    double sp = 0.0;   // the slope gradient is ONE number summed over every pixel of the layer with both signs: kept in float64
     if (y < a.H) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
@@ -181,7 +217,7 @@ __global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
                 float v = acc[p][c] + bias;
                 if (EPI_ACT) {
                     const float zz = a.z[(long)b * a.z_sb + (long)c * a.z_sc + (long)y * a.W + x];
-                    if (zz <= 0.f) sp = fmaf(v, zz, sp);
+                    if (zz <= 0.f) sp += (double)v * (double)zz;
                     v *= act_grad(zz, a.act_kind, slope);
                 }
                 if (ds.p != nullptr) {
@@ -197,15 +233,16 @@ __global__ __launch_bounds__(256) void k_conv3(Conv3Args a) {
         for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
         if ((tid & 63) == 0) s_red[tid >> 6] = sp;
         __syncthreads();
-        if (tid == 0) a.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (tid == 0) a.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] += s_red[0] + s_red[1];
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Weight + bias gradient of a 3x3 convolution:  dW[co][ci][k] = sum_{b,y,x} g[co](y, x) * in[ci](y + ky - 1, x + kx - 1),
-// db[co] = sum g[co].  Thread = one (ci, k) pair (the bias is one more pair with in == 1) x all CO channels x a subset of the
-// tile rows; a block walks a strided run of 16 x 32 tiles and writes one row of the partials table
-// [gridDim.x][CO * CI * 9 + CO], laid out like the blob (weight [CO][CI][3][3], then bias [CO]).
+// Weight + bias gradient of a 3x3 convolution:  dW[co][ci][ky][kx] = sum_{b,y,x} g[co](y, x) * in[ci](y + ky - 1, x + kx - 1),
+// db[co] = sum g[co].  Thread = one (ci, ky) row of taps (the bias is one more "row" with in == 1) x 3 kx x all CO channels x a
+// subset of the tile rows: walking along x it keeps a 3-wide sliding window of the input, so a pixel costs one LDS read of
+// the input and one broadcast read of the CO gradients for 3 * CO FMAs.  A block walks a strided run of 16 x 32 tiles and ADDS
+// its sums to its row of the partials table (columns laid out like the blob: weight [CO][CI][3][3], then bias [CO]).
 // ------------------------------------------------------------------------------------------------------------------
 struct Wg3Args {
     TSrc src[3];
@@ -214,7 +251,8 @@ struct Wg3Args {
     int H, W, tiles_x, tiles_y, batch;
     int act_kind;
     const float* slope;
-    float* part;
+    float* part;        // &table[0][column of this layer's weight]
+    long row_stride;    // floats between the rows of the table
 };
 
 template <int CO>
@@ -224,71 +262,91 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
     __shared__ __attribute__((aligned(16))) float s_g[TH * TW * CO];
     const int tid = threadIdx.x;
     const int CI = a.src[0].nch + a.src[1].nch + a.src[2].nch;
-    const int P = CI * 9 + 1, S = 256 / P;
+    const int P = CI * 3 + 1, S = 256 / P;
     const int pair = tid % P, split = tid / P;
     const bool active = split < S, isb = pair == P - 1;
-    const int ci = pair / 9, k = pair - ci * 9, ky = k / 3, kx = k - ky * 3;
+    const int ci = pair / 3, ky = pair - ci * 3;
     const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
-    float acc[CO];
+    float acc[3][CO];
 #pragma unroll
-    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[k][c] = 0.f;
     const int ntiles = a.tiles_x * a.tiles_y * a.batch;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, b = r0 / a.tiles_y;
         const int x0 = tx * TW, y0 = ty * TH;
         __syncthreads();
-        for (int e = tid; e < CI * IR * IC; e += 256) {
-            const int c = e / (IR * IC), r = e - c * (IR * IC), ir = r / IC, ic = r - ir * IC;
-            const int y = y0 - 1 + ir, x = x0 - 1 + ic;
-            float v = 0.f;
-            if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-                int cs = c, si = 0;
-                if (cs >= a.src[0].nch) { cs -= a.src[0].nch; si = 1; if (cs >= a.src[1].nch) { cs -= a.src[1].nch; si = 2; } }
-                const TSrc& sr = a.src[si];
-                v = sr.p[(long)b * sr.sb + (long)cs * sr.sc + (long)y * a.W + x];
-                if (sr.act) v = act_fwd(v, a.act_kind, slope);
-                v *= sr.scale;
-            }
-            s_x[(c * IR + ir) * PI + ic] = v;
+        {
+            WindowStager<IR, IC, 256> st;
+            st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
+            st.stage(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);
         }
-        for (int e = tid; e < TH * TW * CO; e += 256) {
-            const int c = e / (TH * TW), r = e - c * (TH * TW), iy = r / TW, ix = r - iy * TW;   // consecutive threads: consecutive x
-            const int y = y0 + iy, x = x0 + ix;
-            float v = 0.f;
-            if (y < a.H && x < a.W) v = a.g[(long)b * a.g_sb + (long)c * a.g_sc + (long)y * a.W + x];
-            s_g[(iy * TW + ix) * CO + c] = v;
+        {   // gradient tile, channel-interleaved: s_g[(y * TW + x) * CO + c]
+            constexpr int NG = TH * TW / 256;
+            float gv[CO][NG];
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+#pragma unroll
+                for (int i = 0; i < NG; ++i) {
+                    const int r = tid + i * 256, iy = r / TW, ix = r - iy * TW;
+                    const int y = y0 + iy, x = x0 + ix;
+                    const bool ok = y < a.H && x < a.W;
+                    gv[c][i] = a.g[(long)b * a.g_sb + (long)c * a.g_sc + (ok ? (long)y * a.W + x : 0)];
+                    if (!ok) gv[c][i] = 0.f;
+                }
+#pragma unroll
+            for (int c = 0; c < CO; ++c)
+#pragma unroll
+                for (int i = 0; i < NG; ++i) s_g[(tid + i * 256) * CO + c] = gv[c][i];
         }
         __syncthreads();
         if (active) {
             for (int r = split; r < TH; r += S) {
-                const float* xr = &s_x[(ci * IR + r + ky) * PI + kx];
+                const float* xr = &s_x[(ci * IR + r + ky) * PI];
                 const float* gr = &s_g[r * TW * CO];
+                float xa = isb ? 1.f : xr[0], xb = isb ? 0.f : xr[1];
 #pragma unroll 4
                 for (int c = 0; c < TW; ++c) {
-                    const float xv = isb ? 1.f : xr[c];
+                    const float xc = isb ? 0.f : xr[c + 2];
 #pragma unroll
-                    for (int o = 0; o < CO; ++o) acc[o] = fmaf(gr[c * CO + o], xv, acc[o]);
+                    for (int o = 0; o < CO; ++o) {
+                        const float gv = gr[c * CO + o];
+                        acc[0][o] = fmaf(gv, xa, acc[0][o]);
+                        acc[1][o] = fmaf(gv, xb, acc[1][o]);
+                        acc[2][o] = fmaf(gv, xc, acc[2][o]);
+                    }
+                    xa = isb ? 1.f : xb;
+                    xb = xc;
                 }
             }
         }
     }
-    // reduce over the row subsets (fixed order), then one thread per pair writes the block's row of the table
+    // reduce over the row subsets (fixed order), then one thread per tap row adds the block's sums to its row of the table
     __syncthreads();
-    float* s_red = s_g;   // S * P * CO <= 256 * CO floats <= TH * TW * CO
+    float* s_red = s_x;   // S * P * 3 * CO <= 256 * 24 floats
     if (active) {
 #pragma unroll
-        for (int o = 0; o < CO; ++o) s_red[(split * P + pair) * CO + o] = acc[o];
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) s_red[((split * P + pair) * 3 + k) * CO + o] = acc[k][o];
     }
     __syncthreads();
     if (tid < P) {
-        float* row = a.part + (size_t)blockIdx.x * (CO * CI * 9 + CO);
+        float* row = a.part + (size_t)blockIdx.x * a.row_stride;
+        const int pc = tid / 3, pky = tid - pc * 3;
 #pragma unroll
-        for (int o = 0; o < CO; ++o) {
-            float s = 0.f;
-            for (int q = 0; q < S; ++q) s += s_red[(q * P + tid) * CO + o];
-            const int pc = tid / 9, pk = tid - pc * 9;
-            row[tid == P - 1 ? CO * CI * 9 + o : (o * CI + pc) * 9 + pk] = s;
-        }
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int o = 0; o < CO; ++o) {
+                float sum = 0.f;
+                for (int q = 0; q < S; ++q) sum += s_red[((q * P + tid) * 3 + k) * CO + o];
+                if (tid == P - 1) {
+                    if (k == 0) row[CO * CI * 9 + o] += sum;
+                } else {
+                    row[(o * CI + pc) * 9 + pky * 3 + k] += sum;
+                }
+            }
     }
 }
 
@@ -297,13 +355,14 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
 //     dW[a][b][ky][kx] = sum_{n,Y,X} sm[a](Y, X) * bg[b](2Y + ky - 3, 2X + kx - 3)
 //   down  (Conv2d, weight [out, in, 8, 8]):           sm = grad of the output (a = out), bg = input (b = in)
 //   up    (ConvTranspose2d, weight [in, out, 8, 8]):  sm = input (a = in),               bg = grad of the output (b = out)
-// Thread = (b, ky, kx) x 8 values of a; block walks a run of 8 x 16 tiles of the small tensor; partials [gridDim.x][4096].
+// Thread = (b, ky, kx) x 8 values of a; block walks a run of 8 x 16 tiles of the small tensor and adds to its row of the table.
 // ------------------------------------------------------------------------------------------------------------------
 struct Wg8Args {
     const float* sm; long sm_sb, sm_sc; int hs, ws;
     const float* bg; long bg_sb, bg_sc;
     int tiles_x, tiles_y, batch;
     float* part;
+    long row_stride;
 };
 
 __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
@@ -321,19 +380,27 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
         const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, n = r0 / a.tiles_y;
         const int X0 = tx * TX, Y0 = ty * TY;
         __syncthreads();
-        for (int e = tid; e < kFeat * BR * BC; e += 512) {
-            const int c = e / (BR * BC), r = e - c * (BR * BC), ir = r / BC, ic = r - ir * BC;
-            const int y = 2 * Y0 - 3 + ir, x = 2 * X0 - 3 + ic;
-            float v = 0.f;
-            if (y >= 0 && y < hb && x >= 0 && x < wb) v = a.bg[(long)n * a.bg_sb + (long)c * a.bg_sc + (long)y * wb + x];
-            s_b[(c * BR + ir) * PB + ic] = v;
+        {
+            const TSrc big[3] = {TSrc{a.bg, a.bg_sb, a.bg_sc, kFeat, 1.f, 0}, TSrc{nullptr, 0, 0, 0, 1.f, 0}, TSrc{nullptr, 0, 0, 0, 1.f, 0}};
+            WindowStager<BR, BC, 512> st;
+            st.setup(tid, 2 * Y0 - 3, 2 * X0 - 3, hb, wb, PB);
+            st.stage(big, kFeat, n, s_b, BR * PB, 0, 0.f);
         }
-        for (int e = tid; e < TY * TX * kFeat; e += 512) {
-            const int c = e / (TY * TX), r = e - c * (TY * TX), iy = r / TX, ix = r - iy * TX;
-            const int y = Y0 + iy, x = X0 + ix;
-            float v = 0.f;
-            if (y < a.hs && x < a.ws) v = a.sm[(long)n * a.sm_sb + (long)c * a.sm_sc + (long)y * a.ws + x];
-            s_s[(iy * TX + ix) * kFeat + c] = v;
+        {   // small tensor tile, channel-interleaved: s_s[(Y * TX + X) * 8 + c]; 128 positions x 8 channels = 2 per thread
+            float sv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * 512, c = e >> 7, r = e & 127, iy = r / TX, ix = r - iy * TX;
+                const int y = Y0 + iy, x = X0 + ix;
+                const bool ok = y < a.hs && x < a.ws;
+                sv[i] = a.sm[(long)n * a.sm_sb + (long)c * a.sm_sc + (ok ? (long)y * a.ws + x : 0)];
+                if (!ok) sv[i] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int e = tid + i * 512;
+                s_s[(e & 127) * kFeat + (e >> 7)] = sv[i];
+            }
         }
         __syncthreads();
         const float* bp = &s_b[(bch * BR + ky) * PB + kx];
@@ -347,13 +414,13 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
                 for (int c = 0; c < kFeat; ++c) acc[c] = fmaf(sp[c], xv, acc[c]);
             }
     }
-    float* row = a.part + (size_t)blockIdx.x * (kFeat * kFeat * 64);
+    float* row = a.part + (size_t)blockIdx.x * a.row_stride;
 #pragma unroll
-    for (int c = 0; c < kFeat; ++c) row[(c * kFeat + bch) * 64 + k] = acc[c];
+    for (int c = 0; c < kFeat; ++c) row[(c * kFeat + bch) * 64 + k] += acc[c];
 }
 
-// per-channel sums of a [B, C, plane] tensor (bias gradients of the 8x8 convolutions): partials [gridDim.x][C]
-__global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x, long sb, long sc, long plane, int batch, float* __restrict__ part, int C) {
+// per-channel sums of a [B, C, plane] tensor (bias gradients of the 8x8 convolutions), added to rows [0, gridDim.x) of the table
+__global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x, long sb, long sc, long plane, int batch, float* __restrict__ part, long row_stride) {
     __shared__ float s_red[4];
     const int c = blockIdx.y;
     float s = 0.f;
@@ -366,11 +433,10 @@ __global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) part[(size_t)blockIdx.x * C + c] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * row_stride + c] += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
 }
 
-// out[j] += sum over rows of part[row][j], in a fixed order.  Wide tables: one thread per column; narrow ones (bias, slope,
-// the 1x1 layer): one block per column, threads strided over the rows.
+// grad[j] = sum over the rows of the table, in a fixed order (every weight-gradient kernel of the call has added to its row)
 __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int rows, int count, float* __restrict__ out) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= count) return;
@@ -383,18 +449,20 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
         s3 += part[(size_t)(r + 3) * count + j];
     }
     for (; r < rows; ++r) s0 += part[(size_t)r * count + j];
-    out[j] += (s0 + s1) + (s2 + s3);
+    out[j] = (s0 + s1) + (s2 + s3);
 }
-__global__ __launch_bounds__(256) void k_reduce_col(const float* __restrict__ part, int rows, int count, float* __restrict__ out) {
-    __shared__ float s_red[4];
+// PReLU slope gradients: block j sums the rows[j] per-block partial sums of DoubleConv j (fixed order) into grad[off[j]]
+struct SlopeJobs { int rows[3 * kMaxDepth + 2]; int off[3 * kMaxDepth + 2]; };
+__global__ __launch_bounds__(256) void k_reduce_slopes(const double* __restrict__ part, int stride, SlopeJobs jobs, float* __restrict__ grad) {
+    __shared__ double s_red[4];
     const int j = blockIdx.x;
-    float s = 0.f;
-    for (int r = threadIdx.x; r < rows; r += 256) s += part[(size_t)r * count + j];
+    double s = 0.0;
+    for (int r = threadIdx.x; r < jobs.rows[j]; r += 256) s += part[(size_t)j * stride + r];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[j] += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (threadIdx.x == 0) grad[jobs.off[j]] = (float)((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
 }
 
 // ---- output layer: d = Conv1x1(8 -> 2)(y0); wf_next = wf + d / 1e3   (architectures.py:57-60, hybridnet.py:570) ----------
@@ -415,9 +483,9 @@ __global__ __launch_bounds__(256) void k_outc_fwd(const float* __restrict__ y0, 
     wf_next[o] = d0 / 1e3f + wf[o];
     wf_next[o + plane] = d1 / 1e3f + wf[o + plane];
 }
-// backward: gd = g_wfnext / 1e3;  g_y0[c] = sum_o w[o][c] gd[o];  partials of dW[o][c] = sum gd[o] y0[c], db[o] = sum gd[o]  ([gridDim.x][18])
+// backward: gd = g_wfnext / 1e3;  g_y0[c] = sum_o w[o][c] gd[o];  sums of dW[o][c] = sum gd[o] y0[c], db[o] = sum gd[o] added to the block's row of the table
 __global__ __launch_bounds__(256) void k_outc_bwd(const float* __restrict__ g_wfn, const float* __restrict__ y0, const float* __restrict__ w,
-                                                  float* __restrict__ g_y0, float* __restrict__ part, long plane, long total) {
+                                                  float* __restrict__ g_y0, float* __restrict__ part, long row_stride, long plane, long total) {
     __shared__ float s_red[4][18];
     float acc[18];
 #pragma unroll
@@ -445,7 +513,7 @@ __global__ __launch_bounds__(256) void k_outc_bwd(const float* __restrict__ g_wf
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][q] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 18) part[(size_t)blockIdx.x * 18 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+    if (threadIdx.x < 18) part[(size_t)blockIdx.x * row_stride + threadIdx.x] += (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
 }
 
 // g = [g_in +] c * res   (the loss term of one unrolled iteration: d/d res of scale * mean(res^2))
@@ -465,12 +533,35 @@ __global__ void k_loss_finalize(const float* __restrict__ sumsq, int n, float sc
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if (threadIdx.x == 0) loss[0] = s * scale_over_count;
 }
-// 8x8 weights -> [in][kh*kw][out] for the direct kernels of hn_unet.hip.  mode 0: raw is [out][in][64]; mode 1: raw is [in][out][64]
-__global__ __launch_bounds__(256) void k_repack8(const float* __restrict__ raw, float* __restrict__ dst, int mode) {
-    const int e = blockIdx.x * 256 + threadIdx.x;   // index into dst: (i * 64 + t) * 8 + o
+// A-operand fragments of the fp32 matrix-core 8x8 kernels (hn_mfma.hip: pack_frag_down / pack_frag_up), built on the device.
+//   up == 0: raw is [out][in][8][8] -> [in][kx][64 lanes]:      lane -> (co = (l & 15) >> 1, h = l & 1, k = l >> 4): raw[co][ci][4h + k][kx]
+//   up == 1: raw is [in][out][8][8] -> [in][px][bb][64 lanes]:  lane -> (co, py = l & 1, a = l >> 4): raw[ci][co][6 + py - 2a][7 - px - 2bb]
+__global__ __launch_bounds__(256) void k_pack_frag8(const float* __restrict__ raw, float* __restrict__ dst, int up) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= kFeat * kFeat * 64) return;
-    const int o = e & 7, t = (e >> 3) & 63, i = e >> 9;
-    dst[e] = mode == 0 ? raw[(o * kFeat + i) * 64 + t] : raw[(i * kFeat + o) * 64 + t];
+    const int l = e & 63, blk = (e >> 6) & 7, ci = e >> 9;
+    const int co = (l & 15) >> 1, j = l & 1, q = l >> 4;
+    if (!up) dst[e] = raw[((co * kFeat + ci) * 8 + 4 * j + q) * 8 + blk];
+    else {
+        const int px = blk >> 2, bb = blk & 3;
+        dst[e] = raw[((ci * kFeat + co) * 8 + (6 + j - 2 * q)) * 8 + (7 - px - 2 * bb)];
+    }
+}
+// 3x3 weights raw [O][I][3][3] -> both arrangements k_conv3 reads: forward [I][9][O] at dst + off, backward-data [O][9][I]
+// (taps flipped) at dst + total + off.  One launch packs every 3x3 convolution of the network (blockIdx.y = job).
+struct Pack3Jobs { int n; int off[32]; short o[32], i[32]; };
+__global__ __launch_bounds__(256) void k_pack3(const float* __restrict__ raw, float* __restrict__ dst, long total, Pack3Jobs jobs) {
+    const int j = blockIdx.y, O = jobs.o[j], I = jobs.i[j], off = jobs.off[j];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= O * I * 9) return;
+    {   // forward: index (ci * 9 + k) * O + co
+        const int co = e % O, r = e / O, k = r % 9, ci = r / 9;
+        dst[off + e] = raw[off + (co * I + ci) * 9 + k];
+    }
+    {   // backward-data: input channel = forward output o, output channel = forward input i: index (o * 9 + k) * I + i
+        const int i = e % I, r = e / I, k = r % 9, o = r / 9;
+        dst[total + off + e] = raw[off + (o * I + i) * 9 + (8 - k)];
+    }
 }
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                                               const unsigned char* __restrict__ trainable, size_t n, float step_size, float inv_sqrt_bc2, float b1,
@@ -491,30 +582,31 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 
 // ---- host-side drivers -------------------------------------------------------------------------------------------------
 template <int CO>
-void launch_conv3_co(const Conv3Args& a, bool epi, dim3 grid, hipStream_t s) {
-    if (epi) hipLaunchKernelGGL((k_conv3<CO, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((k_conv3<CO, false>), grid, dim3(256), 0, s, a);
+void launch_conv3_co(const Conv3Args& a, bool epi, dim3 grid, size_t lds, hipStream_t s) {
+    if (epi) hipLaunchKernelGGL((k_conv3<CO, true>), grid, dim3(128), lds, s, a);
+    else hipLaunchKernelGGL((k_conv3<CO, false>), grid, dim3(128), lds, s, a);
 }
 int launch_conv3(hn_ctx* ctx, int co, bool epi, const Conv3Args& a, int batch, hipStream_t s) {
-    const dim3 grid(cdiv(a.W, 32), cdiv(a.H, 32), batch);
+    const dim3 grid(cdiv(a.W, kC3TW), cdiv(a.H, kC3TH), batch);
+    const int ci = a.src[0].nch + a.src[1].nch + a.src[2].nch;
+    const size_t lds = sizeof(float) * ((size_t)ci * (kC3TH + 2) * kC3PI + 8);
     switch (co) {
-        case 2: launch_conv3_co<2>(a, epi, grid, s); break;
-        case 6: launch_conv3_co<6>(a, epi, grid, s); break;
-        case 8: launch_conv3_co<8>(a, epi, grid, s); break;
-        case 10: launch_conv3_co<10>(a, epi, grid, s); break;
-        case 16: launch_conv3_co<16>(a, epi, grid, s); break;
+        case 2: launch_conv3_co<2>(a, epi, grid, lds, s); break;
+        case 6: launch_conv3_co<6>(a, epi, grid, lds, s); break;
+        case 8: launch_conv3_co<8>(a, epi, grid, lds, s); break;
+        case 10: launch_conv3_co<10>(a, epi, grid, lds, s); break;
+        case 16: launch_conv3_co<16>(a, epi, grid, lds, s); break;
         default: return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no 3x3 kernel for %d output channels", co);
     }
     return HN_OK;
 }
 
-constexpr int kPartBlocks = 256;   // rows of the partials table a weight-gradient launch may write
+constexpr int kPartRows = 256;   // rows of the partials table = the most blocks a weight-gradient launch uses
 
 struct Trainer {
     hn_ctx* ctx;
     hipStream_t s;
     const float* w;      // device blob (raw layouts)
-    float* grad;
     RawLayout L;
     int B, n, depth, act;
     long Lst;            // flat state length per channel
@@ -529,96 +621,92 @@ struct Trainer {
     static TDst nodst() { return TDst{nullptr, 0, 0, 0, 1.f, 0}; }
     TSrc state_src(const float* flat, int d) const { return TSrc{flat + ctx->state_off[d], 2 * Lst, Lst, kState, 1.f, 0}; }
     TDst state_dst(float* flat, int d, int accum = 0) const { return TDst{flat + ctx->state_off[d], 2 * Lst, Lst, kState, 1.f, accum}; }
+    Src msrc(const float* p, int d) const { return Src{p, kFeat * plane(d), plane(d), 1.f}; }
+    Dst mdst(float* p, int d) const { return Dst{p, kFeat * plane(d), plane(d)}; }
+    const float* wfwd(size_t off) const { return T().w3 + off; }                // k_pack3: forward arrangement at the raw offset
+    const float* wbwd(size_t off) const { return T().w3 + L.total + off; }      // backward-data arrangement behind it
+    float* table(size_t col) const { return T().part + col; }                   // &table[0][col]; rows are L.total floats apart
+    const float* frag8(int d, int which) const { return T().k8 + ((size_t)d * 4 + which) * 4096; }   // 0 down fwd, 1 down bwd-data, 2 up fwd, 3 up bwd-data
 
-    // forward convolution of a DoubleConv half: out = conv(w_off) (srcs) + bias
-    int conv_fwd(const TSrc (&src)[3], size_t w_off, size_t b_off, int w_o, int w_i, size_t slope_off, TDst dst, int d) {
+    int conv_fwd(const TSrc (&src)[3], size_t w_off, size_t b_off, int w_o, size_t slope_off, TDst dst, int d) {
         Conv3Args a{};
         for (int i = 0; i < 3; ++i) a.src[i] = src[i];
         a.dst[0] = dst; a.dst[1] = nodst(); a.dst[2] = nodst();
-        a.w = w + w_off; a.bias = w + b_off; a.w_o = w_o; a.w_i = w_i; a.wmode = 0;
+        a.wpk = wfwd(w_off); a.bias = w + b_off;
         a.H = a.W = side(d);
         a.act_kind = act; a.slope = w + slope_off;
         return launch_conv3(ctx, w_o, false, a, B, s);
     }
     // DoubleConv forward with tape: z = conv1(in) (stored), out = conv2(act(z))
     int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d) {
-        int rc = conv_fwd(in, dc.w1, dc.b1, dc.cm, dc.cin, dc.slope, featdst(z, d, dc.cm), d);
+        int rc = conv_fwd(in, dc.w1, dc.b1, dc.cm, dc.slope, featdst(z, d, dc.cm), d);
         if (rc != HN_OK) return rc;
         const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
-        return conv_fwd(mid, dc.w2, dc.b2, dc.co, dc.cm, dc.slope, out, d);
+        return conv_fwd(mid, dc.w2, dc.b2, dc.co, dc.slope, out, d);
     }
-    int reduce(int rows, int count, size_t grad_off) {
-        if (count >= 64) hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv(count, 256)), dim3(256), 0, s, T().part, rows, count, grad + grad_off);
-        else hipLaunchKernelGGL(k_reduce_col, dim3(count), dim3(256), 0, s, T().part, rows, count, grad + grad_off);
-        return HN_OK;
-    }
-    int wgrad3(const TSrc (&in)[3], TSrc g, int co, int cin, size_t grad_off, int d, size_t slope_off) {
+    int wgrad3(const TSrc (&in)[3], TSrc g, int co, size_t grad_off, int d, size_t slope_off) {
         Wg3Args a{};
         for (int i = 0; i < 3; ++i) a.src[i] = in[i];
         a.g = g.p; a.g_sb = g.sb; a.g_sc = g.sc;
         a.H = a.W = side(d);
         a.tiles_x = cdiv(a.W, 32); a.tiles_y = cdiv(a.H, 16); a.batch = B;
-        a.act_kind = act; a.slope = w + slope_off; a.part = T().part;
+        a.act_kind = act; a.slope = w + slope_off;
+        a.part = table(grad_off); a.row_stride = (long)L.total;
         const int ntiles = a.tiles_x * a.tiles_y * B;
-        const int blocks = ntiles < kPartBlocks ? ntiles : kPartBlocks;
+        const int blocks = ntiles < kPartRows ? ntiles : kPartRows;
         if (co == 8) hipLaunchKernelGGL(k_conv3_wgrad<8>, dim3(blocks), dim3(256), 0, s, a);
         else if (co == 2) hipLaunchKernelGGL(k_conv3_wgrad<2>, dim3(blocks), dim3(256), 0, s, a);
         else return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no weight-gradient kernel for %d output channels", co);
-        return reduce(blocks, co * cin * 9 + co, grad_off);
+        return HN_OK;
     }
     // DoubleConv backward: g_out (co channels) -> weight gradients, gradients of the inputs into `gin` (channel groups of the concatenation)
-    int dc_bwd(const RawDc& dc, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
+    int dc_bwd(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
         int rc;
-        // conv2: dW2, db2 from (act(z), g_out)
-        {
+        {   // conv2: dW2, db2 from (act(z), g_out)
             const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
-            if ((rc = wgrad3(mid, g_out, dc.co, dc.cm, dc.w2, d, dc.slope)) != HN_OK) return rc;
+            if ((rc = wgrad3(mid, g_out, dc.co, dc.w2, d, dc.slope)) != HN_OK) return rc;
         }
-        // g_z = conv2^T(g_out) * act'(z);  d slope
-        {
+        {   // g_z = conv2^T(g_out) * act'(z);  d slope
             Conv3Args a{};
             a.src[0] = g_out; a.src[1] = nosrc(); a.src[2] = nosrc();
             a.dst[0] = featdst(T().gz, d, dc.cm); a.dst[1] = nodst(); a.dst[2] = nodst();
-            a.w = w + dc.w2; a.bias = nullptr; a.w_o = dc.co; a.w_i = dc.cm; a.wmode = 1;
+            a.wpk = wbwd(dc.w2); a.bias = nullptr;
             a.H = a.W = side(d);
             a.act_kind = act; a.slope = w + dc.slope;
             a.z = z; a.z_sb = dc.cm * plane(d); a.z_sc = plane(d);
-            a.slope_part = act == HN_ACT_PRELU ? T().part : nullptr;
+            a.slope_part = act == HN_ACT_PRELU ? T().slope_part + (size_t)slot * T().slope_stride : nullptr;
             if ((rc = launch_conv3(ctx, dc.cm, true, a, B, s)) != HN_OK) return rc;
-            if (act == HN_ACT_PRELU) reduce(cdiv(side(d), 32) * cdiv(side(d), 32) * B, 1, dc.slope);
         }
         // conv1: dW1, db1 from (in, g_z)
-        if ((rc = wgrad3(in, feat(T().gz, d, dc.cm), dc.cm, dc.cin, dc.w1, d, dc.slope)) != HN_OK) return rc;
-        // g_in = conv1^T(g_z)
-        {
+        if ((rc = wgrad3(in, feat(T().gz, d, dc.cm), dc.cm, dc.w1, d, dc.slope)) != HN_OK) return rc;
+        {   // g_in = conv1^T(g_z)
             Conv3Args a{};
             a.src[0] = feat(T().gz, d, dc.cm); a.src[1] = nosrc(); a.src[2] = nosrc();
             for (int i = 0; i < 3; ++i) a.dst[i] = gin[i];
-            a.w = w + dc.w1; a.bias = nullptr; a.w_o = dc.cm; a.w_i = dc.cin; a.wmode = 1;
+            a.wpk = wbwd(dc.w1); a.bias = nullptr;
             a.H = a.W = side(d);
             a.act_kind = act; a.slope = nullptr;
             if ((rc = launch_conv3(ctx, dc.cin, false, a, B, s)) != HN_OK) return rc;
         }
         return HN_OK;
     }
-    K8W k8(int d, int which, size_t bias_off, bool with_bias) const {   // which: 0 down fwd, 1 down bwd-data, 2 up fwd, 3 up bwd-data
-        return K8W{T().k8 + ((size_t)d * 4 + which) * 4096, with_bias ? w + bias_off : T().zero8};
-    }
-    int wgrad8(const float* sm, int d_small, const float* bg, size_t grad_off) {
+    int slot_inc() const { return 0; }
+    int slot_sig(int d) const { return 1 + d; }
+    int slot_st(int d) const { return 1 + depth + d; }
+    int slot_dec(int d) const { return 1 + 2 * depth + d; }
+    int slope_rows(int d) const { return cdiv(side(d), kC3TW) * cdiv(side(d), kC3TH) * B; }
+
+    void wgrad8(const float* sm, int d_small, const float* bg, size_t grad_off) {
         Wg8Args a{};
         a.sm = sm; a.sm_sb = kFeat * plane(d_small); a.sm_sc = plane(d_small); a.hs = a.ws = side(d_small);
         a.bg = bg; a.bg_sb = kFeat * plane(d_small - 1); a.bg_sc = plane(d_small - 1);
         a.tiles_x = cdiv(a.ws, 16); a.tiles_y = cdiv(a.hs, 8); a.batch = B;
-        a.part = T().part;
+        a.part = table(grad_off); a.row_stride = (long)L.total;
         const int ntiles = a.tiles_x * a.tiles_y * B;
-        const int blocks = ntiles < kPartBlocks ? ntiles : kPartBlocks;
-        hipLaunchKernelGGL(k_conv8_wgrad, dim3(blocks), dim3(512), 0, s, a);
-        return reduce(blocks, kFeat * kFeat * 64, grad_off);
+        hipLaunchKernelGGL(k_conv8_wgrad, dim3(ntiles < kPartRows ? ntiles : kPartRows), dim3(512), 0, s, a);
     }
-    int bias8(const float* g, int d, size_t grad_off) {
-        const int blocks = 32;
-        hipLaunchKernelGGL(k_channel_sum, dim3(blocks, kFeat), dim3(256), 0, s, g, (long)kFeat * plane(d), plane(d), plane(d), B, T().part, kFeat);
-        return reduce(blocks, kFeat, grad_off);
+    void bias8(const float* g, int d, size_t grad_off) {
+        hipLaunchKernelGGL(k_channel_sum, dim3(32, kFeat), dim3(256), 0, s, g, (long)kFeat * plane(d), plane(d), plane(d), B, table(grad_off), (long)L.total);
     }
 
     // one unrolled iteration, forward (hybridnet.py:558-584), filling step t of the tape
@@ -636,19 +724,19 @@ struct Trainer {
             if ((rc = dc_fwd(L.sig[d], in_sig, tape(t, W.o_zsig[d]), featdst(tape(t, W.o_out[d]), d), d)) != HN_OK) return rc;
             const TSrc in_st[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
             if ((rc = dc_fwd(L.st[d], in_st, tape(t, W.o_zst[d]), state_dst(st_next, d), d)) != HN_OK) return rc;
-            if ((rc = module_conv8x8(ctx, tape(t, W.o_out[d]), k8(d, 0, L.down[d].b, true), false, tape(t, W.o_x[d + 1]), B, side(d), side(d), s)) != HN_OK) return rc;
+            launch_down(ctx, msrc(tape(t, W.o_out[d]), d), mdst(tape(t, W.o_x[d + 1]), d + 1), frag8(d, 0), w + L.down[d].b, side(d), side(d), B, s);
         }
         {
             const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
             if ((rc = dc_fwd(L.dec[depth], in, tape(t, W.o_zdec[depth]), featdst(tape(t, W.o_y[depth]), depth), depth)) != HN_OK) return rc;
         }
         for (int d = depth - 1; d >= 0; --d) {
-            if ((rc = module_conv8x8(ctx, tape(t, W.o_y[d + 1]), k8(d, 2, L.up[d].b, true), true, tape(t, W.o_u[d]), B, side(d + 1), side(d + 1), s)) != HN_OK) return rc;
+            launch_up(ctx, msrc(tape(t, W.o_y[d + 1]), d + 1), mdst(tape(t, W.o_u[d]), d), frag8(d, 2), w + L.up[d].b, side(d + 1), side(d + 1), B, s);
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
             if ((rc = dc_fwd(L.dec[d], in, tape(t, W.o_zdec[d]), featdst(tape(t, W.o_y[d]), d), d)) != HN_OK) return rc;
         }
         const long total = (long)B * p0;
-        hipLaunchKernelGGL(k_outc_fwd, dim3((unsigned)cdiv((int)total, 256)), dim3(256), 0, s, tape(t, W.o_y[0]), w + L.outc_w, w + L.outc_b, wf, wf_next, p0, total);
+        hipLaunchKernelGGL(k_outc_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tape(t, W.o_y[0]), w + L.outc_w, w + L.outc_b, wf, wf_next, p0, total);
         return spec_apply(ctx, wf_next, res_next, ksq, src, src_batch, B, W.sumsq + (size_t)t * B, s);
     }
 
@@ -667,27 +755,27 @@ struct Trainer {
         float* G = W.g_wf[cur_wf];   // d loss / d wf_next; wf_next = wf + d / 1e3, so it is also the direct part of d loss / d wf
         {
             const long total = (long)B * p0;
-            const int blocks = (int)((total + 255) / 256) < kPartBlocks ? (int)((total + 255) / 256) : kPartBlocks;
-            hipLaunchKernelGGL(k_outc_bwd, dim3(blocks), dim3(256), 0, s, G, tape(t, W.o_y[0]), w + L.outc_w, W.g_y[0], W.part, p0, total);
-            reduce(blocks, 18, L.outc_w);
+            const int blocks = (int)((total + 255) / 256) < kPartRows ? (int)((total + 255) / 256) : kPartRows;
+            hipLaunchKernelGGL(k_outc_bwd, dim3(blocks), dim3(256), 0, s, G, tape(t, W.o_y[0]), w + L.outc_w, W.g_y[0], table(L.outc_w), (long)L.total, p0, total);
         }
         for (int d = 0; d < depth; ++d) {   // decoder, top down
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
             const TDst gin[3] = {featdst(W.g_u[d], d), featdst(W.g_out[d], d), nodst()};
-            if ((rc = dc_bwd(L.dec[d], in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d)) != HN_OK) return rc;
-            // up[d]: backward-data = the stride-2 convolution kernel on the transposed-convolution weights
-            if ((rc = module_conv8x8(ctx, W.g_u[d], k8(d, 3, 0, false), false, W.g_y[d + 1], B, side(d), side(d), s)) != HN_OK) return rc;
+            if ((rc = dc_bwd(L.dec[d], slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d)) != HN_OK) return rc;
+            // up[d]: backward-data = the stride-2 convolution kernel on the transposed-convolution weights read as [out, in, kh, kw]
+            launch_down(ctx, msrc(W.g_u[d], d), mdst(W.g_y[d + 1], d + 1), frag8(d, 3), W.zero8, side(d), side(d), B, s);
             wgrad8(tape(t, W.o_y[d + 1]), d + 1, W.g_u[d], L.up[d].w);
             bias8(W.g_u[d], d, L.up[d].b);
         }
         {
             const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
             const TDst gin[3] = {featdst(W.g_x[depth], depth), nodst(), nodst()};
-            if ((rc = dc_bwd(L.dec[depth], in, tape(t, W.o_zdec[depth]), feat(W.g_y[depth], depth), gin, depth)) != HN_OK) return rc;
+            if ((rc = dc_bwd(L.dec[depth], slot_dec(depth), in, tape(t, W.o_zdec[depth]), feat(W.g_y[depth], depth), gin, depth)) != HN_OK) return rc;
         }
         for (int d = depth - 1; d >= 0; --d) {   // encoder, bottom up
-            // down[d]: backward-data = the transposed-convolution kernel on the convolution weights; added to the skip gradient
-            if ((rc = module_conv8x8(ctx, W.g_x[d + 1], k8(d, 1, 0, false), true, W.tmp8, B, side(d + 1), side(d + 1), s)) != HN_OK) return rc;
+            // down[d]: backward-data = the transposed-convolution kernel on the convolution weights read as [in, out, kh, kw];
+            // added to the skip gradient
+            launch_up(ctx, msrc(W.g_x[d + 1], d + 1), mdst(W.tmp8, d), frag8(d, 1), W.zero8, side(d + 1), side(d + 1), B, s);
             const long tot8 = (long)B * kFeat * plane(d);
             hipLaunchKernelGGL(k_add, dim3((unsigned)((tot8 + 255) / 256)), dim3(256), 0, s, W.g_out[d], W.tmp8, tot8);
             wgrad8(W.g_x[d + 1], d + 1, tape(t, W.o_out[d]), L.down[d].w);
@@ -695,18 +783,18 @@ struct Trainer {
             {   // conv_state: new_state = DC(cat[out, state])
                 const TSrc in[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
                 const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 1), state_dst(W.g_st[cur_st ^ 1], d, 0), nodst()};
-                if ((rc = dc_bwd(L.st[d], in, tape(t, W.o_zst[d]), state_src(W.g_st[cur_st], d), gin, d)) != HN_OK) return rc;
+                if ((rc = dc_bwd(L.st[d], slot_st(d), in, tape(t, W.o_zst[d]), state_src(W.g_st[cur_st], d), gin, d)) != HN_OK) return rc;
             }
             {   // conv_signal: out = DC(cat[x, state])
                 const TSrc in[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
                 const TDst gin[3] = {featdst(W.g_x[d], d), state_dst(W.g_st[cur_st ^ 1], d, 1), nodst()};
-                if ((rc = dc_bwd(L.sig[d], in, tape(t, W.o_zsig[d]), feat(W.g_out[d], d), gin, d)) != HN_OK) return rc;
+                if ((rc = dc_bwd(L.sig[d], slot_sig(d), in, tape(t, W.o_zsig[d]), feat(W.g_out[d], d), gin, d)) != HN_OK) return rc;
             }
         }
         {   // inc: DC(cat[wf, 1e3 * res, sigmas]); the sigma channels need no gradient
             const TSrc in[3] = {TSrc{wf_in, 2 * p0, p0, 2, 1.f, 0}, TSrc{res_in, 2 * p0, p0, 2, 1e3f, 0}, TSrc{ctx->tab.sigmas, 0, p0, 2, 1.f, 0}};
             const TDst gin[3] = {TDst{G, 2 * p0, p0, 2, 1.f, 1}, TDst{W.g_res, 2 * p0, p0, 2, 1e3f, 0}, nodst()};
-            if ((rc = dc_bwd(L.inc, in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0)) != HN_OK) return rc;
+            if ((rc = dc_bwd(L.inc, slot_inc(), in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0)) != HN_OK) return rc;
         }
         cur_st ^= 1;
         HN_HIP(ctx, hipGetLastError());
@@ -759,10 +847,12 @@ int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
     W.gz = W.gbuf + o_gz; W.tmp8 = W.gbuf + o_tmp;
     W.g_wf[0] = W.gbuf + o_wf0; W.g_wf[1] = W.gbuf + o_wf1; W.g_res = W.gbuf + o_res;
     W.g_st[0] = W.gbuf + o_st0; W.g_st[1] = W.gbuf + o_st1;
-    W.part_floats = (size_t)kPartBlocks * kFeat * kFeat * 64;
-    const size_t slope_rows = (size_t)nb * cdiv(n, 32) * cdiv(n, 32);
-    if (slope_rows > W.part_floats) W.part_floats = slope_rows;
+    const size_t total = raw_layout(depth).total;
+    W.part_floats = (size_t)kPartRows * total;
     HN_HIP(ctx, hipMalloc((void**)&W.part, sizeof(float) * W.part_floats));
+    W.slope_stride = (size_t)nb * cdiv(n, kC3TW) * cdiv(n, kC3TH);
+    HN_HIP(ctx, hipMalloc((void**)&W.slope_part, sizeof(double) * W.slope_stride * (3 * depth + 2)));
+    HN_HIP(ctx, hipMalloc((void**)&W.w3, sizeof(float) * 2 * total));
     HN_HIP(ctx, hipMalloc((void**)&W.k8, sizeof(float) * (size_t)depth * 4 * 4096));
     HN_HIP(ctx, hipMalloc((void**)&W.zero8, sizeof(float) * 8));
     HN_HIP(ctx, hipMemset(W.zero8, 0, sizeof(float) * 8));
@@ -785,7 +875,7 @@ int train_ready(hn_ctx* ctx, int batch, int n_unroll) {
 
 void train_free(hn_ctx* ctx) {
     auto& W = ctx->tr;
-    for (float* p : {W.tape, W.gbuf, W.part, W.k8, W.zero8, W.sumsq}) (void)hipFree(p);
+    for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.zero8, (void*)W.sumsq}) (void)hipFree(p);
     W = hn_ctx::TrainWs{};
 }
 
@@ -815,20 +905,34 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     hipStream_t s = (hipStream_t)stream;
     auto& W = ctx->tr;
     const int n = ctx->tab.n, depth = ctx->depth;
-    Trainer tr{ctx, s, weights, grad, raw_layout(depth), batch, n, depth, ctx->act_kind, (long)ctx->state_len};
+    Trainer tr{ctx, s, weights, raw_layout(depth), batch, n, depth, ctx->act_kind, (long)ctx->state_len};
     const size_t fwf = (size_t)batch * 2 * n * n, fst = (size_t)batch * kState * ctx->state_len;
-    // 8x8 weights in the layout of the direct kernels: forward and backward-data of every down / up convolution
-    for (int d = 0; d < depth; ++d) {
-        const float* wd = weights + tr.L.down[d].w;
-        const float* wu = weights + tr.L.up[d].w;
-        float* k = W.k8 + (size_t)d * 4 * 4096;
-        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wd, k, 0);
-        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wd, k + 4096, 1);
-        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wu, k + 2 * 4096, 1);
-        hipLaunchKernelGGL(k_repack8, dim3(16), dim3(256), 0, s, wu, k + 3 * 4096, 0);
+    // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
+    struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};
+    ctx->precision = HN_PREC_FP32;
+    {   // weights in the layouts the kernels read: 3x3 both arrangements (one launch), 8x8 matrix-core fragments
+        Pack3Jobs jobs{};
+        auto add = [&](const RawDc& dc) {
+            jobs.off[jobs.n] = (int)dc.w1; jobs.o[jobs.n] = (short)dc.cm; jobs.i[jobs.n] = (short)dc.cin; ++jobs.n;
+            jobs.off[jobs.n] = (int)dc.w2; jobs.o[jobs.n] = (short)dc.co; jobs.i[jobs.n] = (short)dc.cm; ++jobs.n;
+        };
+        add(tr.L.inc);
+        for (int d = 0; d < depth; ++d) { add(tr.L.sig[d]); add(tr.L.st[d]); }
+        for (int d = 0; d <= depth; ++d) add(tr.L.dec[d]);
+        hipLaunchKernelGGL(k_pack3, dim3(cdiv(16 * 9 * 8, 256), jobs.n), dim3(256), 0, s, weights, W.w3, (long)tr.L.total, jobs);
+        for (int d = 0; d < depth; ++d) {
+            const float* wd = weights + tr.L.down[d].w;
+            const float* wu = weights + tr.L.up[d].w;
+            float* k = W.k8 + (size_t)d * 4 * 4096;
+            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wd, k, 0);             // down, forward
+            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wd, k + 4096, 1);      // down, backward-data: [out, in] read as [in, out] by the transposed kernel
+            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wu, k + 2 * 4096, 1);  // up, forward
+            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wu, k + 3 * 4096, 0);  // up, backward-data: [in, out] read as [out, in] by the convolution kernel
+        }
     }
     HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));
-    HN_HIP(ctx, hipMemsetAsync(grad, 0, sizeof(float) * tr.L.total, s));
+    HN_HIP(ctx, hipMemsetAsync(W.part, 0, sizeof(float) * W.part_floats, s));
+    HN_HIP(ctx, hipMemsetAsync(W.slope_part, 0, sizeof(double) * W.slope_stride * (3 * depth + 2), s));
     for (int t = 0; t < n_unroll; ++t) {
         const float* wf_in = t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf;
         const float* res_in = t == 0 ? res : res_hist + (size_t)(t - 1) * fwf;
@@ -848,6 +952,16 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         const float* res_in = t == 0 ? res : res_hist + (size_t)(t - 1) * fwf;
         const float* st_in = t == 0 ? states : st_hist + (size_t)(t - 1) * fst;
         if ((rc = tr.backward_step(t, wf_in, res_in, st_in, res_hist + (size_t)t * fwf, k_sq, loss_c, cur_wf, cur_st)) != HN_OK) return rc;
+    }
+    // the table's rows -> the gradient blob, then the slope entries from their own per-block sums
+    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv((int)tr.L.total, 256)), dim3(256), 0, s, W.part, kPartRows, (int)tr.L.total, grad);
+    if (ctx->act_kind == HN_ACT_PRELU) {
+        SlopeJobs sj{};
+        auto put = [&](int slot, const RawDc& dc, int d) { sj.rows[slot] = tr.slope_rows(d); sj.off[slot] = (int)dc.slope; };
+        put(tr.slot_inc(), tr.L.inc, 0);
+        for (int d = 0; d < depth; ++d) { put(tr.slot_sig(d), tr.L.sig[d], d); put(tr.slot_st(d), tr.L.st[d], d); }
+        for (int d = 0; d <= depth; ++d) put(tr.slot_dec(d), tr.L.dec[d], d);
+        hipLaunchKernelGGL(k_reduce_slopes, dim3(3 * depth + 2), dim3(256), 0, s, W.slope_part, (int)W.slope_stride, sj, grad);
     }
     if (grad_wf0) HN_HIP(ctx, hipMemcpyAsync(grad_wf0, W.g_wf[cur_wf], sizeof(float) * fwf, hipMemcpyDeviceToDevice, s));
     if (grad_res0) HN_HIP(ctx, hipMemcpyAsync(grad_res0, W.g_res, sizeof(float) * fwf, hipMemcpyDeviceToDevice, s));
