@@ -182,6 +182,9 @@ def secondary(solver, dev, n, B, precision, steps, warmup):
             "residual_rmse_max": float(rmse[steps - 1].max().item())}
 
 
+STEP_COMPULSORY_BYTES_256 = 3751936.0   # read 4[(2+2+1) N^2 + 2 sum N_d^2] + write 4[(2+2) N^2 + 2 sum N_d^2] at N = 256
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,6 +200,9 @@ def main():
                          "every kernel, which measures ~4 %% faster (tools/graph_ab.py)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning knob for A/B runs (hn_set_option): deep=0, side_stream=0, ...")
+    ap.add_argument("--settle", type=float, default=None, metavar="SECONDS",
+                    help="keep the loop running untimed for this long right before the timed region (clock settling; default 0.3 s "
+                         "when --steps < 200, else 0); the iterations it adds are reported as warmup_extra / effective_warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short 512^2 / bf16x3 side measurements")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel time table (stderr)")
@@ -267,7 +273,8 @@ def main():
     # ends in a host read-back) are enough for the clocks to drop, and the first ~10 ms afterwards then run ~9 % slow --
     # invisible at --steps 300, a tenth of a --steps 20 measurement
     extra, t_w = 0, time.perf_counter()
-    while time.perf_counter() - t_w < 0.3:
+    settle_s = args.settle if args.settle is not None else (0.3 if K < 200 else 0.0)
+    while time.perf_counter() - t_w < settle_s:
         eng.step(wf, res, st, k_sq, src, 32, rmse_hist=rmse[:min(32, rmse.shape[0])] if rmse.shape[0] >= 32 else None)
         torch.cuda.synchronize()
         extra += 32
@@ -335,7 +342,7 @@ def main():
             "metric": f"solver iterations/sec (whole node), {n}^2 domain batch={B}",
             "value": round(world * K / dt, 2),
             "unit": "iterations/s",
-            "n_gpus": world, "steps": K, "warmup": W, "warmup_extra": W1 + 8 + extra - W,
+            "n_gpus": world, "steps": K, "warmup": W, "warmup_extra": W1 + 8 + extra - W, "effective_warmup": W1 + 8 + extra,
             "ms_per_step": round(dt / K * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": DTYPE[prec], "data": "synthetic",
@@ -346,10 +353,21 @@ def main():
                        "parallelism": f"dp{world} (batch shards, no data-path collective)"},
             "sample_iterations_per_s": round(world * B * K / dt, 1),
             "unet_tflops": round(total_flops * K / dt / 1e12, 2),
-            "residual_rmse_after_timed_steps": {"median": float(np.median(final_rmse)), "max": float(worst.max().item())},
+            "residual_rmse_after_timed_steps": {"median": float(np.median(final_rmse)), "max": float(worst.max().item()),
+                                                "iterations_from_zero_wavefield": W1 + 8 + extra + K},
             "roofline": roof,
             "cpu_baseline": cpu,
         }
+        # whole-step HBM view: compulsory bytes of one fused sample-iteration x batch x iterations/s against the HBM peak.
+        # The step is compute-bound (fused arithmetic intensity 281 FLOP/B): at the fp32 peak the figure could reach ~7 %.
+        step_bytes = STEP_COMPULSORY_BYTES_256 * (n / 256.0) ** 2 * B
+        step_gbs = step_bytes * world * K / dt / 1e9
+        line["step_hbm"] = {"compulsory_bytes_per_step": step_bytes, "achieved": round(step_gbs / world, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(step_gbs / world / HBM_PEAK_GBS, 4),
+                            "note": "per GPU; whole iteration fused would move 3,751,936 B per sample at 256^2 (SURVEY 8d); compute-limited ceiling ~0.07"}
+        if roof is not None and roof.get("kernel") == "decode0" and prec == "fp32":
+            roof["flops_note"] = ("credited FLOPs are the reference layers' (conv 16->8, conv 8->8, 1x1 8->2: 228.6 MFLOP per sample at 256^2); the kernel "
+                                  "executes ~0.85 of them (final 3x3 + 1x1 composed into one 2-channel 3x3, plus mid-tensor halo recompute)")
         # secondary line for the HBM-bound part of the path (north_star: "achieved HBM GB/s for the FFT path"):
         # compulsory bytes of get_residual (5 planes per sample) over the shortest bracketed launches of the two
         # spectral kernels in the fully bracketed warm-up pass

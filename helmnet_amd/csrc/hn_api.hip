@@ -171,15 +171,29 @@ int hn_create(hn_ctx** out, int device_id) {
     hn_ctx* c = new (std::nothrow) hn_ctx();
     if (!c) return fail(nullptr, HN_ERR_NOMEM, "out of host memory");
     c->device = device_id;
-    // environment variables are defaults only, read here and nowhere else
+    // environment variables are defaults only, read here and nowhere else; they go through the validators of
+    // hn_set_unet_precision / hn_set_option, and a value those would reject fails the creation instead of being clamped
+    *out = c;
+    auto bad_env = [&](const char* name, const char* v) {
+        const std::string why = c->err;
+        hn_destroy(c);
+        *out = nullptr;
+        return fail(nullptr, HN_ERR_ARG, "hn_create: environment variable %s=%s rejected (%s)", name, v, why.c_str());
+    };
     if (const char* v = getenv("HN_UNET_IMPL")) {
-        c->precision = std::strcmp(v, "bf16x3") == 0 ? HN_PREC_BF16X3 : std::strcmp(v, "fp16") == 0 ? HN_PREC_FP16
-                     : std::strcmp(v, "bf16x2") == 0 ? HN_PREC_BF16X2 : std::strcmp(v, "valu") == 0 ? HN_PREC_FP32_VALU : HN_PREC_FP32;
+        const int mode = std::strcmp(v, "fp32") == 0 ? HN_PREC_FP32 : std::strcmp(v, "bf16x3") == 0 ? HN_PREC_BF16X3 : std::strcmp(v, "fp16") == 0 ? HN_PREC_FP16
+                       : std::strcmp(v, "bf16x2") == 0 ? HN_PREC_BF16X2 : std::strcmp(v, "valu") == 0 ? HN_PREC_FP32_VALU : -1;
+        if (hn_set_unet_precision(c, mode) != HN_OK) return bad_env("HN_UNET_IMPL", v);
     }
-    if (const char* v = getenv("HN_STREAMS")) { const int n = atoi(v); c->opt_lanes = n < 1 ? 1 : n > 8 ? 8 : n; }
-    if (const char* v = getenv("HN_SIDE_STREAM")) { const int n = atoi(v); c->opt_side_stream = n < 0 ? 0 : n > 3 ? 3 : n; }
-    if (const char* v = getenv("HN_GRAPH")) { const int n = atoi(v); c->opt_graph = n < 0 ? 0 : n > 64 ? 64 : n; }
-    if (const char* v = getenv("HN_DEEP")) c->opt_deep = atoi(v) != 0;
+    const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
+                                                            {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP}};
+    for (const auto& k : knobs)
+        if (const char* v = getenv(k.env)) {
+            char* end = nullptr;
+            const long n = std::strtol(v, &end, 10);
+            if (end == v || *end != '\0') { c->err = "not an integer"; return bad_env(k.env, v); }
+            if (hn_set_option(c, k.opt, (int)n) != HN_OK) return bad_env(k.env, v);
+        }
     *out = c;
     return HN_OK;
 }
@@ -211,10 +225,26 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
                 return fail(ctx, HN_ERR_ARG, "HN_OPT_GRAPH must be 0, 1 or an even number of iterations per graph <= 64 (got %d)", value);
             ctx->opt_graph = value;
             break;
-        case HN_OPT_DEEP: ctx->opt_deep = value != 0; break;
-        case HN_OPT_SPECTRAL_PFA: ctx->opt_pfa = value != 0; break;
-        case HN_OPT_DC_VALU: ctx->opt_dc_valu = value < 0 ? 0 : value > 2 ? 2 : value; break;
-        case HN_OPT_SPECTRAL_RADIX16: ctx->opt_radix16 = value < 0 ? 0 : value > 2 ? 2 : value; break;
+        case HN_OPT_DEEP:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_DEEP must be 0 or 1 (got %d)", value);
+            ctx->opt_deep = value;
+            break;
+        case HN_OPT_SPECTRAL_PFA:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_SPECTRAL_PFA must be 0 or 1 (got %d)", value);
+            ctx->opt_pfa = value;
+            break;
+        case HN_OPT_DC_VALU:
+            if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0, 1 or 2 (got %d)", value);
+            ctx->opt_dc_valu = value;
+            break;
+        case HN_OPT_SPECTRAL_RADIX16:
+            if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_SPECTRAL_RADIX16 must be 0, 1 or 2 (got %d)", value);
+            ctx->opt_radix16 = value;
+            break;
+        case HN_OPT_SPECTRAL_COLS:
+            if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_SPECTRAL_COLS must be 0, 1 or 2 (got %d)", value);
+            ctx->opt_cols_t = value;
+            break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }
     clear_step_graphs(ctx);
@@ -709,9 +739,10 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     const size_t fb_all = sizeof(float) * (size_t)batch * 2 * plane, sb_all = sizeof(float) * (size_t)batch * kState * L;
     if (ns == 1) {
         // One lane: an iteration is a fixed kernel sequence over fixed buffers (the hidden states ping-pong between the
-        // caller's buffer and the library's), so it is captured once per direction and replayed -- one host call per
-        // iteration instead of ~25 launches and 4 event operations.  Iterations in which hn_profile_* brackets a kernel,
-        // and everything when capture is unavailable, are launched kernel by kernel; the two forms are interchangeable
+        // caller's buffer and the library's).  By default (HN_OPT_GRAPH 0) every kernel is launched on the caller's stream:
+        // the host stays ahead of the GPU and in-order launches measured 4 % faster than graph replay.  With HN_OPT_GRAPH the
+        // iteration is captured once per direction and replayed; iterations in which hn_profile_* brackets a kernel, and
+        // everything when capture is unavailable, are still launched kernel by kernel -- the two forms are interchangeable
         // iteration by iteration (same kernels, same arguments, same order).
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         const bool caller_capturing = s != nullptr && hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;

@@ -404,6 +404,34 @@ __device__ __forceinline__ void bfly4(v2& x0, v2& x1, v2& x2, v2& x3) {
     x3 = a1 - r3;
 }
 
+// The 1-D tables of a 256-point axis (twiddles, k, -k^2, PML a and b: 8 KB) copied into LDS at kernel start, together with the
+// first data loads: the kernels then take their multipliers from LDS instead of paying an L2 round trip at each of the three
+// points of the line's critical path where a table is first needed.
+struct LdsTabs {
+    const float2* tw;
+    const float* k1;
+    const float* k2;
+    const float2* a;
+    const float2* b;
+};
+constexpr int kLdsTabFloats = 256 * 2 + 256 + 256 + 256 * 2 + 256 * 2;   // 2048 floats
+template <int NT>
+__device__ __forceinline__ LdsTabs stage_tables_256(float* dst, const SpecPtrs& t, int tid) {
+    float2* tw = reinterpret_cast<float2*>(dst);
+    float* k1 = dst + 512;
+    float* k2 = dst + 768;
+    float2* a = reinterpret_cast<float2*>(dst + 1024);
+    float2* b = reinterpret_cast<float2*>(dst + 1536);
+    for (int i = tid; i < 256; i += NT) {
+        tw[i] = t.tw[i];
+        k1[i] = t.k1[i];
+        k2[i] = t.k2[i];
+        a[i] = t.a[i];
+        b[i] = t.b[i];
+    }
+    return LdsTabs{tw, k1, k2, a, b};
+}
+
 // in-register 16-point DFT, X[k] = sum_n x[n] W16^(+-n k): 4 + 4 radix-4 butterflies around the W16^(m q) twiddles
 template <bool INV>
 __device__ __forceinline__ void dft16(v2 (&x)[16]) {
@@ -451,7 +479,8 @@ __device__ __forceinline__ void xchg16(v2 (&v)[NB][16], v2* reg, int nbs, int t)
 
 // Forward transform of one line of 256 and the two derivative spectra: in u[k] = x[t + 16 k]; out d[0] = i k U, d[1] = -k^2 U
 // after the first inverse radix-16 pass and its twiddles, i.e. ready for the inverse exchange.
-__device__ __forceinline__ void axis_forward16(const v2 (&u)[16], v2 (&d)[2][16], v2* reg, int nbs, int t, const SpecPtrs& tab) {
+template <typename Tab>
+__device__ __forceinline__ void axis_forward16(const v2 (&u)[16], v2 (&d)[2][16], v2* reg, int nbs, int t, const Tab& tab) {
     v2 w[16];   // W_256^(t q)
 #pragma unroll
     for (int q = 1; q < 16; ++q) { const float2 f = tab.tw[t * q]; w[q] = (v2){f.x, f.y}; }
@@ -479,7 +508,8 @@ __device__ __forceinline__ void axis_forward16(const v2 (&u)[16], v2 (&d)[2][16]
     }
 }
 // ... and the rest: inverse exchange, second inverse pass, PML coefficients: acc[k] = (a du + b ddu)[t + 16 k]
-__device__ __forceinline__ void axis_finish16(v2 (&d)[2][16], v2 (&acc)[16], int t, const SpecPtrs& tab) {
+template <typename Tab>
+__device__ __forceinline__ void axis_finish16(v2 (&d)[2][16], v2 (&acc)[16], int t, const Tab& tab) {
     dft16<true>(d[0]);
     dft16<true>(d[1]);
     constexpr float inv_n = 1.0f / 256.0f;
@@ -675,6 +705,71 @@ __global__ __launch_bounds__(256) void k_spec16_cols(const float* __restrict__ w
         const long o = (long)(t + 16 * k) * N;
         po[o] = acc[k].x;
         po[o + plane] = acc[k].y;
+    }
+}
+
+// column pass at N = 256, coalesced through an LDS transpose (r3).  k_spec16_cols above addresses global memory as 16 rows x 16
+// bytes per wave instruction.  Here a block owns COLS columns x all 256 rows of one sample: it loads row segments of COLS * 4
+// bytes as float4 (a wave instruction covers 64 / (COLS / 4) rows x COLS * 4 contiguous bytes), writes them TRANSPOSED into LDS
+// (column c at buf + c * P, (re, im) interleaved), runs the two radix-16 passes per column out of LDS with the 16 threads of a
+// transform on consecutive lanes (lane = 16 c' + t: the exchange pattern of the row kernel, whose conflicts are 1.6 cycles per
+// LDS instruction against 24 for lane = 4 t + c), writes the result back into the column's region and stores it the way it
+// was loaded.  P = 545 float2: a column region holds the 2 x 272 float2 of the lock-step inverse exchange, and 8 P = 8 (mod 64)
+// dwords puts the COLS / 4 float4 segments of a row on disjoint banks for the transposed writes and reads.
+constexpr int kColsP = 545;
+
+template <int COLS>
+__global__ __launch_bounds__(COLS * 16) void k_spec16_cols_t(const float* __restrict__ wf, float* __restrict__ out, SpecPtrs tab,
+                                                           int* __restrict__ it_counter) {
+    constexpr int N = 256, NT = COLS * 16, P = kColsP, SEG = COLS / 4, RPP = NT / SEG, NP = N / RPP;
+    extern __shared__ v2 cbuf[];   // [COLS][P], then the tables
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (it_counter != nullptr && (blockIdx.x | blockIdx.y | tid) == 0) atomicAdd(it_counter, 1);
+    const TileId tl = xcd_tile();
+    const long plane = (long)N * N;
+    const int seg = tid % SEG, rr = tid / SEG;
+    const LdsTabs ltab = stage_tables_256<NT>(reinterpret_cast<float*>(cbuf + COLS * P), tab, tid);
+    const float* pre = wf + (long)tl.y * 2 * plane + tl.x * COLS + 4 * seg;
+    {
+        float4 re[NP], im[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const long o = (long)(rr + RPP * i) * N;
+            re[i] = *reinterpret_cast<const float4*>(pre + o);
+            im[i] = *reinterpret_cast<const float4*>(pre + o + plane);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            v2* q = cbuf + (4 * seg) * P + rr + RPP * i;
+            q[0] = (v2){re[i].x, im[i].x};
+            q[P] = (v2){re[i].y, im[i].y};
+            q[2 * P] = (v2){re[i].z, im[i].z};
+            q[3 * P] = (v2){re[i].w, im[i].w};
+        }
+    }
+    __syncthreads();
+    {
+        const int t = lane & 15, cl = wave * 4 + (lane >> 4);
+        v2* reg = cbuf + cl * P;
+        v2 u[16], d[2][16], acc[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) u[k] = reg[t + 16 * k];
+        axis_forward16(u, d, reg, kReg16Rows, t, ltab);   // the first exchange overwrites the column's region: every lane of the wave has read its inputs
+        xchg16<2>(d, reg, kReg16Rows, t);
+        axis_finish16(d, acc, t, ltab);
+        exchange_sync<true>();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) reg[t + 16 * k] = acc[k];
+    }
+    __syncthreads();
+    float* po = out + (long)tl.y * 2 * plane + tl.x * COLS + 4 * seg;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const v2* q = cbuf + (4 * seg) * P + rr + RPP * i;
+        const v2 a = q[0], b = q[P], c = q[2 * P], d4 = q[3 * P];
+        const long o = (long)(rr + RPP * i) * N;
+        *reinterpret_cast<float4*>(po + o) = make_float4(a.x, b.x, c.x, d4.x);
+        *reinterpret_cast<float4*>(po + o + plane) = make_float4(a.y, b.y, c.y, d4.y);
     }
 }
 
@@ -1168,7 +1263,16 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
                 if (ctx->opt_radix16) {
                     {
                         ProfScope ps(ctx, KID_SPEC_COLS, s);
-                        hipLaunchKernelGGL(k_spec16_cols, dim3(16, batch), dim3(256), 0, s, wf, out, p, it_counter);
+                        if (ctx->opt_cols_t == 0) hipLaunchKernelGGL(k_spec16_cols, dim3(16, batch), dim3(256), 0, s, wf, out, p, it_counter);
+                        else {
+                            if (!ctx->cols_t_attr_set) {
+                                HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec16_cols_t<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * kColsP * 8 + kLdsTabFloats * 4));
+                                HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec16_cols_t<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 32 * kColsP * 8 + kLdsTabFloats * 4));
+                                ctx->cols_t_attr_set = true;
+                            }
+                            if (ctx->opt_cols_t == 1) hipLaunchKernelGGL(k_spec16_cols_t<16>, dim3(16, batch), dim3(256), 16 * kColsP * 8 + kLdsTabFloats * 4, s, wf, out, p, it_counter);
+                            else hipLaunchKernelGGL(k_spec16_cols_t<32>, dim3(8, batch), dim3(512), 32 * kColsP * 8 + kLdsTabFloats * 4, s, wf, out, p, it_counter);
+                        }
                     }
                     ProfScope ps(ctx, KID_SPEC_ROWS, s);
                     if (ctx->opt_radix16 == 2)

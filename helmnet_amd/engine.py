@@ -117,6 +117,13 @@ def module_engine(device) -> "Engine":
     return _MODULE_ENGINES[dev]
 
 
+def release_module_engines():
+    """Destroy the shared per-device contexts of the standalone sub-module forwards (they otherwise live until interpreter exit)."""
+    for eng in _MODULE_ENGINES.values():
+        eng.close()
+    _MODULE_ENGINES.clear()
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
@@ -179,11 +186,20 @@ class Engine:
     @property
     def unet_precision(self) -> str:
         code = self.lib.hn_get_unet_precision(self.ctx)
-        return {v: k for k, v in _lib.HN_PRECISION.items()}[code]
+        names = {v: k for k, v in _lib.HN_PRECISION.items()}
+        if code not in names:
+            raise _lib.HelmnetHipError(f"hn_get_unet_precision returned {code} (context closed?)")
+        return names[code]
 
     def set_option(self, name: str, value: int):
-        """hn_step tuning knobs: 'lanes' (1..8), 'side_stream' (0/1), 'graph' (0/1), 'deep' (0/1)."""
+        """Library tuning knobs (enum hn_option of include/helmnet_hip.h): 'lanes' 1..8, 'side_stream' 0..3, 'graph' 0, 1 or an even
+        number <= 64 of iterations per graph, 'deep' 0/1, 'spectral_pfa' 0/1, 'spectral_radix16' 0..2, 'dc_valu' 0..2,
+        'spectral_cols' 0..2.  'spectral_pfa' is read when the spectral tables are built: changing it re-builds them."""
+        if name not in _lib.HN_OPTION:
+            raise ValueError(f"unknown option {name!r} (choose from {sorted(_lib.HN_OPTION)})")
         _lib.check(self.lib.hn_set_option(self.ctx, _lib.HN_OPTION[name], int(value)), self.ctx, "hn_set_option")
+        if name == "spectral_pfa" and self.domain_key is not None:
+            self.set_domain(*self.domain_key)
 
     def counter(self, name: str) -> int:
         return int(self.lib.hn_get_counter(self.ctx, _lib.HN_COUNTER[name]))

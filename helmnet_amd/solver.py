@@ -265,7 +265,9 @@ class IterativeSolver(nn.Module):
         wf = wavefield.detach().float().clone().contiguous()
         res = residual.detach().float().clone().contiguous()
         st = self.f.get_states(flatten=True).float().contiguous().clone()
+        keep = self.f.to_engine_states(st)
         eng.step(wf, res, st, k_sq.float().contiguous(), self._src(), 1)
+        self.f.from_engine_states(keep, st)
         self.f.adopt_states(st)
         return (wf, res) if get_residual else wf
 
@@ -289,7 +291,9 @@ class IterativeSolver(nn.Module):
         st_hist = hist((K, b, 2, eng.state_len), "every hidden state") if return_states and K > 0 else None
         rmse = torch.empty((K, b), device=dev, dtype=torch.float32) if K > 0 else None
         if K > 0:
+            keep = self.f.to_engine_states(st)      # levels without state: zeros in, the caller's values back out
             eng.step(wf, res, st, k_sq, self._src(), K, res_hist, wf_hist, st_hist, rmse)
+            self.f.from_engine_states(keep, st, st_hist)
         self.f.adopt_states(st)
         out = {
             "wavefields": list(wf_hist.unbind(0)) if wf_hist is not None else [wf],

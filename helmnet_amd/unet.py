@@ -173,6 +173,27 @@ class HybridNet(nn.Module):
             if enc.use_state:
                 enc.set_state(h[d])
 
+    def to_engine_states(self, flat):
+        """Levels without state (d >= state_depth) run in the kernels as zero-weight stateful levels (engine.pack_weights): their
+        slot is multiplied by 0 and rewritten with 0.  Hand the library zeros there (0 * NaN from a diverged earlier run would
+        otherwise reach conv_signal) and remember what the slot held; ``from_engine_states`` puts it back, so the slot reads as
+        the reference leaves it: untouched (architectures.py:250-251).  ``flat`` is modified in place; returns the kept slices."""
+        keep = {}
+        for d, (a, b) in enumerate(self.state_boundaries):
+            if d >= self.state_depth:
+                keep[(a, b)] = flat[:, :, a:b].clone()
+                flat[:, :, a:b] = 0
+        return keep
+
+    @staticmethod
+    def from_engine_states(keep, *tensors):
+        """Restore the stateless slots in flat state tensors [..., B, 2, L] (the state itself, a history of states)."""
+        for t in tensors:
+            if t is None:
+                continue
+            for (a, b), v in keep.items():
+                t[..., a:b] = v
+
     def flatten_state(self, h_list):
         return torch.cat([x.reshape(x.shape[0], x.shape[1], -1) for x in h_list], 2)
 
@@ -223,6 +244,8 @@ class HybridNet(nn.Module):
             raise ValueError("You must set or clear the state before using this module")
         eng = self._get_engine(x.device)
         flat = self.get_states(flatten=True).contiguous()
+        keep = self.to_engine_states(flat)
         d, new_flat = eng.unet(x.contiguous(), flat)
+        self.from_engine_states(keep, new_flat)
         self.adopt_states(new_flat)
         return d

@@ -61,8 +61,10 @@ enum hn_act { HN_ACT_PRELU = 0, HN_ACT_RELU = 1, HN_ACT_LEAKYRELU = 2, HN_ACT_CE
  *   HN_PREC_FP32_VALU  fp32 on the vector ALU (direct convolution; A/B reference for the matrix-core kernels) */
 enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_PREC_BF16X2 = 3, HN_PREC_FP32_VALU = 4 };
 
-/* Tuning knobs of hn_step (hn_set_option); none changes a result bit except HN_OPT_DC_VALU (same fp32 FMA arithmetic,
- * another summation order: results agree to rounding, like two fp32 implementations of the reference do). */
+/* Tuning knobs (hn_set_option).  Bit-exact ones -- the same kernels and summation order, only launched differently: LANES,
+ * SIDE_STREAM, GRAPH, SPECTRAL_COLS (same butterflies, other memory access).  The others select a different kernel for the same
+ * fp32 arithmetic and agree to fp32 rounding, like two fp32 implementations of the reference do: DEEP (other summation order,
+ * 2e-6 * max), SPECTRAL_PFA (FFT instead of the dense operator), SPECTRAL_RADIX16 (other butterfly order), DC_VALU. */
 enum hn_option {
     HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
     HN_OPT_SIDE_STREAM = 1,  /* conv_state kernels: 0 in line; on a library side stream released 1 after the last `down`,
@@ -70,12 +72,14 @@ enum hn_option {
     HN_OPT_GRAPH = 2,        /* 0: launch every kernel (default; measured faster); 1: replay one captured iteration per HIP graph
                               * launch; even n <= 64: n iterations per graph                                          */
     HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
-    HN_OPT_SPECTRAL_RADIX16 = 5, /* 0/1: 256-point lines as two register-resident radix-16 passes (default 1; 0: radix-4 kernels) */
+    HN_OPT_SPECTRAL_PFA = 4, /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k instead of the dense n x n operator (default 1;
+                              * read by the next hn_set_domain)                                                     */
+    HN_OPT_SPECTRAL_RADIX16 = 5, /* 256-point lines: 0 the radix-4 kernels, 1 radix-16 columns + 8x4x8 rows (default), 2 radix-16 rows too */
     HN_OPT_DC_VALU = 6,      /* fp32 DoubleConvs of the largest level (W >= 256) on the packed vector FMA (every FMA useful, same peak as the
                               * fp32 MFMA, whose 3x3 packing fills 75 % of its slots): 0 none (matrix core), 1 inc and the decoder
                               * (default; conv_signal stays on the matrix core: the vector kernels lower the sustained clock), 2 all three */
-    HN_OPT_SPECTRAL_PFA = 4  /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k instead of the dense n x n operator (default 1;
-                              * read by the next hn_set_domain)                                                     */
+    HN_OPT_SPECTRAL_COLS = 7 /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
+                              * segments transposed through LDS, 16 / 32 columns per workgroup                      */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };

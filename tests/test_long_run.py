@@ -168,3 +168,35 @@ def test_config5_fp16_unet_arc_source_convergence_to_tolerance(g_long):
     e32 = np.abs(wa[:, :, ::st, ::st] - gold).max() / scale
     e16 = np.abs(wb[:, :, ::st, ::st] - gold).max() / scale
     assert e32 <= 1e-3 and e16 <= 5e-3, (e32, e16, n_it)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rank", [0, 7])
+def test_config3_random_sos_shards_of_the_8_way_run(weights, rank):
+    """BASELINE configs[2] (SURVEY 8d cfg 3): 256 smooth random maps, `1 + U(0,1)` box-blurred (seed 1), sharded 8 ways -- the
+    slices ranks 0 and 7 of the 8-GPU run would take (shard_bounds(256, r, 8): 32 maps each), on one GPU.
+      * 40 iterations of the first 4 maps of the shard against the CPU oracle (L_inf(wavefield) <= 1e-4, RMSE trace 2 %);
+      * the full 1000 iterations at B = 32 through the size-independent properties: everything finite, the residual converges
+        to the floor the trained network reaches on in-distribution maps, and sample i of the shard equals sample i solved in
+        a batch of 4 bit for bit (samples never interact, so the sharded run IS the unsharded one)."""
+    from helmnet_amd.distributed import shard_bounds
+    from helmnet_amd.phantoms import smooth_random_sos
+    lo, hi = shard_bounds(256, rank, 8)
+    assert (lo, hi) == (32 * rank, 32 * rank + 32)
+    sos = torch.from_numpy(smooth_random_sos(256, 256, seed=1)[lo:hi])
+    assert sos.shape == (32, 1, 256, 256) and float(sos.min()) >= 1.0 and float(sos.max()) <= 2.0
+    s = _solver()
+    s.set_domain_size(256, source_location=[30, 128])
+    out = s.forward(sos[:4].to(DEV), num_iterations=40, residuals="norms")
+    want = O.solve(sos[:4], weights, O.point_source_map(256, [30, 128], 10.0), O.SpectralTables(256, 8, 2, 1.0), 40)
+    assert (out["wavefields"][0].cpu() - want["wavefield"]).abs().max() <= 1e-4
+    trace = torch.stack(want["trace"]).numpy()
+    assert np.abs(out["residual_norms"].cpu().numpy() / trace - 1).max() <= 2e-2
+    full = s.forward(sos.to(DEV), num_iterations=1000, residuals="norms")
+    wf = full["wavefields"][0]
+    rm = full["residual_norms"].cpu().numpy()
+    assert torch.isfinite(wf).all() and np.isfinite(rm).all()
+    assert rm[-1].max() <= 2e-4 and rm[-1].max() <= 0.05 * rm[0].max(), (rm[0].max(), rm[-1].max())
+    part = s.forward(sos[8:12].to(DEV), num_iterations=1000, residuals="norms")
+    assert torch.equal(part["wavefields"][0], wf[8:12])
+    assert torch.equal(part["residual_norms"], full["residual_norms"][:, 8:12])

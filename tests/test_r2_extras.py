@@ -177,6 +177,17 @@ def test_gpu_state_depth_below_depth_vs_reference_fixture(g_sd):
         assert np.abs(got_s - want_s).max() <= 1e-5 * np.abs(want_s).max()
     a = _sd_bounds()[2][0]
     assert np.array_equal(got_s[:, :, a:], g_sd["st0"][:, :, a:])
+    # a stateless slot holding NaN / Inf (e.g. left by a diverged run) is never read by the reference; here it must neither
+    # reach the output (0 * NaN) nor be overwritten
+    st = torch.from_numpy(g_sd["st0"]).clone()
+    st[:, :, a:] = float("nan")
+    st[0, 0, a + 5] = float("inf")
+    net.set_states(st.to(DEV), flatten=True)
+    d = net(torch.from_numpy(g_sd["x1"]).to(DEV)).cpu().numpy()
+    assert np.abs(d - g_sd["d1"]).max() <= 1e-5 * np.abs(g_sd["d1"]).max()
+    after = net.get_states(flatten=True).cpu()
+    assert torch.isnan(after[:, :, a:]).sum() == st[:, :, a:].numel() - 1 and torch.isinf(after[0, 0, a + 5])
+    assert np.abs(after[:, :, :a].numpy() - g_sd["s1"][:, :, :a]).max() <= 1e-5 * np.abs(g_sd["s1"]).max()
 
 
 @pytest.mark.gpu
