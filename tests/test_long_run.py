@@ -172,31 +172,57 @@ def test_config5_fp16_unet_arc_source_convergence_to_tolerance(g_long):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("rank", [0, 7])
-def test_config3_random_sos_shards_of_the_8_way_run(weights, rank):
-    """BASELINE configs[2] (SURVEY 8d cfg 3): 256 smooth random maps, `1 + U(0,1)` box-blurred (seed 1), sharded 8 ways -- the
-    slices ranks 0 and 7 of the 8-GPU run would take (shard_bounds(256, r, 8): 32 maps each), on one GPU.
-      * 40 iterations of the first 4 maps of the shard against the CPU oracle (L_inf(wavefield) <= 1e-4, RMSE trace 2 %);
-      * the full 1000 iterations at B = 32 through the size-independent properties: everything finite, the residual converges
-        to the floor the trained network reaches on in-distribution maps, and sample i of the shard equals sample i solved in
-        a batch of 4 bit for bit (samples never interact, so the sharded run IS the unsharded one)."""
-    from helmnet_amd.distributed import shard_bounds
-    from helmnet_amd.phantoms import smooth_random_sos
+def test_config3_shards_of_the_8_way_run(weights, rank):
+    """BASELINE configs[2]: a batch of 256 random sound-speed maps sharded 8 ways -- on one GPU, the slices ranks 0 and 7 of the
+    8-GPU run take (``shard_bounds(256, r, 8)``: 32 maps each; the maps are what ``bench.py --gpus 8`` gives rank r: random ring
+    phantoms of the training distribution, dataloaders.py:115-156, seed r).
+      * 40 iterations of the first 4 maps of the shard against the CPU oracle (L_inf(wavefield) <= 1e-4 * max|wf|, RMSE trace 2 %);
+      * the full 1000 iterations at B = 32 through the size-independent properties: everything finite, the residual converged
+        to the trained network's floor, and sample i of the shard equals sample i solved in a batch of 4 bit for bit
+        (samples never interact, so the sharded run IS the unsharded one)."""
+    from helmnet_amd.distributed import shard_batch, shard_bounds
     lo, hi = shard_bounds(256, rank, 8)
     assert (lo, hi) == (32 * rank, 32 * rank + 32)
-    sos = torch.from_numpy(smooth_random_sos(256, 256, seed=1)[lo:hi])
-    assert sos.shape == (32, 1, 256, 256) and float(sos.min()) >= 1.0 and float(sos.max()) <= 2.0
+    everything = torch.from_numpy(np.concatenate([ring_sos_batch(256, 32, seed=r) for r in range(8)]))     # the 256-map job
+    sos = shard_batch(everything, rank, 8)
+    assert sos.shape == (32, 1, 256, 256) and torch.equal(sos, torch.from_numpy(ring_sos_batch(256, 32, seed=rank)))
     s = _solver()
     s.set_domain_size(256, source_location=[30, 128])
     out = s.forward(sos[:4].to(DEV), num_iterations=40, residuals="norms")
     want = O.solve(sos[:4], weights, O.point_source_map(256, [30, 128], 10.0), O.SpectralTables(256, 8, 2, 1.0), 40)
-    assert (out["wavefields"][0].cpu() - want["wavefield"]).abs().max() <= 1e-4
+    err = float((out["wavefields"][0].cpu() - want["wavefield"]).abs().max())
     trace = torch.stack(want["trace"]).numpy()
-    assert np.abs(out["residual_norms"].cpu().numpy() / trace - 1).max() <= 2e-2
+    terr = float(np.abs(out["residual_norms"].cpu().numpy() / trace - 1).max())
+    print(f"config3 rank {rank}: Linf(wf) after 40 it = {err:.3e} (|wf| max {float(want['wavefield'].abs().max()):.3f}), trace rel err {terr:.3e}")
+    # 40 iterations into the transient (|wf| ~ 2.7) two fp32 evaluations differ by ~1e-4 of the field's scale (the reference's own
+    # fp32 run is 0.7 .. 8e-5 from its float64 run after 100 iterations, DESIGN section 2): the bar is relative to that scale
+    assert err <= 1e-4 * max(1.0, float(want["wavefield"].abs().max())) and terr <= 2e-2, (err, terr)
     full = s.forward(sos.to(DEV), num_iterations=1000, residuals="norms")
     wf = full["wavefields"][0]
     rm = full["residual_norms"].cpu().numpy()
+    print(f"config3 rank {rank}: RMSE it 1 max {rm[0].max():.3e}, it 1000 median {np.median(rm[-1]):.3e} max {rm[-1].max():.3e}")
     assert torch.isfinite(wf).all() and np.isfinite(rm).all()
     assert rm[-1].max() <= 2e-4 and rm[-1].max() <= 0.05 * rm[0].max(), (rm[0].max(), rm[-1].max())
     part = s.forward(sos[8:12].to(DEV), num_iterations=1000, residuals="norms")
     assert torch.equal(part["wavefields"][0], wf[8:12])
     assert torch.equal(part["residual_norms"], full["residual_norms"][:, 8:12])
+
+
+@pytest.mark.gpu
+def test_smooth_random_maps_of_the_survey_follow_the_oracle_while_they_diverge(weights):
+    """SURVEY 8(d) proposed `1 + U(0,1)` box-blurred maps for configs[2] (phantoms.smooth_random_sos).  Averaging 64 uniform
+    samples gives c ~ 1.5 +- 0.04 EVERYWHERE -- source, PML and background included -- which the network, trained on a c = 1
+    background, was never shown: the reference's iteration DIVERGES on them (|wavefield| ~ 2.6e3 after 40 iterations in the oracle
+    and here alike).  The HIP path must still follow the oracle for as long as that is meaningful: 10 iterations, relative 1e-4."""
+    from helmnet_amd.phantoms import smooth_random_sos
+    sos = torch.from_numpy(smooth_random_sos(256, 4, seed=1))
+    assert float(sos.min()) >= 1.0 and float(sos.max()) <= 2.0 and abs(float(sos.mean()) - 1.5) < 0.01
+    s = _solver()
+    s.set_domain_size(256, source_location=[30, 128])
+    out = s.forward(sos.to(DEV), num_iterations=10, residuals="norms")
+    want = O.solve(sos, weights, O.point_source_map(256, [30, 128], 10.0), O.SpectralTables(256, 8, 2, 1.0), 10)
+    scale = float(want["wavefield"].abs().max())
+    assert (out["wavefields"][0].cpu() - want["wavefield"]).abs().max() <= 1e-4 * scale
+    trace = torch.stack(want["trace"]).numpy()
+    assert np.abs(out["residual_norms"].cpu().numpy() / trace - 1).max() <= 1e-3
+    assert trace[-1].min() > trace[0].max()       # the residual grows: this input is outside what the network can solve
