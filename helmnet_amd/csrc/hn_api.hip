@@ -187,6 +187,8 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP}};
+    if (const char* v = getenv("HN_SIDE_PRIORITY")) c->opt_side_low_priority = std::atoi(v) != 0;
+    if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
         if (const char* v = getenv(k.env)) {
             char* end = nullptr;
@@ -620,7 +622,11 @@ int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side) {
         for (int j = 0; j < ns; ++j) {
             auto& sl = ctx->side[j];
             if (sl.stream) continue;
-            HN_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
+            // HN_SIDE_PRIORITY=1 (A/B only): lowest stream priority, so that the hidden-state kernels only fill what the main chain
+            // leaves idle -- measured 1 % SLOWER than the default priority (r3), so it stays off
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            HN_HIP(ctx, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, ctx->opt_side_low_priority ? least : 0));
             for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&sl.ev[d], hipEventDisableTiming));
             HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
@@ -631,7 +637,7 @@ int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side) {
 // One solver iteration of samples [b0, b0 + nb) on stream sj (hybridnet.py:558-584): the UNet update with the
 // wavefield updated in place by its last kernel, then the residual of the new wavefield.  `parity` selects the
 // direction of the hidden-state ping-pong (0: caller's buffer -> library buffer).
-int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, int lane, hipStream_t sj, hipEvent_t stagger) {
+int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, int lane, hipStream_t sj, hipEvent_t stagger, bool defer_join = false) {
     const long plane = (long)ctx->tab.n * ctx->tab.n, L = ctx->state_len;
     float* wf_j = a.wf + (size_t)b0 * 2 * plane;
     float* res_j = a.res + (size_t)b0 * 2 * plane;
@@ -641,7 +647,7 @@ int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, in
     const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
     const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
     int rc = unet_forward(ctx, s_wf, s_res, s_sig, parity ? st_tmp : st_user, parity ? st_user : st_tmp, nullptr, wf_j, nb, sj, b0,
-                          stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr);
+                          stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr, defer_join);
     if (rc != HN_OK) return rc;
     const float* src_j = a.src_batch == 1 ? a.src : a.src + (size_t)b0 * 2 * plane;
     return spec_apply(ctx, wf_j, res_j, a.k_sq + (size_t)b0 * plane, src_j, a.src_batch == 1 ? 1 : nb, nb,
@@ -768,7 +774,10 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
                 if (ctx->prof_mask)
                     for (int id = 0; id < KID_COUNT; ++id) if (ctx->prof_mask >> id & 1ull) ++ctx->prof_seen[id];
             } else {
-                if ((rc = one_iteration(ctx, a, it & 1, 0, batch, 0, s, nullptr)) != HN_OK) return rc;
+                // the new hidden states are first needed by the next iteration's conv_signal_0: the side-stream join moves there,
+                // unless something reads them right away (a state history) or this is the last iteration
+                const bool defer = ctx->opt_defer_join && ctx->opt_side_stream && !st_hist && it + 1 < n_iter && g == nullptr;
+                if ((rc = one_iteration(ctx, a, it & 1, 0, batch, 0, s, nullptr, defer)) != HN_OK) return rc;
                 ++ctx->eager_iterations;
             }
             if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + (size_t)it * batch * 2 * plane, res, fb_all, hipMemcpyDeviceToDevice, s));

@@ -123,6 +123,10 @@ struct hn_ctx {
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
     int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
     int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
+    bool opt_side_low_priority = false;  // side stream at the lowest stream priority (HN_SIDE_PRIORITY=1): measured -1 % (1961 / 1974 vs 1979 / 2001 it/s)
+    int opt_defer_join = 0;    // HN_DEFER_JOIN=1 (A/B): hn_step joins the side stream behind the NEXT iteration's input layer instead of at the end of
+                               // the UNet -- measured no gain (1902 / 1927 / 1938 vs 1932 / 1933 / 1946 it/s, r3): the ~6 us bubble is the event
+                               // packet itself, wherever it sits
     int opt_graph = 0;         // hn_step replays captured iterations (HIP graph; n > 1: n iterations per graph) instead of launching
                                // ~25 kernels per iteration.  Off by default: [measured] replay is 4 % SLOWER (586 vs 563 us per
                                // iteration at 256^2 x 32, graphs of 1, 2 or 8 iterations alike) -- the host keeps ahead of the GPU
@@ -149,7 +153,10 @@ struct hn_ctx {
     // hn_step pipelines sub-batches on internal streams (samples are independent): while one
     // sub-batch walks the small, latency-bound UNet levels the other one keeps the CUs busy
     // conv_state kernels run on a side stream per pipeline lane (HN_SIDE_STREAM, hn_step only)
-    struct SideLane { hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr; };
+    struct SideLane {
+        hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr;
+        bool pending = false;   // `done` has been recorded on the side stream and not been waited for yet (deferred join, hn_step)
+    };
     SideLane side[8];
     int n_streams = 0;         // internal streams created so far
     hipStream_t sub_stream[8]{};
@@ -300,7 +307,9 @@ int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, f
 // wavefield is updated in place (wf += d / 1e3) by the last kernel; if d_out != nullptr d is stored.
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
                  float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off = 0, hipEvent_t after_down0 = nullptr,
-                 hn_ctx::SideLane* side_lane = nullptr);
+                 hn_ctx::SideLane* side_lane = nullptr, bool defer_join = false);
+// make stream s wait for the hidden-state kernels of the previous unet_forward(..., defer_join = true) on this lane
+int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
 
 // standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv): fp32 vector kernels of hn_unet.hip on packed device weights
 int module_double_conv(hn_ctx* ctx, const float* x, int cin, int cout, const DcW& w, float* out, int batch, int H, int W, hipStream_t s);

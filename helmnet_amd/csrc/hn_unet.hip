@@ -426,7 +426,7 @@ __global__ __launch_bounds__(UpCfg::NT) void k_up8x8(Src in, Dst out, K8W w, int
 
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
                  float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off, hipEvent_t after_down0,
-                 hn_ctx::SideLane* side_lane) {
+                 hn_ctx::SideLane* side_lane, bool defer_join) {
     const int n = ctx->tab.n, depth = ctx->depth;
     const long L = ctx->state_len;
     const Src none{nullptr, 0, 0, 1.f};
@@ -443,6 +443,13 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     ProfScope ps(ctx, KID_INC, s);
     if (mfma) launch_dc8(ctx, 0, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, ctx->f_inc[0], ctx->f_inc[1], false, nullptr, nullptr, n, n, batch, s);
     else launch_dc<2, 2, 2, kFeat, kFeat, 0>(in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, noepi, n, n, batch, s);
+    }
+    // deferred join (hn_step): the hidden-state kernels of the PREVIOUS iteration are waited for here, behind the input layer (the
+    // first reader of the new states is conv_signal_0 below; the side kernels read the skip buffers, which conv_signal_0 is also the
+    // first to overwrite).  By now they have long finished, and the wait no longer sits in front of the spectral passes.
+    if (side_lane != nullptr) {
+        int rc = side_join(ctx, side_lane, s);
+        if (rc != HN_OK) return rc;
     }
     // the deepest level (32 x 32) and the bottleneck run as one per-sample kernel (hn_deep.hip) where they fit LDS
     const bool deep = mfma && deep_applies(ctx);
@@ -547,9 +554,21 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     }
     if (policy != 0) {  // the next iteration's conv_signal reads the new states
         HN_HIP(ctx, hipEventRecord(side_lane->done, side));
-        HN_HIP(ctx, hipStreamWaitEvent(s, side_lane->done, 0));
+        side_lane->pending = true;
+        if (!defer_join) {
+            int rc = side_join(ctx, side_lane, s);
+            if (rc != HN_OK) return rc;
+        }
     }
     HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s) {
+    if (side_lane != nullptr && side_lane->pending) {
+        HN_HIP(ctx, hipStreamWaitEvent(s, side_lane->done, 0));
+        side_lane->pending = false;
+    }
     return HN_OK;
 }
 
