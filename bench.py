@@ -68,7 +68,7 @@ def kernel_bytes(n: int, depth: int = 4) -> dict:
 # HBM traffic up in profiles/*_traffic.json (FETCH_SIZE + WRITE_SIZE of the same command, tools/summarize_profiles.py)
 ROCPROF_NAME = {"decode0": ("k_dc_valu<8, 8, 0, 1, false>", "k_dc_mfma_s<8, 8, 0, 1, false>", "k_dc_mfma_s<8, 8, 0, 1>"),
                 "inc": ("k_dc_valu<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0>"),
-                "spectral_rows": ("k_spec8_rows", "k_spec_rows<256>"), "spectral_cols": ("k_spec16_cols", "k_spec_cols<256, 16>")}
+                "spectral_rows": ("k_spec8_rows", "k_spec_rows<256>"), "spectral_cols": ("k_spec16_cols_t<16>", "k_spec16_cols_t<32>", "k_spec16_cols", "k_spec_cols<256, 16>")}
 
 
 def measured_traffic(kernel: str, n: int, batch: int, precision: str):

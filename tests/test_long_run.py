@@ -176,7 +176,7 @@ def test_config3_shards_of_the_8_way_run(weights, rank):
     """BASELINE configs[2]: a batch of 256 random sound-speed maps sharded 8 ways -- on one GPU, the slices ranks 0 and 7 of the
     8-GPU run take (``shard_bounds(256, r, 8)``: 32 maps each; the maps are what ``bench.py --gpus 8`` gives rank r: random ring
     phantoms of the training distribution, dataloaders.py:115-156, seed r).
-      * 40 iterations of the first 4 maps of the shard against the CPU oracle (L_inf(wavefield) <= 1e-4 * max|wf|, RMSE trace 2 %);
+      * 40 iterations of the first 2 maps of the shard against the CPU oracle (L_inf(wavefield) <= 1e-4 * max|wf|, RMSE trace 2 %);
       * the full 1000 iterations at B = 32 through the size-independent properties: everything finite, the residual converged
         to the trained network's floor, and sample i of the shard equals sample i solved in a batch of 4 bit for bit
         (samples never interact, so the sharded run IS the unsharded one)."""
@@ -188,8 +188,8 @@ def test_config3_shards_of_the_8_way_run(weights, rank):
     assert sos.shape == (32, 1, 256, 256) and torch.equal(sos, torch.from_numpy(ring_sos_batch(256, 32, seed=rank)))
     s = _solver()
     s.set_domain_size(256, source_location=[30, 128])
-    out = s.forward(sos[:4].to(DEV), num_iterations=40, residuals="norms")
-    want = O.solve(sos[:4], weights, O.point_source_map(256, [30, 128], 10.0), O.SpectralTables(256, 8, 2, 1.0), 40)
+    out = s.forward(sos[:2].to(DEV), num_iterations=40, residuals="norms")
+    want = O.solve(sos[:2], weights, O.point_source_map(256, [30, 128], 10.0), O.SpectralTables(256, 8, 2, 1.0), 40)
     err = float((out["wavefields"][0].cpu() - want["wavefield"]).abs().max())
     trace = torch.stack(want["trace"]).numpy()
     terr = float(np.abs(out["residual_norms"].cpu().numpy() / trace - 1).max())

@@ -5,7 +5,9 @@
 
 writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats, verbatim),
 profiles/<tag>_pmc_per_kernel.csv (per-kernel averages of every collected counter) and
-profiles/<tag>_traffic.json (HBM bytes per launch of each kernel: (FETCH_SIZE + WRITE_SIZE) * 1024).
+profiles/<tag>_traffic.json (fabric bytes per launch of each kernel: (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- on gfx950 FETCH_SIZE
+tallies a 128-byte line at 64 bytes (MI355X_MICROARCH.md, HBM section); profiles/r3_tcc_xcd_ab.csv shows that every fabric read of
+these kernels is such a line: TCC_EA0_RDREQ_32B = 0, FETCH_SIZE * 1024 = TCC_EA0_RDREQ * 64 = TCC_MISS * 64).
 """
 import collections
 import csv
@@ -52,8 +54,9 @@ with open(os.path.join(out, f"{tag}_pmc_per_kernel.csv"), "w", newline="") as f:
 traffic = {}
 for k in agg:
     if "FETCH_SIZE" in agg[k] and "WRITE_SIZE" in agg[k]:
-        fb = agg[k]["FETCH_SIZE"] / len(launches[k]["FETCH_SIZE"]) * 1024
+        fb = agg[k]["FETCH_SIZE"] / len(launches[k]["FETCH_SIZE"]) * 1024 * 2    # 128-byte lines tallied at 64 bytes (see the docstring)
         wb = agg[k]["WRITE_SIZE"] / len(launches[k]["WRITE_SIZE"]) * 1024
-        traffic[k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes_per_launch": round(fb + wb)}
+        traffic[k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes_per_launch": round(fb + wb),
+                      "fetch_counter_rule": "2 x FETCH_SIZE x 1024"}
 json.dump(traffic, open(os.path.join(out, f"{tag}_traffic.json"), "w"), indent=1, sort_keys=True)
 print("wrote", sorted(os.listdir(out)))
