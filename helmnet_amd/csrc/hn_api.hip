@@ -481,7 +481,9 @@ int hn_profile_min(hn_ctx* ctx, double* min_ms, int n_ids) {
 int hn_profile_stride(hn_ctx* ctx, int every_nth) {
     if (!ctx || every_nth < 1) return fail(ctx, HN_ERR_ARG, "hn_profile_stride: stride must be >= 1");
     ctx->prof_stride = every_nth;
-    for (auto& v : ctx->prof_seen) v = 0;
+    // sampling starts half a stride in: the first launches after the caller's synchronisation run on a GPU that has just idled
+    // (clocks still ramping) and are not representative of the region being sampled
+    for (auto& v : ctx->prof_seen) v = every_nth - every_nth / 2;
     return HN_OK;
 }
 

@@ -183,7 +183,7 @@ struct hn_ctx {
         float* gbuf = nullptr;       // gradient buffers, carved below
         float *g_x[hn::kMaxDepth + 1]{}, *g_out[hn::kMaxDepth]{}, *g_u[hn::kMaxDepth]{}, *g_y[hn::kMaxDepth + 1]{};
         float *gz = nullptr, *tmp8 = nullptr, *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
-        float* part = nullptr;       // [256 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
+        float* part = nullptr;       // [640 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
         size_t part_floats = 0;
         double* slope_part = nullptr; // [3 depth + 2 DoubleConvs][slope_stride]: per-block sums of the PReLU-slope gradients (float64)
         size_t slope_stride = 0;

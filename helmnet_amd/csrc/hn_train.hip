@@ -18,7 +18,7 @@
 //     transposed-convolution matrix-core kernel of the inference path (hn_mfma.hip) with the forward weights read as
 //     [in, out, kh, kw], and vice versa; their A-operand fragments are packed on the device too.
 //   * Weight gradients: a block accumulates the [cout, cin, kh, kw] (+ bias) sums of its run of tiles in registers and adds
-//     them to ITS row of a [256 rows][blob] table that collects all layers and all unrolled iterations; ONE reduction kernel
+//     them to ITS row of a [640 rows][blob] table that collects all layers and all unrolled iterations; ONE reduction kernel
 //     at the end of the call sums the rows in a fixed order into the gradient blob -- no atomics: gradients are
 //     bit-reproducible.
 //   * The spectral operator is linear: its backward is the adjoint pass spec_adjoint (hn_spectral.hip).
@@ -111,7 +111,7 @@ struct WindowStager {
     }
     // channels [0, nch) of the concatenation src[0..2]; `slope` / `act_kind` for groups staged through the activation
     __device__ __forceinline__ void stage(const TSrc (&src)[3], int nch, int b, float* dst, int cstride, int act_kind, float slope) const {
-#pragma unroll 4
+#pragma unroll 8
         for (int c = 0; c < nch; ++c) {
             int cs = c, si = 0;
             if (cs >= src[0].nch) { cs -= src[0].nch; si = 1; if (cs >= src[1].nch) { cs -= src[1].nch; si = 2; } }
@@ -142,9 +142,10 @@ __device__ __forceinline__ CfPtr cf(const float* p) { return (CfPtr)(uintptr_t)p
 // (backward-data: out = gradient of the input).
 //   EPI_ACT: out *= act'(z) (z: the pre-activation tensor the gradient flows back into) and, for PReLU, this block's partial sum
 //            of out_before * min(z, 0) (d loss / d slope) is added to slope_part[block].
-// Tile 16 x 32, 128 threads, thread = 1 x 4 strip x all CO channels; ALL input channels staged at once (one load phase, one
-// barrier: at the reference's training size a launch is ~2 wavefronts per SIMD, so the serial load -> barrier -> compute
-// chain of a block is what its time is made of).
+// Tile 16 x 32, 512 threads, thread = ONE pixel x all CO channels; ALL input channels staged at once (one load phase, one barrier).
+// At the reference's training size (96^2 x 32) a layer is 295 k pixels: one pixel per thread makes it 4.5 wavefronts per SIMD, and
+// what a launch costs is the serial load -> barrier -> compute chain of one wavefront -- with 1 x 4 strips per thread (1.1 wavefronts
+// per SIMD, four times the chain) the same kernels measured 22-31 us.
 // ------------------------------------------------------------------------------------------------------------------
 struct Conv3Args {
     TSrc src[3];
@@ -161,70 +162,58 @@ struct Conv3Args {
 constexpr int kC3TH = 16, kC3TW = 32, kC3PI = 36;
 
 template <int CO, bool EPI_ACT>
-__global__ __launch_bounds__(128) void k_conv3(Conv3Args a) {
+__global__ __launch_bounds__(512) void k_conv3(Conv3Args a) {
     constexpr int TH = kC3TH, TW = kC3TW, PI = kC3PI, IR = TH + 2, IC = TW + 2;
     extern __shared__ __attribute__((aligned(16))) float s_in[];   // [CI][IR][PI] + 8
-    __shared__ double s_red[2];
+    __shared__ double s_red[8];
     const int tid = threadIdx.x;
     const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int CI = a.src[0].nch + a.src[1].nch + a.src[2].nch;
     const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
     {
-        WindowStager<IR, IC, 128> st;
+        WindowStager<IR, IC, 512> st;
         st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
         st.stage(a.src, CI, b, s_in, IR * PI, a.act_kind, slope);
     }
     __syncthreads();
-    const int ry = tid >> 3, sx = tid & 7;   // output row y0 + ry, columns x0 + 4 sx .. + 3
-    float acc[4][CO];
+    const int ry = tid >> 5, cx = tid & 31;   // one output pixel per thread: (y0 + ry, x0 + cx), all CO channels
+    float acc[CO];
 #pragma unroll
-    for (int p = 0; p < 4; ++p)
-#pragma unroll
-        for (int c = 0; c < CO; ++c) acc[p][c] = 0.f;
+    for (int c = 0; c < CO; ++c) acc[c] = 0.f;
     const CfPtr wc = cf(a.wpk);
-#pragma unroll 1
+#pragma unroll CO <= 8 ? 2 : 1
     for (int ci = 0; ci < CI; ++ci) {
-        const float* t = &s_in[(ci * IR + ry) * PI + 4 * sx];
+        const float* t = &s_in[(ci * IR + ry) * PI + cx];
         const CfPtr wq = wc + ci * 9 * CO;
+        float v[9];
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) {
-            const float4 lo = *reinterpret_cast<const float4*>(t + dy * PI);
-            const float2 hi = *reinterpret_cast<const float2*>(t + dy * PI + 4);
-            const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+        for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx)
+            for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = t[dy * PI + dx];
 #pragma unroll
-                for (int c = 0; c < CO; ++c) {
-                    const float wv = wq[(dy * 3 + dx) * CO + c];
+        for (int k = 0; k < 9; ++k)
 #pragma unroll
-                    for (int p = 0; p < 4; ++p) acc[p][c] = fmaf(wv, v[p + dx], acc[p][c]);
-                }
-        }
+            for (int c = 0; c < CO; ++c) acc[c] = fmaf(wq[k * CO + c], v[k], acc[c]);
     }
-    const int y = y0 + ry;
+    const int y = y0 + ry, x = x0 + cx;
     double sp = 0.0;   // the slope gradient is ONE number summed over every pixel of the layer with both signs: kept in float64
-    if (y < a.H) {
+    if (y < a.H && x < a.W) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
             const float bias = a.bias != nullptr ? a.bias[c] : 0.f;
             int cd = c, di = 0;
             if (cd >= a.dst[0].nch) { cd -= a.dst[0].nch; di = 1; if (cd >= a.dst[1].nch) { cd -= a.dst[1].nch; di = 2; } }
             const TDst& ds = a.dst[di];
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int x = x0 + 4 * sx + p;
-                if (x >= a.W) continue;
-                float v = acc[p][c] + bias;
-                if (EPI_ACT) {
-                    const float zz = a.z[(long)b * a.z_sb + (long)c * a.z_sc + (long)y * a.W + x];
-                    if (zz <= 0.f) sp += (double)v * (double)zz;
-                    v *= act_grad(zz, a.act_kind, slope);
-                }
-                if (ds.p != nullptr) {
-                    float* q = ds.p + (long)b * ds.sb + (long)cd * ds.sc + (long)y * a.W + x;
-                    v *= ds.scale;
-                    *q = ds.accum ? *q + v : v;
-                }
+            float v = acc[c] + bias;
+            if (EPI_ACT) {
+                const float zz = a.z[(long)b * a.z_sb + (long)c * a.z_sc + (long)y * a.W + x];
+                if (zz <= 0.f) sp += (double)v * (double)zz;
+                v *= act_grad(zz, a.act_kind, slope);
+            }
+            if (ds.p != nullptr) {
+                float* q = ds.p + (long)b * ds.sb + (long)cd * ds.sc + (long)y * a.W + x;
+                v *= ds.scale;
+                *q = ds.accum ? *q + v : v;
             }
         }
     }
@@ -233,7 +222,12 @@ __global__ __launch_bounds__(128) void k_conv3(Conv3Args a) {
         for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
         if ((tid & 63) == 0) s_red[tid >> 6] = sp;
         __syncthreads();
-        if (tid == 0) a.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] += s_red[0] + s_red[1];
+        if (tid == 0) {
+            double tot = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < 8; ++wv) tot += s_red[wv];
+            a.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] += tot;
+        }
     }
 }
 
@@ -255,11 +249,13 @@ struct Wg3Args {
     long row_stride;    // floats between the rows of the table
 };
 
+constexpr int kWgTH = 16;  // tile rows of the weight-gradient kernel (8-row tiles, twice the blocks: measured the same, r3)
 template <int CO>
 __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
-    constexpr int TH = 16, TW = 32, IR = TH + 2, IC = TW + 2, PI = 35;
-    __shared__ float s_x[16 * IR * PI];
-    __shared__ __attribute__((aligned(16))) float s_g[TH * TW * CO];
+    constexpr int TH = kWgTH, TW = 32, IR = TH + 2, IC = TW + 2, PI = 35;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // gradient tile [TH][TW][CO], then the input window [CI][IR][PI] (>= 256 * 3 * CO floats)
+    float* const s_g = s_dyn;
+    float* const s_x = s_dyn + TH * TW * CO;
     const int tid = threadIdx.x;
     const int CI = a.src[0].nch + a.src[1].nch + a.src[2].nch;
     const int P = CI * 3 + 1, S = 256 / P;
@@ -302,12 +298,13 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
         }
         __syncthreads();
         if (active) {
-            for (int r = split; r < TH; r += S) {
-                const float* xr = &s_x[(ci * IR + r + ky) * PI];
-                const float* gr = &s_g[r * TW * CO];
+            for (int u = split; u < 2 * TH; u += S) {   // work units: (row, half of the columns), dealt round-robin to the S row subsets
+                const int r = u >> 1, c0 = (u & 1) * (TW / 2);
+                const float* xr = &s_x[(ci * IR + r + ky) * PI + c0];
+                const float* gr = &s_g[(r * TW + c0) * CO];
                 float xa = isb ? 1.f : xr[0], xb = isb ? 0.f : xr[1];
 #pragma unroll 4
-                for (int c = 0; c < TW; ++c) {
+                for (int c = 0; c < TW / 2; ++c) {
                     const float xc = isb ? 0.f : xr[c + 2];
 #pragma unroll
                     for (int o = 0; o < CO; ++o) {
@@ -332,8 +329,8 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
             for (int o = 0; o < CO; ++o) s_red[((split * P + pair) * 3 + k) * CO + o] = acc[k][o];
     }
     __syncthreads();
+    float* s_out = s_g;   // the block's sums in the layout of the table row: [CO][CI][3][3], then [CO]
     if (tid < P) {
-        float* row = a.part + (size_t)blockIdx.x * a.row_stride;
         const int pc = tid / 3, pky = tid - pc * 3;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -342,12 +339,17 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
                 float sum = 0.f;
                 for (int q = 0; q < S; ++q) sum += s_red[((q * P + tid) * 3 + k) * CO + o];
                 if (tid == P - 1) {
-                    if (k == 0) row[CO * CI * 9 + o] += sum;
+                    if (k == 0) s_out[CO * CI * 9 + o] = sum;
                 } else {
-                    row[(o * CI + pc) * 9 + pky * 3 + k] += sum;
+                    s_out[(o * CI + pc) * 9 + pky * 3 + k] = sum;
                 }
             }
     }
+    __syncthreads();
+    // coalesced read-modify-write of the block's own cells (scattered 4-byte atomics here cost 40 us per level-0 launch: 1.3 M of
+    // them, each a 64-byte transaction at the memory side)
+    float* row = a.part + (size_t)blockIdx.x * a.row_stride;
+    for (int i = tid; i < CO * CI * 9 + CO; i += 256) row[i] += s_out[i];
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
     }
     float* row = a.part + (size_t)blockIdx.x * a.row_stride;
 #pragma unroll
-    for (int c = 0; c < kFeat; ++c) row[(c * kFeat + bch) * 64 + k] += acc[c];
+    for (int c = 0; c < kFeat; ++c) unsafeAtomicAdd(&row[(c * kFeat + bch) * 64 + k], acc[c]);
 }
 
 // per-channel sums of a [B, C, plane] tensor (bias gradients of the 8x8 convolutions), added to rows [0, gridDim.x) of the table
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) part[(size_t)blockIdx.x * row_stride + c] += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (threadIdx.x == 0) unsafeAtomicAdd(&part[(size_t)blockIdx.x * row_stride + c], (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
 }
 
 // grad[j] = sum over the rows of the table, in a fixed order (every weight-gradient kernel of the call has added to its row)
@@ -513,7 +515,7 @@ __global__ __launch_bounds__(256) void k_outc_bwd(const float* __restrict__ g_wf
         if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][q] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 18) part[(size_t)blockIdx.x * row_stride + threadIdx.x] += (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+    if (threadIdx.x < 18) unsafeAtomicAdd(&part[(size_t)blockIdx.x * row_stride + threadIdx.x], (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]));
 }
 
 // g = [g_in +] c * res   (the loss term of one unrolled iteration: d/d res of scale * mean(res^2))
@@ -583,8 +585,8 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // ---- host-side drivers -------------------------------------------------------------------------------------------------
 template <int CO>
 void launch_conv3_co(const Conv3Args& a, bool epi, dim3 grid, size_t lds, hipStream_t s) {
-    if (epi) hipLaunchKernelGGL((k_conv3<CO, true>), grid, dim3(128), lds, s, a);
-    else hipLaunchKernelGGL((k_conv3<CO, false>), grid, dim3(128), lds, s, a);
+    if (epi) hipLaunchKernelGGL((k_conv3<CO, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((k_conv3<CO, false>), grid, dim3(512), lds, s, a);
 }
 int launch_conv3(hn_ctx* ctx, int co, bool epi, const Conv3Args& a, int batch, hipStream_t s) {
     const dim3 grid(cdiv(a.W, kC3TW), cdiv(a.H, kC3TH), batch);
@@ -601,7 +603,7 @@ int launch_conv3(hn_ctx* ctx, int co, bool epi, const Conv3Args& a, int batch, h
     return HN_OK;
 }
 
-constexpr int kPartRows = 256;   // rows of the partials table = the most blocks a weight-gradient launch uses
+constexpr int kPartRows = 640;   // rows of the partials table = the most blocks a weight-gradient launch uses (96^2 x 32: 576 tiles of 16 x 32, one each)
 
 struct Trainer {
     hn_ctx* ctx;
@@ -649,13 +651,17 @@ struct Trainer {
         for (int i = 0; i < 3; ++i) a.src[i] = in[i];
         a.g = g.p; a.g_sb = g.sb; a.g_sc = g.sc;
         a.H = a.W = side(d);
-        a.tiles_x = cdiv(a.W, 32); a.tiles_y = cdiv(a.H, 16); a.batch = B;
+        a.tiles_x = cdiv(a.W, 32); a.tiles_y = cdiv(a.H, kWgTH); a.batch = B;
         a.act_kind = act; a.slope = w + slope_off;
         a.part = table(grad_off); a.row_stride = (long)L.total;
         const int ntiles = a.tiles_x * a.tiles_y * B;
         const int blocks = ntiles < kPartRows ? ntiles : kPartRows;
-        if (co == 8) hipLaunchKernelGGL(k_conv3_wgrad<8>, dim3(blocks), dim3(256), 0, s, a);
-        else if (co == 2) hipLaunchKernelGGL(k_conv3_wgrad<2>, dim3(blocks), dim3(256), 0, s, a);
+        const int ci = in[0].nch + in[1].nch + in[2].nch;
+        size_t lds_x = (size_t)ci * (kWgTH + 2) * 35;                     // input window; doubles as the reduction scratch (256 * 3 * CO floats)
+        if (lds_x < (size_t)256 * 3 * co) lds_x = (size_t)256 * 3 * co;
+        const size_t lds = sizeof(float) * ((size_t)kWgTH * 32 * co + lds_x);
+        if (co == 8) hipLaunchKernelGGL(k_conv3_wgrad<8>, dim3(blocks), dim3(256), lds, s, a);
+        else if (co == 2) hipLaunchKernelGGL(k_conv3_wgrad<2>, dim3(blocks), dim3(256), lds, s, a);
         else return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no weight-gradient kernel for %d output channels", co);
         return HN_OK;
     }

@@ -243,8 +243,8 @@ int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_
  * launch counts for ids [0, n_ids) and resets the accumulators. */
 #define HN_KERNEL_IDS 35
 int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
-/* Bracket only every `every_nth` launch of a selected kernel (default 1).  An event pair costs a few
- * microseconds of stream gap, so timed runs sample instead of bracketing every launch. */
+/* Bracket only every `every_nth` launch of a selected kernel (default 1), starting every_nth / 2 launches in.  An event pair
+ * costs a few microseconds of stream gap, so timed runs sample instead of bracketing every launch. */
 int hn_profile_stride(hn_ctx* ctx, int every_nth);
 int hn_profile_collect(hn_ctx* ctx, double* total_ms, int64_t* count, int n_ids);
 /* Shortest bracketed launch per kernel id in the interval closed by the last hn_profile_collect
