@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void k_pack_frag8(const float* __restrict__ ra
 }
 // 3x3 weights raw [O][I][3][3] -> both arrangements k_conv3 reads: forward [I][9][O] at dst + off, backward-data [O][9][I]
 // (taps flipped) at dst + total + off.  One launch packs every 3x3 convolution of the network (blockIdx.y = job).
-struct Pack3Jobs { int n; int off[32]; short o[32], i[32]; };
+struct Pack3Jobs { int n; int off[2 * (3 * kMaxDepth + 2)]; short o[2 * (3 * kMaxDepth + 2)], i[2 * (3 * kMaxDepth + 2)]; };
 __global__ __launch_bounds__(256) void k_pack3(const float* __restrict__ raw, float* __restrict__ dst, long total, Pack3Jobs jobs) {
     const int j = blockIdx.y, O = jobs.o[j], I = jobs.i[j], off = jobs.off[j];
     const int e = blockIdx.x * 256 + threadIdx.x;

@@ -347,3 +347,40 @@ def test_trainer_runs_training_steps_and_learns(solver):
     b = tr2.loss_and_grad(*probe[:5])
     tr2.optimizer_step()
     assert torch.equal(a["grad"], b["grad"]) and torch.equal(tr.weights, tr2.weights)
+
+
+def test_other_depth_and_fresh_weights(weights):
+    """depth 3 (three encoder levels, bottleneck at N / 8), a freshly initialised network, tanh, two unrolled iterations: the
+    launch sequence, tape layout and weight-blob offsets follow hparams.depth, not the shipped checkpoint's 4."""
+    from helmnet_amd import IterativeSolver
+    torch.manual_seed(3)
+    n, b, depth = 48, 2, 3
+    s = IterativeSolver(domain_size=n, k=1.0, omega=1, PMLsize=8, sigma_max=2, source_location=[16, 24], activation_function="tanh",
+                        depth=depth, state_depth=depth, features=8, state_channels=2, source_amplitude=10)
+    with torch.no_grad():
+        for p in s.f.parameters():
+            if p.dim() == 4:
+                p.mul_(15.0)      # Xavier with gain 0.02 (hybridnet.py:70-75) gives a nearly linear tanh: scale into its curved range
+            else:
+                p.uniform_(-0.1, 0.1)
+    s.to(DEV)
+    eng = s.engine()
+    wts = {k: v.detach().cpu() for k, v in s.f.state_dict().items()}
+    ti = teacher_inputs(n, b, seed=77)
+    L = sum((n >> d) ** 2 for d in range(depth))
+    wf, res, sos = (torch.from_numpy(ti[k]) for k in ("wf", "res", "sos"))
+    st = 0.3 * torch.from_numpy(np.random.default_rng(5).standard_normal((b, 2, L)).astype(np.float32))
+    k_sq = (1.0 / sos) ** 2
+    t = O.SpectralTables(n, 8, 2, 1.0, dtype=torch.float64)
+    src = O.point_source_map(n, [16, 24], 10.0)
+    w = {k: v.clone().double().requires_grad_(True) for k, v in wts.items()}
+    wf_, res_, st_ = (x.clone().double().requires_grad_(True) for x in (wf, res, st))
+    loss, *_ = O.training_loss(wf_, res_, st_, k_sq.double(), src.double(), w, t, 2, depth=depth, act="tanh")
+    loss.backward()
+    blob = torch.from_numpy(pack_weights(wts, depth, "tanh")).to(DEV)
+    out = eng.train_grad(blob, wf.to(DEV), res.to(DEV), st.to(DEV), k_sq.to(DEV).contiguous(), src.to(DEV).contiguous(), 2, 1e4, input_grads=True)
+    got = unpack_weights(out["grad"], depth)
+    errs = {k: rel(torch.from_numpy(got[k]), w[k].grad) for k in wts}
+    errs.update(grad_wf=rel(out["grad_wf"], wf_.grad), grad_res=rel(out["grad_res"], res_.grad), grad_states=rel(out["grad_states"], st_.grad))
+    _report(errs, 2e-4)
+    assert abs(float(out["loss"][0]) - float(loss)) <= 1e-5 * float(loss)
