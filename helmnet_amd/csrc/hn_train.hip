@@ -19,10 +19,11 @@
 //     [in, out, kh, kw], and vice versa; their A-operand fragments are packed on the device too.
 //   * Weight gradients: a block accumulates the [cout, cin, kh, kw] (+ bias) sums of its run of tiles in registers and adds
 //     them to ITS row of a [640 rows][blob] table that collects all layers and all unrolled iterations; ONE reduction kernel
-//     at the end of the call sums the rows in a fixed order into the gradient blob -- no atomics: gradients are
-//     bit-reproducible.
+//     at the end of the call sums the rows in a fixed order into the gradient blob.  A table cell belongs to one block within a
+//     launch and launches are ordered by the stream, so the updates (plain read-modify-writes, or no-return atomics where they
+//     are coalesced) happen in a fixed order: gradients are bit-reproducible.
 //   * The spectral operator is linear: its backward is the adjoint pass spec_adjoint (hn_spectral.hip).
-//   * Everything is enqueued on the caller's stream; the only host synchronisation is none.
+//   * Everything is enqueued on the caller's stream; nothing synchronises with the host (except when the workspace has to grow).
 #include <cmath>
 
 #include "hn_internal.h"
