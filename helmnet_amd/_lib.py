@@ -14,7 +14,8 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_void_
 
 import torch  # noqa: F401  (must be imported before the library is loaded, see above)
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhelmnet_hip.so")
+# HELMNET_HIP_LIB: another build of the same library (A/B experiments, tools/build_variant.sh); it must export the same ABI
+_LIB_PATH = os.environ.get("HELMNET_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhelmnet_hip.so")
 _lib = None
 
 HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2, "celu": 3, "tanh": 4, "gelu": 5, "tanhshrink": 6, "softplus": 7}
