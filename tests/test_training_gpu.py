@@ -384,3 +384,51 @@ def test_other_depth_and_fresh_weights(weights):
     errs.update(grad_wf=rel(out["grad_wf"], wf_.grad), grad_res=rel(out["grad_res"], res_.grad), grad_states=rel(out["grad_states"], st_.grad))
     _report(errs, 2e-4)
     assert abs(float(out["loss"][0]) - float(loss)) <= 1e-5 * float(loss)
+
+
+_DDP_SCRIPT = r'''
+import os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import torch.distributed as dist
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29537")
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)   # before any other GPU work in this process
+from helmnet_amd import IterativeSolver
+from helmnet_amd.training import Trainer, allreduce_gradients
+from helmnet_amd.phantoms import ring_sos_batch
+torch.manual_seed(0); np.random.seed(0)
+def make():
+    torch.manual_seed(0)
+    s = IterativeSolver(domain_size=32, k=1.0, omega=1, PMLsize=8, sigma_max=2, source_location=[10, 16], activation_function="prelu",
+                        batch_size=4, buffer_size=8, learning_rate=1e-3, minimum_learning_rate=1e-4, weight_decay=1e-6, gradient_clip_val=1,
+                        max_iterations=100, unrolling_steps=3)
+    return s.to(dev)
+sos = torch.from_numpy(ring_sos_batch(32, 8, seed=3))
+calls = []
+def counted(g):
+    calls.append(g.numel())
+    return allreduce_gradients(g)                      # dist.all_reduce over RCCL (world size 1: the identity) + division
+a, b = Trainer(make(), grad_reduce=counted), Trainer(make(), grad_reduce=lambda g: g)
+for t in (a, b):
+    t.fill_replay_buffer(sos)
+probe = a.replaybuffer.sample(4)
+for _ in range(3):
+    oa = a.loss_and_grad(*probe[:5]); a.optimizer_step()
+    ob = b.loss_and_grad(*probe[:5]); b.optimizer_step()
+assert calls == [48160] * 3, calls
+assert torch.equal(a.weights, b.weights) and torch.equal(oa["grad"], ob["grad"]), "the RCCL all-reduce changed the gradient at world size 1"
+dist.barrier(); dist.destroy_process_group()
+print("DDP_OK", float(oa["loss"][0]))
+'''
+
+
+def test_trainer_under_an_rccl_process_group_world_size_1(tmp_path):
+    """The data-parallel training step on hardware: `allreduce_gradients` on the flat device gradient under
+    init_process_group("nccl", world_size=1) between hn_train_grad and hn_adam_step; equals the trainer without a group bit for bit."""
+    import subprocess, sys
+    script = tmp_path / "ddp.py"
+    script.write_text(_DDP_SCRIPT)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, str(script), repo], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DDP_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
