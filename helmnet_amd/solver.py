@@ -237,6 +237,31 @@ class IterativeSolver(nn.Module):
             return x.pow(2).mean()
         raise NotImplementedError("The loss function {} is not implemented".format(self.hparams.loss))
 
+    def get_random_source_loc(self):
+        """hybridnet.py:178-190: a random source location on a circle of radius L - PMLsize - 2 around the domain centre."""
+        import numpy as np
+        theta = 2 * np.pi * np.random.rand()
+        L = self.hparams.domain_size // 2
+        dL = L - self.hparams.PMLsize - 2
+        return [int(L + dL * np.cos(theta)), int(L + dL * np.sin(theta))]
+
+    def validation_step(self, batch, batch_idx=0):
+        """hybridnet.py:333-352: one random source per sample, max_iterations solver iterations, loss = sqrt(mean(res_last^2)) over the
+        batch (NaN -> inf); returns the loss, the first sample's wavefield mapped to [0, 1] and the batch index."""
+        self.set_multiple_sources([self.get_random_source_loc() for _ in range(batch.shape[0])])
+        output = self.forward(batch, num_iterations=self.hparams.max_iterations, return_wavefields=False, return_states=False, residuals="last")
+        loss = self.loss_function(output["residuals"][-1]).sqrt()
+        loss = torch.where(torch.isnan(loss), torch.full_like(loss, float("inf")), loss)
+        sample_wavefield = (torch.nn.functional.hardtanh(output["wavefields"][0][0]) + 1) / 2
+        return {"loss": loss, "sample_wavefield": sample_wavefield, "batch_idx": batch_idx}
+
+    def test_step(self, batch, batch_idx=0):
+        """hybridnet.py:299-314: max_iterations iterations with every wavefield kept; per-sample residual RMSE after every iteration
+        ([B, max_iterations], from the fused on-device norms) and the list of wavefields."""
+        self.reset_source()
+        output = self.forward(batch, num_iterations=self.hparams.max_iterations, return_wavefields=True, return_states=False, residuals="norms")
+        return {"losses": output["residual_norms"].transpose(0, 1).contiguous(), "wavefields": list(output["wavefields"])}
+
     def trainer(self, **kwargs):
         """The training half of the reference class (replay buffer, training_step, Adam + ReduceLROnPlateau) for this solver."""
         from .training import Trainer

@@ -432,3 +432,25 @@ def test_trainer_under_an_rccl_process_group_world_size_1(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, str(script), repo], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DDP_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_validation_and_test_steps(solver):
+    """hybridnet.py:299-314, 333-352 on the HIP loop: shapes and values against plain forward() calls."""
+    np.random.seed(4)
+    solver.set_domain_size(64, source_location=[20, 32])
+    keep_loc = solver.hparams.source_location
+    solver.hparams.source_location = [20, 32]     # reset_source() returns to hparams.source_location (hybridnet.py:155-159)
+    solver.hparams.max_iterations = 30
+    sos = torch.from_numpy(ring_sos_batch(64, 3, seed=9)).to(DEV)
+    t = solver.test_step(sos)
+    ref = solver.forward(sos, num_iterations=30, return_wavefields=True)
+    assert t["losses"].shape == (3, 30) and len(t["wavefields"]) == 30
+    want = torch.stack([solver.test_loss_function(r) for r in ref["residuals"]], 1)
+    assert torch.allclose(t["losses"], want, rtol=1e-4) and torch.equal(t["wavefields"][-1], ref["wavefields"][-1])
+    v = solver.validation_step(sos, 5)
+    assert v["batch_idx"] == 5 and v["loss"].ndim == 0 and torch.isfinite(v["loss"]) and solver.source.shape[0] == 3
+    assert v["sample_wavefield"].shape == (2, 64, 64) and 0.0 <= float(v["sample_wavefield"].min()) and float(v["sample_wavefield"].max()) <= 1.0
+    loc = solver.get_random_source_loc()
+    assert abs(np.hypot(loc[0] - 32, loc[1] - 32) - 22) <= 1.5      # on the circle of radius L - PMLsize - 2 = 22
+    solver.hparams.max_iterations = 1000
+    solver.hparams.source_location = keep_loc
