@@ -274,12 +274,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
         const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, b = r0 / a.tiles_y;
         const int x0 = tx * TW, y0 = ty * TH;
         __syncthreads();
-        {
-            WindowStager<IR, IC, 256> st;
-            st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
-            st.stage(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);
-        }
-        {   // gradient tile, channel-interleaved: s_g[(y * TW + x) * CO + c]
+        {   // gradient tile (channel-interleaved in LDS: s_g[(y * TW + x) * CO + c]): requested first, in flight behind the input window's loads
             constexpr int NG = TH * TW / 256;
             float gv[CO][NG];
 #pragma unroll
@@ -292,6 +287,9 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
                     gv[c][i] = a.g[(long)b * a.g_sb + (long)c * a.g_sc + (ok ? (long)y * a.W + x : 0)];
                     if (!ok) gv[c][i] = 0.f;
                 }
+            WindowStager<IR, IC, 256> st;
+            st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
+            st.stage(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);
 #pragma unroll
             for (int c = 0; c < CO; ++c)
 #pragma unroll
@@ -330,27 +328,18 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
             for (int o = 0; o < CO; ++o) s_red[((split * P + pair) * 3 + k) * CO + o] = acc[k][o];
     }
     __syncthreads();
-    float* s_out = s_g;   // the block's sums in the layout of the table row: [CO][CI][3][3], then [CO]
-    if (tid < P) {
-        const int pc = tid / 3, pky = tid - pc * 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-#pragma unroll
-            for (int o = 0; o < CO; ++o) {
-                float sum = 0.f;
-                for (int q = 0; q < S; ++q) sum += s_red[((q * P + tid) * 3 + k) * CO + o];
-                if (tid == P - 1) {
-                    if (k == 0) s_out[CO * CI * 9 + o] = sum;
-                } else {
-                    s_out[(o * CI + pc) * 9 + pky * 3 + k] = sum;
-                }
-            }
-    }
-    __syncthreads();
-    // coalesced read-modify-write of the block's own cells (scattered 4-byte atomics here cost 40 us per level-0 launch: 1.3 M of
-    // them, each a 64-byte transaction at the memory side)
+    // every thread sums the row subsets (fixed order) of a few cells of the block's table row and adds them to it: consecutive
+    // threads own consecutive cells, so the read-modify-write is coalesced (a cell belongs to this block alone within a launch;
+    // one thread per tap row doing all of it serially was a third of the kernel's fixed cost, scattered 4-byte atomics another)
     float* row = a.part + (size_t)blockIdx.x * a.row_stride;
-    for (int i = tid; i < CO * CI * 9 + CO; i += 256) row[i] += s_out[i];
+    for (int i = tid; i < CO * CI * 9 + CO; i += 256) {
+        int o, p, k;
+        if (i >= CO * CI * 9) { o = i - CO * CI * 9; p = P - 1; k = 0; }
+        else { o = i / (CI * 9); const int r = i - o * (CI * 9), c = r / 9, t9 = r - c * 9, y3 = t9 / 3; p = c * 3 + y3; k = t9 - y3 * 3; }
+        float sum = 0.f;
+        for (int q = 0; q < S; ++q) sum += s_red[((q * P + p) * 3 + k) * CO + o];
+        row[i] += sum;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
