@@ -355,6 +355,7 @@ struct Wg8Args {
     int tiles_x, tiles_y, batch;
     float* part;
     long row_stride;
+    int bias_from_big;   // the bias gradient (per-channel sum of the OUTPUT gradient) behind the weight in the blob: 0 sum of sm (down), 1 sum of bg (up)
 };
 
 __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
@@ -364,9 +365,9 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
     const int tid = threadIdx.x;
     const int bch = tid >> 6, k = tid & 63, ky = k >> 3, kx = k & 7;
     const int hb = 2 * a.hs, wb = 2 * a.ws;
-    float acc[kFeat];
+    float acc[kFeat], bsum[kFeat];
 #pragma unroll
-    for (int c = 0; c < kFeat; ++c) acc[c] = 0.f;
+    for (int c = 0; c < kFeat; ++c) acc[c] = bsum[c] = 0.f;
     const int ntiles = a.tiles_x * a.tiles_y * a.batch;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, n = r0 / a.tiles_y;
@@ -405,27 +406,36 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
 #pragma unroll
                 for (int c = 0; c < kFeat; ++c) acc[c] = fmaf(sp[c], xv, acc[c]);
             }
+        // bias gradient: this thread's share of the tile's own pixels (positions outside the image were staged as zeros)
+        if (a.bias_from_big) {   // the 16 x 32 big-tensor pixels of the tile: one per thread, all 8 channels
+            const int py = tid >> 5, px = tid & 31;
+#pragma unroll
+            for (int c = 0; c < kFeat; ++c) bsum[c] += s_b[(c * BR + 3 + py) * PB + 3 + px];
+        } else if (tid < TY * TX) {   // the 8 x 16 small-tensor pixels
+#pragma unroll
+            for (int c = 0; c < kFeat; ++c) bsum[c] += s_s[tid * kFeat + c];
+        }
     }
     float* row = a.part + (size_t)blockIdx.x * a.row_stride;
 #pragma unroll
     for (int c = 0; c < kFeat; ++c) unsafeAtomicAdd(&row[(c * kFeat + bch) * 64 + k], acc[c]);
-}
-
-// per-channel sums of a [B, C, plane] tensor (bias gradients of the 8x8 convolutions), added to rows [0, gridDim.x) of the table
-__global__ __launch_bounds__(256) void k_channel_sum(const float* __restrict__ x, long sb, long sc, long plane, int batch, float* __restrict__ part, long row_stride) {
-    __shared__ float s_red[4];
-    const int c = blockIdx.y;
-    float s = 0.f;
-    const long total = (long)batch * plane;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const long b = i / plane, p = i - b * plane;
-        s += x[b * sb + (long)c * sc + p];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
+    // per-channel sums over the block (fixed order: wave shuffles, then the 8 wave partials), behind the 4096 weights
     __syncthreads();
-    if (threadIdx.x == 0) unsafeAtomicAdd(&part[(size_t)blockIdx.x * row_stride + c], (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+    float* s_part = s_s;   // [8 waves][8 channels]
+#pragma unroll
+    for (int c = 0; c < kFeat; ++c) {
+        float v = bsum[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((tid & 63) == 0) s_part[(tid >> 6) * kFeat + c] = v;
+    }
+    __syncthreads();
+    if (tid < kFeat) {
+        float v = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) v += s_part[wv * kFeat + tid];
+        row[kFeat * kFeat * 64 + tid] += v;
+    }
 }
 
 // grad[j] = sum over the rows of the table, in a fixed order (every weight-gradient kernel of the call has added to its row)
@@ -692,8 +702,9 @@ struct Trainer {
     int slot_dec(int d) const { return 1 + 2 * depth + d; }
     int slope_rows(int d) const { return cdiv(side(d), kC3TW) * cdiv(side(d), kC3TH) * B; }
 
-    void wgrad8(const float* sm, int d_small, const float* bg, size_t grad_off) {
+    void wgrad8(const float* sm, int d_small, const float* bg, size_t grad_off, int bias_from_big) {   // weight [4096] and bias [8] are adjacent in the blob
         Wg8Args a{};
+        a.bias_from_big = bias_from_big;
         a.sm = sm; a.sm_sb = kFeat * plane(d_small); a.sm_sc = plane(d_small); a.hs = a.ws = side(d_small);
         a.bg = bg; a.bg_sb = kFeat * plane(d_small - 1); a.bg_sc = plane(d_small - 1);
         a.tiles_x = cdiv(a.ws, 16); a.tiles_y = cdiv(a.hs, 8); a.batch = B;
@@ -701,10 +712,6 @@ struct Trainer {
         const int ntiles = a.tiles_x * a.tiles_y * B;
         hipLaunchKernelGGL(k_conv8_wgrad, dim3(ntiles < kPartRows ? ntiles : kPartRows), dim3(512), 0, s, a);
     }
-    void bias8(const float* g, int d, size_t grad_off) {
-        hipLaunchKernelGGL(k_channel_sum, dim3(32, kFeat), dim3(256), 0, s, g, (long)kFeat * plane(d), plane(d), plane(d), B, table(grad_off), (long)L.total);
-    }
-
     // one unrolled iteration, forward (hybridnet.py:558-584), filling step t of the tape
     int forward_step(int t, const float* wf, const float* res, const float* st_in, float* wf_next, float* res_next, float* st_next,
                      const float* ksq, const float* src, int src_batch) {
@@ -760,8 +767,7 @@ struct Trainer {
             if ((rc = dc_bwd(L.dec[d], slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d)) != HN_OK) return rc;
             // up[d]: backward-data = the stride-2 convolution kernel on the transposed-convolution weights read as [out, in, kh, kw]
             launch_down(ctx, msrc(W.g_u[d], d), mdst(W.g_y[d + 1], d + 1), frag8(d, 3), W.zero8, side(d), side(d), B, s);
-            wgrad8(tape(t, W.o_y[d + 1]), d + 1, W.g_u[d], L.up[d].w);
-            bias8(W.g_u[d], d, L.up[d].b);
+            wgrad8(tape(t, W.o_y[d + 1]), d + 1, W.g_u[d], L.up[d].w, 1);
         }
         {
             const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
@@ -774,8 +780,7 @@ struct Trainer {
             launch_up(ctx, msrc(W.g_x[d + 1], d + 1), mdst(W.tmp8, d), frag8(d, 1), W.zero8, side(d + 1), side(d + 1), B, s);
             const long tot8 = (long)B * kFeat * plane(d);
             hipLaunchKernelGGL(k_add, dim3((unsigned)((tot8 + 255) / 256)), dim3(256), 0, s, W.g_out[d], W.tmp8, tot8);
-            wgrad8(W.g_x[d + 1], d + 1, tape(t, W.o_out[d]), L.down[d].w);
-            bias8(W.g_x[d + 1], d + 1, L.down[d].b);
+            wgrad8(W.g_x[d + 1], d + 1, tape(t, W.o_out[d]), L.down[d].w, 0);
             {   // conv_state: new_state = DC(cat[out, state])
                 const TSrc in[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
                 const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 1), state_dst(W.g_st[cur_st ^ 1], d, 0), nodst()};
