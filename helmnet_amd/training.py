@@ -61,13 +61,25 @@ def allreduce_gradients(grad: torch.Tensor) -> torch.Tensor:
     return grad
 
 
-def trainable_mask(depth: int, activation: str) -> np.ndarray:
+def trainable_mask(depth: int, activation: str, state_depth: Optional[int] = None) -> np.ndarray:
     """1 for every blob entry the optimiser may change.  The slope slot of a DoubleConv is a parameter only for PReLU
-    (architectures.py:32-33); for the parameter-free activations it holds a constant."""
+    (architectures.py:32-33); for the parameter-free activations it holds a constant.  An encoder level WITHOUT state
+    (d >= state_depth, architectures.py:353) lives in the blob as its zero-padded stateful equivalent (engine.pack_weights): the
+    two padded input channels of its conv_signal and its whole (all-zero) conv_state are not parameters of the module."""
+    state_depth = depth if state_depth is None else state_depth
     parts = []
     for name, shape in weight_shapes(depth).items():
-        is_slope = name.endswith(".double_conv.1.weight")
-        parts.append(np.full(int(np.prod(shape)), 0 if (is_slope and activation.lower() != "prelu") else 1, np.uint8))
+        m = np.ones(shape, np.uint8)
+        if name.endswith(".double_conv.1.weight") and activation.lower() != "prelu":
+            m[...] = 0
+        if name.startswith("enc."):
+            d = int(name.split(".")[1])
+            if d >= state_depth:
+                if ".conv_state." in name:
+                    m[...] = 0
+                elif name.endswith(".conv_signal.double_conv.0.weight"):
+                    m[:, 8:] = 0
+        parts.append(m.reshape(-1))
     return np.concatenate(parts)
 
 
@@ -87,20 +99,18 @@ class Trainer:
         if hp.minimum_learning_rate > hp.learning_rate:                                             # :264-269
             raise ValueError("Minimum learning rate ({}) must be smaller than the starting learning rate ({})".format(
                 hp.minimum_learning_rate, hp.learning_rate))
-        if hp.state_depth != hp.depth:
-            raise NotImplementedError("training is implemented for state_depth == depth")
         self.solver = solver
         self.grad_reduce = grad_reduce
         self.engine = solver.engine()
         dev = self.engine.device
         f = solver.f
-        self.depth, self.activation = f.depth, f.activation_function
+        self.depth, self.activation, self.state_depth = f.depth, f.activation_function, f.state_depth
         blob = pack_weights(dict(f.state_dict()), f.depth, f.activation_function, f.state_depth)
         self.weights = torch.from_numpy(blob).to(dev)
         self.grad = torch.zeros_like(self.weights)
         self.exp_avg = torch.zeros_like(self.weights)
         self.exp_avg_sq = torch.zeros_like(self.weights)
-        self.trainable = torch.from_numpy(trainable_mask(f.depth, f.activation_function)).to(dev)
+        self.trainable = torch.from_numpy(trainable_mask(f.depth, f.activation_function, f.state_depth)).to(dev)
         self.step_count = 0
         self.current_epoch = 0
         self.global_step = 0
@@ -120,7 +130,10 @@ class Trainer:
         sd = unpack_weights(self.weights, self.depth)
         with torch.no_grad():
             for name, p in self.solver.f.named_parameters():
-                p.copy_(torch.from_numpy(sd[name]).reshape(p.shape))
+                v = torch.from_numpy(sd[name])
+                if v.dim() == 4 and v.shape[1] != p.shape[1]:     # conv_signal of a level without state: drop the zero-padded channels
+                    v = v[:, : p.shape[1]]
+                p.copy_(v.reshape(p.shape))
 
     def state_dict(self) -> dict:
         """Everything needed to resume: parameters, Adam moments and step, learning rate and scheduler state."""

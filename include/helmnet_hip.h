@@ -197,7 +197,8 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
  * checkpoint is those tensors.  The context supplies the architecture (depth / activation of the last hn_load_weights),
  * the spectral tables of hn_set_domain and the activation tape (grown on demand; hn_train_reserve pre-allocates).
  * fp32 throughout; gradients are accumulated in a fixed order (per-block partial sums + one reduction, no atomics):
- * bit-reproducible.  state_depth must equal depth. */
+ * bit-reproducible.  Levels without state (state_depth < depth) are handled by the caller's packing: zero-padded weights whose entries
+ * it marks non-trainable in hn_adam_step. */
 
 /* Pre-allocate the tape for `batch` samples x `n_unroll` unrolled iterations (optional). */
 int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll);

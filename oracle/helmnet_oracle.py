@@ -314,11 +314,12 @@ def unet_forward(x6: Tensor, states: List[Tensor], w: Dict[str, Tensor], depth: 
 # --------------------------------------------------------------------------
 # Solver loop
 # --------------------------------------------------------------------------
-def single_step(wf, k_sq, res, states, w, source, t: SpectralTables, depth: int = 4, act: str = "prelu", tape: Optional[dict] = None):
+def single_step(wf, k_sq, res, states, w, source, t: SpectralTables, depth: int = 4, act: str = "prelu", tape: Optional[dict] = None,
+                state_depth: Optional[int] = None):
     """helmnet/hybridnet.py:558-584."""
     sig = t.sigmas.to(wf.dtype).unsqueeze(0).repeat(wf.shape[0], 1, 1, 1)
     inp = torch.cat([wf, 1e3 * res, sig], dim=1)
-    d, new_states = unet_forward(inp, states, w, depth, act, tape=tape)
+    d, new_states = unet_forward(inp, states, w, depth, act, state_depth=state_depth, tape=tape)
     up = d / 1e3 + wf
     return up, get_residual(up, k_sq, source, t), new_states
 
@@ -346,7 +347,7 @@ def solve(sos: Tensor, w: Dict[str, Tensor], source: Tensor, t: SpectralTables, 
 # --------------------------------------------------------------------------
 def training_loss(wf: Tensor, res: Tensor, states_flat: Tensor, k_sq: Tensor, source: Tensor, w: Dict[str, Tensor],
                   t: SpectralTables, n_unroll: int = 10, depth: int = 4, act: str = "prelu", loss_scale: float = 1e4,
-                  tape: Optional[dict] = None):
+                  tape: Optional[dict] = None, state_depth: Optional[int] = None):
     """helmnet/hybridnet.py:399-409 (the differentiable core of ``training_step``): ``f.set_states(h_states, flatten=True)``
     -> ``n_steps(wavefields, k_sqs, residual, unrolling_steps, True, True)`` (:586-623) -> ``loss = 1e4 * cat(residuals).pow(2).mean()``.
     Every argument may require grad; gradients come from ``torch.autograd`` exactly as in the reference.  ``tape`` (optional
@@ -355,7 +356,7 @@ def training_loss(wf: Tensor, res: Tensor, states_flat: Tensor, k_sq: Tensor, so
     states = unflatten_states(states_flat, n, depth)
     wfs, ress, sts = [], [], []
     for it in range(n_unroll):
-        wf, res, states = single_step(wf, k_sq, res, states, w, source, t, depth, act, tape if it == 0 else None)
+        wf, res, states = single_step(wf, k_sq, res, states, w, source, t, depth, act, tape if it == 0 else None, state_depth)
         wfs.append(wf)
         ress.append(res)
         sts.append(flatten_states(states))

@@ -454,3 +454,65 @@ def test_validation_and_test_steps(solver):
     assert abs(np.hypot(loc[0] - 32, loc[1] - 32) - 22) <= 1.5      # on the circle of radius L - PMLsize - 2 = 22
     solver.hparams.max_iterations = 1000
     solver.hparams.source_location = keep_loc
+
+
+def test_training_with_stateless_levels():
+    """state_depth 2 of depth 4 (architectures.py:353): levels 2 and 3 carry no hidden state.  The blob holds their zero-padded stateful
+    equivalents; gradients of the real parameters match the oracle (float64, tanh, two unrolled iterations), the padding is masked out of the
+    optimiser, and the trained blob finds its way back into the module's smaller tensors."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.training import Trainer, trainable_mask
+    torch.manual_seed(11)
+    n, b, depth, sdepth = 32, 2, 4, 2
+    s = IterativeSolver(domain_size=n, k=1.0, omega=1, PMLsize=8, sigma_max=2, source_location=[10, 16], activation_function="tanh",
+                        depth=depth, state_depth=sdepth, batch_size=2, buffer_size=4, learning_rate=1e-3, minimum_learning_rate=1e-4, unrolling_steps=2)
+    with torch.no_grad():
+        for p in s.f.parameters():
+            if p.dim() == 4:
+                p.mul_(15.0)
+            else:
+                p.uniform_(-0.1, 0.1)
+    s.to(DEV)
+    eng = s.engine()
+    wts = {k: v.detach().cpu() for k, v in s.f.state_dict().items()}
+    assert "enc.2.conv_state.double_conv.0.weight" not in wts and wts["enc.2.conv_signal.double_conv.0.weight"].shape[1] == 8
+    ti = teacher_inputs(n, b, seed=78)
+    wf, res, sos = (torch.from_numpy(ti[k]) for k in ("wf", "res", "sos"))
+    bounds = np.cumsum([0] + [(n >> d) ** 2 for d in range(depth)])
+    st = 0.3 * torch.from_numpy(np.random.default_rng(6).standard_normal((b, 2, int(bounds[-1]))).astype(np.float32))
+    st[:, :, int(bounds[sdepth]):] = 0
+    k_sq = (1.0 / sos) ** 2
+    t = O.SpectralTables(n, 8, 2, 1.0, dtype=torch.float64)
+    src = O.point_source_map(n, [10, 16], 10.0)
+    w = {k: v.clone().double().requires_grad_(True) for k, v in wts.items()}
+    wf_, res_, st_ = (x.clone().double().requires_grad_(True) for x in (wf, res, st))
+    loss, *_ = O.training_loss(wf_, res_, st_, k_sq.double(), src.double(), w, t, 2, depth=depth, act="tanh", state_depth=sdepth)
+    loss.backward()
+    blob = torch.from_numpy(pack_weights(wts, depth, "tanh", state_depth=sdepth)).to(DEV)
+    out = eng.train_grad(blob, wf.to(DEV), res.to(DEV), st.to(DEV), k_sq.to(DEV).contiguous(), src.to(DEV).contiguous(), 2, 1e4, input_grads=True)
+    got = unpack_weights(out["grad"], depth)
+    errs = {}
+    for k, v in w.items():
+        g = torch.from_numpy(got[k])
+        if g.dim() == 4 and g.shape[1] != v.shape[1]:
+            g = g[:, : v.shape[1]]
+        errs[k] = rel(g, v.grad)
+    errs.update(grad_wf=rel(out["grad_wf"], wf_.grad), grad_res=rel(out["grad_res"], res_.grad))
+    a = int(bounds[sdepth])
+    errs["grad_states_stateful"] = rel(out["grad_states"][:, :, :a], st_.grad[:, :, :a])
+    assert float(out["grad_states"][:, :, a:].abs().max()) == 0.0
+    _report(errs, 2e-4)
+    mask = trainable_mask(depth, "tanh", sdepth)
+    assert mask.sum() == 48160 - 730 - 12          # 2 x (221 conv_state + 144 padded conv_signal inputs), the 12 constant slope slots of the other DoubleConvs
+    # a few optimiser steps: padding stays exactly zero, the module receives tensors of its own shapes
+    tr = Trainer(s)
+    zero_pad = (tr.trainable == 0) & (tr.weights == 0)
+    sos_maps = torch.from_numpy(ring_sos_batch(n, 4, seed=2))
+    tr.fill_replay_buffer(sos_maps)
+    for i in range(3):
+        tr.training_step(sos_maps[:2].to(DEV), i)
+    assert bool((tr.weights[zero_pad] == 0).all())
+    before = s.f.enc[2].conv_signal.double_conv[0].weight.detach().clone()
+    tr.training_epoch_end()
+    after = s.f.enc[2].conv_signal.double_conv[0].weight
+    assert after.shape == before.shape == (8, 8, 3, 3) and not torch.equal(after, before)
