@@ -374,6 +374,9 @@ def main():
             roof["flops_note"] = ("credited FLOPs are the reference layers' (conv 16->8, conv 8->8, 1x1 8->2: 228.6 MFLOP per sample at 256^2); the kernel "
                                   "executes ~0.85 of them (final 3x3 + 1x1 composed into one 2-channel 3x3, plus mid-tensor halo recompute)")
         # every level-0 kernel of the main chain: shortest event-bracketed launch of the warm-up pass against the fp32 peak
+        line["level0_kernels_note"] = ("shortest launch per kernel in the warm-up pass in which EVERY kernel is bracketed by an event pair: each figure carries "
+                                       "~5-8 us of event overhead (decode0: compare roofline.avg_launch_us, sampled in the timed region); rocprofv3 durations "
+                                       "are in profiles/r3_kernel_stats.csv")
         line["level0_kernels"] = [{"kernel": k, "us": round(pmin[k] * 1e3, 2), "tflops": round(2.0 * macs[k] * B / per_step / (pmin[k] * 1e-3) / 1e12, 1),
                                    "frac": round(2.0 * macs[k] * B / per_step / (pmin[k] * 1e-3) / 1e12 / PEAK_TFLOPS[prec], 4)}
                                   for k in ("inc", "conv_signal0", "down0", "up0", "decode0") if k in pmin and k in macs and pmin[k] > 0]
