@@ -188,17 +188,18 @@ def test_config3_shards_of_the_8_way_run(weights, rank):
     assert sos.shape == (32, 1, 256, 256) and torch.equal(sos, torch.from_numpy(ring_sos_batch(256, 32, seed=rank)))
     s = _solver()
     s.set_domain_size(256, source_location=[30, 128])
-    out = s.forward(sos[:2].to(DEV), num_iterations=40, residuals="norms")
-    want = O.solve(sos[:2], weights, O.point_source_map(256, [30, 128], 10.0), O.SpectralTables(256, 8, 2, 1.0), 40)
-    err = float((out["wavefields"][0].cpu() - want["wavefield"]).abs().max())
-    trace = torch.stack(want["trace"]).numpy()
-    terr = float(np.abs(out["residual_norms"].cpu().numpy() / trace - 1).max())
-    print(f"config3 rank {rank}: Linf(wf) after 40 it = {err:.3e} (|wf| max {float(want['wavefield'].abs().max()):.3f}), trace rel err {terr:.3e}")
-    # 40 iterations into the transient (|wf| ~ 2.7) two fp32 evaluations differ by ~1e-4 of the field's scale -- the CPU oracle
-    # itself moves by that much with its batch size (oneDNN blocking): 1.0e-4 / 3.4e-4 absolute against the same HIP run at B = 4 / 2
-    # (the reference's own fp32 run is 0.7 .. 8e-5 from its float64 run after 100 iterations): the bar is
-    # 2e-4 relative to the field's scale
-    assert err <= 2e-4 * max(1.0, float(want["wavefield"].abs().max())) and terr <= 2e-2, (err, terr)
+    if rank == 0:   # the CPU oracle is the slow part of this test: one shard is compared against it, both go through the property checks
+        out = s.forward(sos[:2].to(DEV), num_iterations=40, residuals="norms")
+        want = O.solve(sos[:2], weights, O.point_source_map(256, [30, 128], 10.0), O.SpectralTables(256, 8, 2, 1.0), 40)
+        err = float((out["wavefields"][0].cpu() - want["wavefield"]).abs().max())
+        trace = torch.stack(want["trace"]).numpy()
+        terr = float(np.abs(out["residual_norms"].cpu().numpy() / trace - 1).max())
+        print(f"config3 rank {rank}: Linf(wf) after 40 it = {err:.3e} (|wf| max {float(want['wavefield'].abs().max()):.3f}), trace rel err {terr:.3e}")
+        # 40 iterations into the transient (|wf| ~ 2.7) two fp32 evaluations differ by ~1e-4 of the field's scale -- the CPU oracle
+        # itself moves by that much with its batch size (oneDNN blocking): 1.0e-4 / 3.4e-4 absolute against the same HIP run at B = 4 / 2
+        # (the reference's own fp32 run is 0.7 .. 8e-5 from its float64 run after 100 iterations): the bar is
+        # 2e-4 relative to the field's scale
+        assert err <= 2e-4 * max(1.0, float(want["wavefield"].abs().max())) and terr <= 2e-2, (err, terr)
     full = s.forward(sos.to(DEV), num_iterations=1000, residuals="norms")
     wf = full["wavefields"][0]
     rm = full["residual_norms"].cpu().numpy()
