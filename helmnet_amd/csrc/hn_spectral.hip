@@ -849,8 +849,10 @@ struct PfaConst {
     float2 wp[P];       // exp(-2 pi i m / P); the output map k(k1, k2) is baked into the k tables on the host
 };
 
+// (launch bound: blocks are lines_per_block * Q / 4 <= 256 threads.  Without it the compiler assumes 1024 and caps the kernel at 128 VGPRs:
+// 24 spilled registers at P = 3, 227 at P = 5 -- r2 shipped that)
 template <int Q, int P, int AXIS, bool ADJ = false>
-__global__ void k_spec_pfa(const float* __restrict__ wf, float* out, const float* __restrict__ ksq,
+__global__ __launch_bounds__(256) void k_spec_pfa(const float* __restrict__ wf, float* out, const float* __restrict__ ksq,
                            const float* __restrict__ src, long src_sb, const float2* __restrict__ tw_q,
                            const float* __restrict__ k1p, const float* __restrict__ k2p, const float2* __restrict__ ca,
                            const float2* __restrict__ cb, PfaConst<P> pc, int lines_per_block, int flags,
