@@ -1104,9 +1104,9 @@ void launch_pow2(hn_ctx* ctx, const float* wf, float* out, const float* ksq, con
                        1 | (resid ? 2 : 0), sumsq, it_counter, sumsq_stride);
 }
 
-// n = P * Q with P in {3, 5} and Q a power of two (16 .. 512 for P = 3, 16 .. 256 for P = 5): returns P, else 0
+// n = P * Q with P in {3, 5, 7} and Q a power of two (16 .. 512 for P = 3, 16 .. 256 for P = 5, 7): returns P, else 0
 int pfa_factor(int n) {
-    for (int P : {3, 5}) {
+    for (int P : {3, 5, 7}) {
         if (n % P != 0) continue;
         const int Q = n / P;
         if (Q >= 16 && (Q & (Q - 1)) == 0 && Q <= (P == 3 ? 512 : 256)) return P;
@@ -1298,6 +1298,7 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
         switch (t.pfa_p * 1024 + t.pfa_q) {
             HN_PFA(16, 3) HN_PFA(32, 3) HN_PFA(64, 3) HN_PFA(128, 3) HN_PFA(256, 3) HN_PFA(512, 3)
             HN_PFA(16, 5) HN_PFA(32, 5) HN_PFA(64, 5) HN_PFA(128, 5) HN_PFA(256, 5)
+            HN_PFA(16, 7) HN_PFA(32, 7) HN_PFA(64, 7) HN_PFA(128, 7) HN_PFA(256, 7)
             default: return fail(ctx, HN_ERR_ARG, "internal: no prime-factor kernel for %d x %d", t.pfa_p, t.pfa_q);
         }
 #undef HN_PFA
@@ -1333,6 +1334,7 @@ int spec_adjoint(hn_ctx* ctx, const float* g, float* out, const float* ksq, cons
         switch (t.pfa_p * 1024 + t.pfa_q) {
             HN_PFA(16, 3) HN_PFA(32, 3) HN_PFA(64, 3) HN_PFA(128, 3) HN_PFA(256, 3) HN_PFA(512, 3)
             HN_PFA(16, 5) HN_PFA(32, 5) HN_PFA(64, 5) HN_PFA(128, 5) HN_PFA(256, 5)
+            HN_PFA(16, 7) HN_PFA(32, 7) HN_PFA(64, 7) HN_PFA(128, 7) HN_PFA(256, 7)
             default: return fail(ctx, HN_ERR_ARG, "internal: no prime-factor kernel for %d x %d", t.pfa_p, t.pfa_q);
         }
 #undef HN_PFA

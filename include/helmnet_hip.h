@@ -72,7 +72,7 @@ enum hn_option {
     HN_OPT_GRAPH = 2,        /* 0: launch every kernel (default; measured faster); 1: replay one captured iteration per HIP graph
                               * launch; even n <= 64: n iterations per graph                                          */
     HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
-    HN_OPT_SPECTRAL_PFA = 4, /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k instead of the dense n x n operator (default 1;
+    HN_OPT_SPECTRAL_PFA = 4, /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k, 7 * 2^k instead of the dense n x n operator (default 1;
                               * read by the next hn_set_domain)                                                     */
     HN_OPT_SPECTRAL_RADIX16 = 5, /* 256-point lines: 0 the radix-4 kernels, 1 radix-16 columns + 8x4x8 rows (default), 2 radix-16 rows too */
     HN_OPT_DC_VALU = 6,      /* fp32 DoubleConvs of the largest level (W >= 256) on the packed vector FMA (every FMA useful, same peak as the

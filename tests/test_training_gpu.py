@@ -38,9 +38,9 @@ def rel(got, want):
     return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
 
 
-@pytest.mark.parametrize("n", [32, 64, 96, 112, 160, 256])
+@pytest.mark.parametrize("n", [32, 64, 96, 112, 160, 176, 256])
 def test_residual_vjp_is_the_adjoint_of_the_residual(solver, n):
-    """pow2 radix-4 (32, 64, 256), prime-factor (96 = 3 * 32, 160 = 5 * 32) and dense (112) paths."""
+    """pow2 radix-4 (32, 64, 256), prime-factor (96 = 3 * 32, 160 = 5 * 32, 112 = 7 * 16) and dense (176 = 11 * 16) paths."""
     solver.set_domain_size(n, source_location=[n // 3, n // 2])
     eng = solver.engine()
     ti = teacher_inputs(n, 2, seed=77 + n)
