@@ -230,7 +230,8 @@ enum KernelId : int {
     KID_SPEC_COLS = 32,   // spectral column pass
     KID_SPEC_ROWS = 33,   // spectral row pass + residual terms (or the dense operator)
     KID_DEEP = 34,        // deepest level in one per-sample kernel: conv_signal, conv_state, down, bottleneck, up, decoder
-    KID_COUNT = 35
+    KID_SPEC_PAIR = 35,   // one bracket around both spectral passes (the HBM-bound part of the path as a whole)
+    KID_COUNT = 36
 };
 
 // RAII event pair around one launch when that kernel id is selected by hn_profile_enable.

@@ -1254,6 +1254,7 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
     const bool resid = ksq != nullptr;
     const long plane = (long)t.n * t.n;
     const long src_sb = (src_batch == 1) ? 0 : 2 * plane;
+    ProfScope pair(ctx, KID_SPEC_PAIR, s);   // both passes under one event pair (when selected)
     if (t.pow2) {
         const SpecPtrs p{t.tw, t.k1, t.k2, t.a, t.b};
         switch (t.n) {

@@ -400,7 +400,7 @@ class Engine:
         return out
 
     # ---- measurement hooks ---------------------------------------------------------------
-    KERNEL_IDS = 35
+    KERNEL_IDS = 36
 
     @staticmethod
     def kernel_name(kid: int) -> str:
@@ -412,7 +412,7 @@ class Engine:
             return "bottleneck"
         if 20 <= kid <= 31:
             return ("up", "decode")[(kid - 20) % 2] + str((kid - 20) // 2)
-        return {32: "spectral_cols", 33: "spectral_rows", 34: "deep"}[kid]
+        return {32: "spectral_cols", 33: "spectral_rows", 34: "deep", 35: "spectral_pair"}[kid]
 
     def profile_enable(self, kernel_ids=None):
         """Bracket the selected kernels (None = all, [] = none) with HIP events on the launch stream."""

@@ -239,10 +239,10 @@ int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_
  *   20+2d up(d) | 21+2d decoder(d) (d=0 includes outc + wavefield update) |
  *   32 spectral column pass | 33 spectral row pass (or the dense operator) |
  *   34 the fused deepest level (conv_signal, conv_state, down, bottleneck, up, decoder of level depth-1 in one kernel;
- *      those six ids then do not occur).
+ *      those six ids then do not occur) | 35 both spectral passes under ONE event pair.
  * hn_profile_collect synchronises the recorded events, returns per-id total milliseconds and
  * launch counts for ids [0, n_ids) and resets the accumulators. */
-#define HN_KERNEL_IDS 35
+#define HN_KERNEL_IDS 36
 int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
 /* Bracket only every `every_nth` launch of a selected kernel (default 1), starting every_nth / 2 launches in.  An event pair
  * costs a few microseconds of stream gap, so timed runs sample instead of bracketing every launch. */
