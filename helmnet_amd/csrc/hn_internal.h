@@ -135,7 +135,7 @@ struct hn_ctx {
     int opt_pfa = 1;           // prime-factor FFT for n = 3 * 2^k, 5 * 2^k (0: dense operator, A/B; takes effect at hn_set_domain)
     int opt_radix16 = 1;       // 256-point transforms as two register-resident radix-16 passes (0: the radix-4 Stockham kernels)
     int opt_cols_t = 1;        // 256-point column pass through an LDS transpose: 0 the r2 kernel (16-byte global accesses), 1: 16 columns per block, 2: 32
-    bool cols_t_attr_set = false;
+    bool cols_t_attr_set = false, cols512_attr_set = false;
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     int opt_dc_valu = 1;       // fp32 DoubleConvs of the big levels on the packed vector FMA (hn_dcv.hip): 0 none, 1 inc + decoder, 2 all
     const float* outc_w = nullptr;  // [8][2]

@@ -674,6 +674,207 @@ __global__ __launch_bounds__(256, 4) void k_spec8_rows(const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// N = 512 = 8 x 8 x 8 on 64 threads x 8 elements per line (r3): the 256-point scheme above with one more factor of 2 in the
+// middle stage, one wavefront per line.  x[t + 64 k] --DFT8 over k--> A_t[q] x W_512^(t q) --exchange--> thread (a = t % 8, q):
+// DFT8 over b of A_(a + 8 b)[q] --> B_a[c][q] x W_64^(a c) --exchange--> thread u = q + 8 c: DFT8 over a --> X[u + 64 d]: the
+// layout of the input.  Both exchanges stay inside the wavefront that owns the line (wave-level fences, no workgroup barrier).
+// The radix-4 Stockham kernels this replaces at 512^2 run 5 exchange rounds per transform on 128 threads per line and address
+// global memory in 32-byte pieces in the column pass.
+// ------------------------------------------------------------------------------------------
+constexpr int kF1 = 72;            // exchange 1: slot q * 72 + t; reads a + 8 b of row q: the two rows of a 16-lane group sit 144 = 16 (mod 64) dwords apart
+constexpr int kF2 = 9;             // exchange 2: slot (q + 8 c) * 9 + a (stride 18 dwords: conflict-free)
+constexpr int kReg512 = 8 * kF1;   // float2 per transform region (= 64 * kF2)
+
+struct Tw512 {
+    v2 w512[8], w64[8];
+    __device__ __forceinline__ void load(int t, const float2* __restrict__ tw) {
+#pragma unroll
+        for (int q = 1; q < 8; ++q) { const float2 f = tw[t * q]; w512[q] = (v2){f.x, f.y}; }
+#pragma unroll
+        for (int c = 1; c < 8; ++c) { const float2 f = tw[8 * (t & 7) * c]; w64[c] = (v2){f.x, f.y}; }
+    }
+};
+
+// NB lock-step transforms of one line held by 64 threads x 8 elements; v[nb][k] = x[t + 64 k] in, X[t + 64 k] out
+template <bool INV, int NB>
+__device__ __forceinline__ void fft512_t64(v2 (&v)[NB][8], v2* reg, int nbs, int t, const Tw512& tw) {
+    const int a = t & 7, q = t >> 3;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        dft8<INV>(v[nb]);
+#pragma unroll
+        for (int i = 1; i < 8; ++i) v[nb][i] = INV ? cmulv_conj(v[nb][i], tw.w512[i]) : cmulv(v[nb][i], tw.w512[i]);
+    }
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) reg[nb * nbs + i * kF1 + t] = v[nb][i];
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) v[nb][b] = reg[nb * nbs + q * kF1 + a + 8 * b];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        dft8<INV>(v[nb]);   // index b -> c
+#pragma unroll
+        for (int c = 1; c < 8; ++c) v[nb][c] = INV ? cmulv_conj(v[nb][c], tw.w64[c]) : cmulv(v[nb][c], tw.w64[c]);
+    }
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) reg[nb * nbs + (q + 8 * c) * kF2 + a] = v[nb][c];
+    exchange_sync<true>();
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[nb][k] = reg[nb * nbs + t * kF2 + k];   // thread t = q + 8 c reads a = 0 .. 7
+        dft8<INV>(v[nb]);
+    }
+}
+
+// forward transform, derivative multipliers, two inverse transforms, PML coefficients of one 512-point line: u[k] = x[t + 64 k] in,
+// acc[k] = (a du + b ddu)[t + 64 k] out
+__device__ __forceinline__ void axis512(const v2 (&u)[8], v2 (&acc)[8], v2* reg, int t, const Tw512& tw, const SpecPtrs& tab) {
+    v2 f[1][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[0][k] = u[k];
+    fft512_t64<false, 1>(f, reg, kReg512, t, tw);
+    v2 d[2][8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+        const float k1 = tab.k1[t + 64 * p], k2 = tab.k2[t + 64 * p];
+        const v2 U = f[0][p];
+        d[0][p] = (v2){-U.y, U.x} * k1;   // (0, k) * U     (spectral.py:50, 281)
+        d[1][p] = U * k2;                 // (-k^2, 0) * U  (spectral.py:52, 283)
+    }
+    fft512_t64<true, 2>(d, reg, kReg512, t, tw);
+    constexpr float inv_n = 1.0f / 512.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float2 ca = tab.a[t + 64 * k], cb = tab.b[t + 64 * k];
+        acc[k] = (cmulv(d[0][k], (v2){ca.x, ca.y}) + cmulv(d[1][k], (v2){cb.x, cb.y})) * inv_n;
+    }
+}
+
+// row pass at N = 512: workgroup = 8 rows, one wavefront per row.  (With 4 rows per workgroup the 128 workgroups of a sample each add their sum
+// of squares to ONE address: same-address float atomics are serialised at the memory side, and in the solver loop -- where the RMSE
+// history is on -- the kernel took 55 us instead of the 35 us it takes alone.  64 per sample, as the radix-4 kernel has, are hidden.)
+__global__ __launch_bounds__(512, 2) void k_spec512_rows(const float* __restrict__ wf, float* __restrict__ out, const float* __restrict__ ksq,
+                                                       const float* __restrict__ src, long src_sb, SpecPtrs tab, int flags,
+                                                       float* __restrict__ sumsq, const int* __restrict__ it_counter, int sumsq_stride) {
+    constexpr int N = 512;
+    __shared__ v2 buf[8 * 2 * kReg512];
+    __shared__ float red[8];
+    const int t = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const TileId tl = xcd_tile();
+    const int row = tl.x * 8 + wave, b = tl.y;
+    const long plane = (long)N * N, ro = (long)row * N;
+    const float* pre = wf + (long)b * 2 * plane + ro;
+    float* po = out + (long)b * 2 * plane + ro;
+    v2 acc[8];
+    {
+        v2 u[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = (v2){pre[t + 64 * k], pre[plane + t + 64 * k]};
+        Tw512 tw;
+        tw.load(t, tab.tw);
+        axis512(u, acc, buf + wave * 2 * kReg512, t, tw, tab);
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int x = t + 64 * k;
+        v2 o = acc[k];
+        if (flags & 1) o = o + (v2){po[x], po[plane + x]};
+        if (flags & 2) {
+            // the line itself is read again here (an L2 hit) instead of being held through the transforms: 16 registers, which at
+            // 128 VGPRs (four wavefronts per SIMD) would otherwise be spilled
+            const v2 uk = (v2){pre[x], pre[plane + x]};
+            const float kq = ksq[(long)b * plane + ro + x];
+            o = o + uk * kq;
+            if (src != nullptr) {
+                const float* ps = src + (long)b * src_sb + ro + x;
+                o = o - (v2){ps[0], ps[plane]};
+            }
+        }
+        po[x] = o.x;
+        po[plane + x] = o.y;
+        ss += o.x * o.x + o.y * o.y;
+    }
+    if (sumsq != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) ss += __shfl_down(ss, o, 64);
+        if (t == 0) red[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long hist_row = it_counter != nullptr ? (long)(*it_counter - 1) * sumsq_stride : 0;
+            atomicAdd(&sumsq[hist_row + b], ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])));
+        }
+    }
+}
+
+// column pass at N = 512, coalesced through an LDS transpose like k_spec16_cols_t: a workgroup owns 16 columns x all 512 rows of a
+// sample (16 wavefronts, one per column); column c lives at cbuf + c * kCols512P: its 512 inputs first, then the 2 x 576 float2 of
+// the lock-step inverse exchange, finally its 512 outputs.  8 * 1153 = 8 (mod 64) dwords: the four float4 segments of a row land
+// on disjoint banks in the transposed writes and reads.
+constexpr int kCols512P = 1153;
+
+__global__ __launch_bounds__(1024) void k_spec512_cols_t(const float* __restrict__ wf, float* __restrict__ out, SpecPtrs tab,
+                                                        int* __restrict__ it_counter) {
+    constexpr int N = 512, COLS = 16, NT = 1024, P = kCols512P, SEG = COLS / 4, RPP = NT / SEG, NP = N / RPP;
+    extern __shared__ v2 cbuf512[];   // [COLS][P]
+    const int tid = threadIdx.x, t = tid & 63, wave = tid >> 6;
+    if (it_counter != nullptr && (blockIdx.x | blockIdx.y | tid) == 0) atomicAdd(it_counter, 1);
+    const TileId tl = xcd_tile();
+    const long plane = (long)N * N;
+    const int seg = tid % SEG, rr = tid / SEG;
+    const float* pre = wf + (long)tl.y * 2 * plane + tl.x * COLS + 4 * seg;
+    Tw512 tw;
+    tw.load(t, tab.tw);
+    {
+        float4 re[NP], im[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            const long o = (long)(rr + RPP * i) * N;
+            re[i] = *reinterpret_cast<const float4*>(pre + o);
+            im[i] = *reinterpret_cast<const float4*>(pre + o + plane);
+        }
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            v2* q = cbuf512 + (4 * seg) * P + rr + RPP * i;
+            q[0] = (v2){re[i].x, im[i].x};
+            q[P] = (v2){re[i].y, im[i].y};
+            q[2 * P] = (v2){re[i].z, im[i].z};
+            q[3 * P] = (v2){re[i].w, im[i].w};
+        }
+    }
+    __syncthreads();
+    {
+        v2* reg = cbuf512 + wave * P;
+        v2 u[8], acc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) u[k] = reg[t + 64 * k];
+        axis512(u, acc, reg, t, tw, tab);   // the first exchange overwrites the column's region: every lane of the wavefront has read its inputs
+        exchange_sync<true>();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) reg[t + 64 * k] = acc[k];
+    }
+    __syncthreads();
+    float* po = out + (long)tl.y * 2 * plane + tl.x * COLS + 4 * seg;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const v2* q = cbuf512 + (4 * seg) * P + rr + RPP * i;
+        const v2 a = q[0], b = q[P], c = q[2 * P], d4 = q[3 * P];
+        const long o = (long)(rr + RPP * i) * N;
+        *reinterpret_cast<float4*>(po + o) = make_float4(a.x, b.x, c.x, d4.x);
+        *reinterpret_cast<float4*>(po + o + plane) = make_float4(a.y, b.y, c.y, d4.y);
+    }
+}
+
 constexpr int kReg16Rows = 272;   // float2 per transform region: 16 x 17; 544 dwords = 32 (mod 64): the two transforms of a 32-lane group on disjoint banks
 constexpr int kReg16Cols = 280;   // 560 dwords = 48 (mod 64): the four transforms of a 32-lane group (lane = 4 t + c) on disjoint quarters
 
@@ -1288,7 +1489,23 @@ int spec_apply(hn_ctx* ctx, const float* wf, float* out, const float* ksq, const
                     launch_pow2<256>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride);
                 }
                 break;
-            case 512: launch_pow2<512>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
+            case 512:
+                if (ctx->opt_radix16) {   // 8 x 8 x 8 register-resident passes, column pass through an LDS transpose (r3)
+                    if (!ctx->cols512_attr_set) {
+                        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec512_cols_t), hipFuncAttributeMaxDynamicSharedMemorySize, 16 * kCols512P * 8));
+                        ctx->cols512_attr_set = true;
+                    }
+                    {
+                        ProfScope ps(ctx, KID_SPEC_COLS, s);
+                        hipLaunchKernelGGL(k_spec512_cols_t, dim3(32, batch), dim3(1024), 16 * kCols512P * 8, s, wf, out, p, it_counter);
+                    }
+                    ProfScope ps(ctx, KID_SPEC_ROWS, s);
+                    hipLaunchKernelGGL(k_spec512_rows, dim3(64, batch), dim3(512), 0, s, wf, out, ksq, src, src_sb, p, 1 | (resid ? 2 : 0), accum_sumsq,
+                                       it_counter, sumsq_stride);
+                } else {
+                    launch_pow2<512>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride);
+                }
+                break;
             case 1024: launch_pow2<1024>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             case 2048: launch_pow2<2048>(ctx, wf, out, ksq, src, src_sb, batch, p, resid, accum_sumsq, s, it_counter, sumsq_stride); break;
             default: return fail(ctx, HN_ERR_ARG, "unsupported power-of-two size %d", t.n);
