@@ -182,7 +182,8 @@ struct hn_ctx {
                o_u[hn::kMaxDepth]{}, o_zdec[hn::kMaxDepth + 1]{}, o_y[hn::kMaxDepth + 1]{};
         float* gbuf = nullptr;       // gradient buffers, carved below
         float *g_x[hn::kMaxDepth + 1]{}, *g_out[hn::kMaxDepth]{}, *g_u[hn::kMaxDepth]{}, *g_y[hn::kMaxDepth + 1]{};
-        float *gz = nullptr, *tmp8 = nullptr, *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
+        float *gz[3 * hn::kMaxDepth + 2]{};   // gradient of every DoubleConv's mid tensor (it feeds conv1's weight gradient at the end of the iteration)
+        float *tmp8 = nullptr, *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
         float* part = nullptr;       // [640 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
         size_t part_floats = 0;
         double* slope_part = nullptr; // [3 depth + 2 DoubleConvs][slope_stride]: per-block sums of the PReLU-slope gradients (float64)
@@ -191,6 +192,12 @@ struct hn_ctx {
         float* k8 = nullptr;         // 8x8 weights as fp32 matrix-core fragments: [depth][4][4096]
         float* zero8 = nullptr;      // 8 zeros (bias of the backward-data convolutions)
         float* sumsq = nullptr;      // [n_unroll][batch] per-sample sum of squared residuals
+        // job tables of the batched weight-gradient launches: one region per unrolled iteration, filled on the host (pinned), copied
+        // behind the iteration's backward-data chain, read by the three launches that follow the copy
+        unsigned char *jobs_host = nullptr, *jobs_dev = nullptr;
+        size_t jobs_region = 0;      // bytes per iteration
+        hipEvent_t jobs_copied = nullptr;   // the last call's last copy (the host side is not rewritten before it has happened)
+        bool jobs_in_flight = false;
     } tr;
     // optional per-kernel timing with HIP events on the caller's stream (hn_profile_*)
     uint64_t prof_mask = 0;

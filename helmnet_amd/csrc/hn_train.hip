@@ -25,6 +25,8 @@
 //   * The spectral operator is linear: its backward is the adjoint pass spec_adjoint (hn_spectral.hip).
 //   * Everything is enqueued on the caller's stream; nothing synchronises with the host (except when the workspace has to grow).
 #include <cmath>
+#include <cstring>
+#include <vector>
 
 #include "hn_internal.h"
 
@@ -112,12 +114,22 @@ struct WindowStager {
     }
     // channels [0, nch) of the concatenation src[0..2]; `slope` / `act_kind` for groups staged through the activation
     __device__ __forceinline__ void stage(const TSrc (&src)[3], int nch, int b, float* dst, int cstride, int act_kind, float slope) const {
+        // the three groups' fields as plain values (statically indexed reads, once): a job-table copy of `src` then lives in registers --
+        // selecting among src[k].field inside the loop is turned back into an indexed access of the struct in scratch memory
+        const float *p0 = src[0].p, *p1 = src[1].p, *p2 = src[2].p;
+        const long sb0 = src[0].sb, sb1 = src[1].sb, sb2 = src[2].sb, sc0 = src[0].sc, sc1 = src[1].sc, sc2 = src[2].sc;
+        const float f0 = src[0].scale, f1 = src[1].scale, f2 = src[2].scale;
+        const int a0 = src[0].act, a1 = src[1].act, a2 = src[2].act;
+        const int n0 = src[0].nch, n01 = n0 + src[1].nch;
 #pragma unroll 8
         for (int c = 0; c < nch; ++c) {
-            int cs = c, si = 0;
-            if (cs >= src[0].nch) { cs -= src[0].nch; si = 1; if (cs >= src[1].nch) { cs -= src[1].nch; si = 2; } }
-            const TSrc& sr = src[si];
-            const float* p = sr.p + (long)b * sr.sb + (long)cs * sr.sc;
+            const bool g1 = c >= n0, g2 = c >= n01;
+            const int cs = g2 ? c - n01 : g1 ? c - n0 : c;
+            const float* sp = g2 ? p2 : g1 ? p1 : p0;
+            const long ssb = g2 ? sb2 : g1 ? sb1 : sb0, ssc = g2 ? sc2 : g1 ? sc1 : sc0;
+            const float sscale = g2 ? f2 : g1 ? f1 : f0;
+            const int sact = g2 ? a2 : g1 ? a1 : a0;
+            const float* p = sp + (long)b * ssb + (long)cs * ssc;
             float v[NE];
 #pragma unroll
             for (int i = 0; i < NE; ++i) v[i] = p[goff[i]];
@@ -125,8 +137,8 @@ struct WindowStager {
             for (int i = 0; i < NE; ++i)
                 if (inmask >> i & 1u) {
                     float x = v[i];
-                    if (sr.act) x = act_fwd(x, act_kind, slope);
-                    dst[c * cstride + lidx[i]] = (okmask >> i & 1u) ? x * sr.scale : 0.f;
+                    if (sact) x = act_fwd(x, act_kind, slope);
+                    dst[c * cstride + lidx[i]] = (okmask >> i & 1u) ? x * sscale : 0.f;
                 }
         }
     }
@@ -135,6 +147,31 @@ struct WindowStager {
 // Wave-uniform reads through the constant address space become scalar loads (SGPR operands of the FMAs).
 typedef const float __attribute__((address_space(4))) * CfPtr;
 __device__ __forceinline__ CfPtr cf(const float* p) { return (CfPtr)(uintptr_t)p; }
+
+// Entry `j` of a job table, read word by word through the constant address space: the index is the same for the whole block, so
+// the struct arrives in SGPRs and everything derived from it (loop bounds, base pointers) stays wave-uniform.
+typedef const unsigned __attribute__((address_space(4))) * CuPtr;
+template <class T>
+__device__ __forceinline__ T load_job(const T* table, int j) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    const CuPtr q = (CuPtr)(uintptr_t)(table + j);
+    T t;
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; ++i) {
+        const unsigned w = q[i];
+        __builtin_memcpy(reinterpret_cast<char*>(&t) + 4 * i, &w, 4);
+    }
+    return t;
+}
+// Batched launches: the jobs of one launch own consecutive runs of blocks [blk0, blk0 + nblk); `first` = &table[0].blk0.
+template <class T>
+__device__ __forceinline__ int find_job(const T* table, int njobs, int block) {
+    const CuPtr q = (CuPtr)(uintptr_t)&table[0].blk0;
+    constexpr int stride = sizeof(T) / 4;
+    int j = 0;
+    while (j + 1 < njobs && block >= (int)q[(j + 1) * stride]) ++j;
+    return j;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // 3x3 convolution, padding 1, any (cin <= 16) -> CO channels, direct fp32 on the vector ALU.
@@ -248,11 +285,14 @@ struct Wg3Args {
     const float* slope;
     float* part;        // &table[0][column of this layer's weight]
     long row_stride;    // floats between the rows of the table
+    int blk0, nblk;     // this job's run of blocks within the batched launch
 };
 
 constexpr int kWgTH = 16;  // tile rows of the weight-gradient kernel (8-row tiles, twice the blocks: measured the same, r3)
 template <int CO>
-__global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
+__global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__ jobs, int njobs) {
+    const Wg3Args a = load_job(jobs, find_job(jobs, njobs, (int)blockIdx.x));
+    const int bid = (int)blockIdx.x - a.blk0;
     constexpr int TH = kWgTH, TW = 32, IR = TH + 2, IC = TW + 2, PI = 35;
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // gradient tile [TH][TW][CO], then the input window [CI][IR][PI] (>= 256 * 3 * CO floats)
     float* const s_g = s_dyn;
@@ -270,7 +310,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) acc[k][c] = 0.f;
     const int ntiles = a.tiles_x * a.tiles_y * a.batch;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = bid; tile < ntiles; tile += a.nblk) {
         const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, b = r0 / a.tiles_y;
         const int x0 = tx * TW, y0 = ty * TH;
         __syncthreads();
@@ -331,7 +371,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(Wg3Args a) {
     // every thread sums the row subsets (fixed order) of a few cells of the block's table row and adds them to it: consecutive
     // threads own consecutive cells, so the read-modify-write is coalesced (a cell belongs to this block alone within a launch;
     // one thread per tap row doing all of it serially was a third of the kernel's fixed cost, scattered 4-byte atomics another)
-    float* row = a.part + (size_t)blockIdx.x * a.row_stride;
+    float* row = a.part + (size_t)bid * a.row_stride;
     for (int i = tid; i < CO * CI * 9 + CO; i += 256) {
         int o, p, k;
         if (i >= CO * CI * 9) { o = i - CO * CI * 9; p = P - 1; k = 0; }
@@ -356,9 +396,14 @@ struct Wg8Args {
     float* part;
     long row_stride;
     int bias_from_big;   // the bias gradient (per-channel sum of the OUTPUT gradient) behind the weight in the blob: 0 sum of sm (down), 1 sum of bg (up)
+    int blk0, nblk;      // this job's run of blocks within the batched launch
+    int pad_;
 };
+static_assert(sizeof(Wg8Args) % 4 == 0 && sizeof(Wg3Args) % 4 == 0, "job tables are read dword by dword");
 
-__global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
+__global__ __launch_bounds__(512) void k_conv8_wgrad(const Wg8Args* __restrict__ jobs, int njobs) {
+    const Wg8Args a = load_job(jobs, find_job(jobs, njobs, (int)blockIdx.x));
+    const int bid = (int)blockIdx.x - a.blk0;
     constexpr int TY = 8, TX = 16, BR = 2 * TY + 6, BC = 2 * TX + 6, PB = 39;
     __shared__ float s_b[kFeat * BR * PB];
     __shared__ __attribute__((aligned(16))) float s_s[TY * TX * kFeat];
@@ -369,7 +414,7 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
 #pragma unroll
     for (int c = 0; c < kFeat; ++c) acc[c] = bsum[c] = 0.f;
     const int ntiles = a.tiles_x * a.tiles_y * a.batch;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int tile = bid; tile < ntiles; tile += a.nblk) {
         const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, n = r0 / a.tiles_y;
         const int X0 = tx * TX, Y0 = ty * TY;
         __syncthreads();
@@ -416,7 +461,7 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(Wg8Args a) {
             for (int c = 0; c < kFeat; ++c) bsum[c] += s_s[tid * kFeat + c];
         }
     }
-    float* row = a.part + (size_t)blockIdx.x * a.row_stride;
+    float* row = a.part + (size_t)bid * a.row_stride;
 #pragma unroll
     for (int c = 0; c < kFeat; ++c) unsafeAtomicAdd(&row[(c * kFeat + bch) * 64 + k], acc[c]);
     // per-channel sums over the block (fixed order: wave shuffles, then the 8 wave partials), behind the 4096 weights
@@ -646,6 +691,13 @@ struct Trainer {
         const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
         return conv_fwd(mid, dc.w2, dc.b2, dc.co, dc.slope, out, d);
     }
+    // Weight gradients are not on the backward chain: every call below only files a job; flush_wgrads() at the end of the
+    // iteration runs them as three launches (3x3 with 8 / with 2 output channels, 8x8) whose grids are the concatenation of the
+    // jobs' block runs.  (One launch per layer -- 36 per iteration -- cost 6.2 of the 16.4 ms of a step at 96^2 x 32: at the small
+    // levels a launch is 1-2 tiles per block on a fraction of the chip.)
+    std::vector<Wg3Args> jobs8, jobs2;
+    std::vector<Wg8Args> jobsk;
+    size_t lds8 = 0, lds2 = 0;
     int wgrad3(const TSrc (&in)[3], TSrc g, int co, size_t grad_off, int d, size_t slope_off) {
         Wg3Args a{};
         for (int i = 0; i < 3; ++i) a.src[i] = in[i];
@@ -655,19 +707,45 @@ struct Trainer {
         a.act_kind = act; a.slope = w + slope_off;
         a.part = table(grad_off); a.row_stride = (long)L.total;
         const int ntiles = a.tiles_x * a.tiles_y * B;
-        const int blocks = ntiles < kPartRows ? ntiles : kPartRows;
+        a.nblk = ntiles < kPartRows ? ntiles : kPartRows;
         const int ci = in[0].nch + in[1].nch + in[2].nch;
         size_t lds_x = (size_t)ci * (kWgTH + 2) * 35;                     // input window; doubles as the reduction scratch (256 * 3 * CO floats)
         if (lds_x < (size_t)256 * 3 * co) lds_x = (size_t)256 * 3 * co;
         const size_t lds = sizeof(float) * ((size_t)kWgTH * 32 * co + lds_x);
-        if (co == 8) hipLaunchKernelGGL(k_conv3_wgrad<8>, dim3(blocks), dim3(256), lds, s, a);
-        else if (co == 2) hipLaunchKernelGGL(k_conv3_wgrad<2>, dim3(blocks), dim3(256), lds, s, a);
+        if (co == 8) { jobs8.push_back(a); if (lds > lds8) lds8 = lds; }
+        else if (co == 2) { jobs2.push_back(a); if (lds > lds2) lds2 = lds; }
         else return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no weight-gradient kernel for %d output channels", co);
+        return HN_OK;
+    }
+    template <class J>
+    static int number_blocks(std::vector<J>& jobs) {
+        int total = 0;
+        for (J& j : jobs) { j.blk0 = total; total += j.nblk; }
+        return total;
+    }
+    // the jobs filed during the backward pass of iteration t: table -> device (stream-ordered copy out of this iteration's own
+    // region of the pinned buffer), then the three launches
+    int flush_wgrads(int t) {
+        auto& W = T();
+        const size_t b8 = jobs8.size() * sizeof(Wg3Args), b2 = jobs2.size() * sizeof(Wg3Args), bk = jobsk.size() * sizeof(Wg8Args);
+        if (b8 + b2 + bk > W.jobs_region) return fail(ctx, HN_ERR_STATE, "internal: weight-gradient job table overflow (%zu > %zu bytes)", b8 + b2 + bk, W.jobs_region);
+        const int n8 = number_blocks(jobs8), n2 = number_blocks(jobs2), nk = number_blocks(jobsk);
+        unsigned char* h = W.jobs_host + (size_t)t * W.jobs_region;
+        unsigned char* dv = W.jobs_dev + (size_t)t * W.jobs_region;
+        if (b8) std::memcpy(h, jobs8.data(), b8);
+        if (b2) std::memcpy(h + b8, jobs2.data(), b2);
+        if (bk) std::memcpy(h + b8 + b2, jobsk.data(), bk);
+        HN_HIP(ctx, hipMemcpyAsync(dv, h, b8 + b2 + bk, hipMemcpyHostToDevice, s));
+        if (n8) hipLaunchKernelGGL(k_conv3_wgrad<8>, dim3(n8), dim3(256), lds8, s, reinterpret_cast<const Wg3Args*>(dv), (int)jobs8.size());
+        if (n2) hipLaunchKernelGGL(k_conv3_wgrad<2>, dim3(n2), dim3(256), lds2, s, reinterpret_cast<const Wg3Args*>(dv + b8), (int)jobs2.size());
+        if (nk) hipLaunchKernelGGL(k_conv8_wgrad, dim3(nk), dim3(512), 0, s, reinterpret_cast<const Wg8Args*>(dv + b8 + b2), (int)jobsk.size());
+        jobs8.clear(); jobs2.clear(); jobsk.clear();
         return HN_OK;
     }
     // DoubleConv backward: g_out (co channels) -> weight gradients, gradients of the inputs into `gin` (channel groups of the concatenation)
     int dc_bwd(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
         int rc;
+        float* const gz = T().gz[slot];   // its own buffer per DoubleConv: the filed weight-gradient job reads it at the end of the iteration
         {   // conv2: dW2, db2 from (act(z), g_out)
             const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
             if ((rc = wgrad3(mid, g_out, dc.co, dc.w2, d, dc.slope)) != HN_OK) return rc;
@@ -675,7 +753,7 @@ struct Trainer {
         {   // g_z = conv2^T(g_out) * act'(z);  d slope
             Conv3Args a{};
             a.src[0] = g_out; a.src[1] = nosrc(); a.src[2] = nosrc();
-            a.dst[0] = featdst(T().gz, d, dc.cm); a.dst[1] = nodst(); a.dst[2] = nodst();
+            a.dst[0] = featdst(gz, d, dc.cm); a.dst[1] = nodst(); a.dst[2] = nodst();
             a.wpk = wbwd(dc.w2); a.bias = nullptr;
             a.H = a.W = side(d);
             a.act_kind = act; a.slope = w + dc.slope;
@@ -684,10 +762,10 @@ struct Trainer {
             if ((rc = launch_conv3(ctx, dc.cm, true, a, B, s)) != HN_OK) return rc;
         }
         // conv1: dW1, db1 from (in, g_z)
-        if ((rc = wgrad3(in, feat(T().gz, d, dc.cm), dc.cm, dc.w1, d, dc.slope)) != HN_OK) return rc;
+        if ((rc = wgrad3(in, feat(gz, d, dc.cm), dc.cm, dc.w1, d, dc.slope)) != HN_OK) return rc;
         {   // g_in = conv1^T(g_z)
             Conv3Args a{};
-            a.src[0] = feat(T().gz, d, dc.cm); a.src[1] = nosrc(); a.src[2] = nosrc();
+            a.src[0] = feat(gz, d, dc.cm); a.src[1] = nosrc(); a.src[2] = nosrc();
             for (int i = 0; i < 3; ++i) a.dst[i] = gin[i];
             a.wpk = wbwd(dc.w1); a.bias = nullptr;
             a.H = a.W = side(d);
@@ -710,7 +788,8 @@ struct Trainer {
         a.tiles_x = cdiv(a.ws, 16); a.tiles_y = cdiv(a.hs, 8); a.batch = B;
         a.part = table(grad_off); a.row_stride = (long)L.total;
         const int ntiles = a.tiles_x * a.tiles_y * B;
-        hipLaunchKernelGGL(k_conv8_wgrad, dim3(ntiles < kPartRows ? ntiles : kPartRows), dim3(512), 0, s, a);
+        a.nblk = ntiles < kPartRows ? ntiles : kPartRows;
+        jobsk.push_back(a);
     }
     // one unrolled iteration, forward (hybridnet.py:558-584), filling step t of the tape
     int forward_step(int t, const float* wf, const float* res, const float* st_in, float* wf_next, float* res_next, float* st_next,
@@ -798,6 +877,7 @@ struct Trainer {
             if ((rc = dc_bwd(L.inc, slot_inc(), in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0)) != HN_OK) return rc;
         }
         cur_st ^= 1;
+        if ((rc = flush_wgrads(t)) != HN_OK) return rc;
         HN_HIP(ctx, hipGetLastError());
         return HN_OK;
     }
@@ -836,7 +916,14 @@ int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
         o_gy[d] = gtake((size_t)nb * kFeat * plane(d));
         if (d < depth) { o_go[d] = gtake((size_t)nb * kFeat * plane(d)); o_gu[d] = gtake((size_t)nb * kFeat * plane(d)); }
     }
-    const size_t o_gz = gtake((size_t)nb * kFeat * plane(0)), o_tmp = gtake((size_t)nb * kFeat * plane(0));
+    const size_t o_tmp = gtake((size_t)nb * kFeat * plane(0));
+    size_t o_gz[3 * kMaxDepth + 2];   // slots as Trainer::slot_*: inc, sig[d], st[d], dec[d]
+    o_gz[0] = gtake((size_t)nb * kFeat * plane(0));
+    for (int d = 0; d < depth; ++d) {
+        o_gz[1 + d] = gtake((size_t)nb * kFeat * plane(d));
+        o_gz[1 + depth + d] = gtake((size_t)nb * kState * plane(d));
+    }
+    for (int d = 0; d <= depth; ++d) o_gz[1 + 2 * depth + d] = gtake((size_t)nb * kFeat * plane(d));
     const size_t o_wf0 = gtake((size_t)nb * 2 * plane(0)), o_wf1 = gtake((size_t)nb * 2 * plane(0)), o_res = gtake((size_t)nb * 2 * plane(0));
     const size_t o_st0 = gtake((size_t)nb * kState * ctx->state_len), o_st1 = gtake((size_t)nb * kState * ctx->state_len);
     HN_HIP(ctx, hipMalloc((void**)&W.gbuf, sizeof(float) * g));
@@ -845,7 +932,8 @@ int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
         W.g_y[d] = W.gbuf + o_gy[d];
         if (d < depth) { W.g_out[d] = W.gbuf + o_go[d]; W.g_u[d] = W.gbuf + o_gu[d]; }
     }
-    W.gz = W.gbuf + o_gz; W.tmp8 = W.gbuf + o_tmp;
+    for (int i = 0; i < 3 * depth + 2; ++i) W.gz[i] = W.gbuf + o_gz[i];
+    W.tmp8 = W.gbuf + o_tmp;
     W.g_wf[0] = W.gbuf + o_wf0; W.g_wf[1] = W.gbuf + o_wf1; W.g_res = W.gbuf + o_res;
     W.g_st[0] = W.gbuf + o_st0; W.g_st[1] = W.gbuf + o_st1;
     const size_t total = raw_layout(depth).total;
@@ -858,6 +946,11 @@ int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
     HN_HIP(ctx, hipMalloc((void**)&W.zero8, sizeof(float) * 8));
     HN_HIP(ctx, hipMemset(W.zero8, 0, sizeof(float) * 8));
     HN_HIP(ctx, hipMalloc((void**)&W.sumsq, sizeof(float) * (size_t)nu * nb));
+    // per iteration: 2 jobs per DoubleConv (3 depth + 2 of them) + 2 depth 8x8 jobs
+    W.jobs_region = (size_t)(6 * depth + 4) * sizeof(Wg3Args) + (size_t)2 * depth * sizeof(Wg8Args);
+    HN_HIP(ctx, hipHostMalloc((void**)&W.jobs_host, W.jobs_region * nu, hipHostMallocDefault));
+    HN_HIP(ctx, hipMalloc((void**)&W.jobs_dev, W.jobs_region * nu));
+    HN_HIP(ctx, hipEventCreateWithFlags(&W.jobs_copied, hipEventDisableTiming));
     W.batch = nb; W.n_unroll = nu; W.n = n; W.depth = depth;
     return HN_OK;
 }
@@ -876,7 +969,9 @@ int train_ready(hn_ctx* ctx, int batch, int n_unroll) {
 
 void train_free(hn_ctx* ctx) {
     auto& W = ctx->tr;
-    for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.zero8, (void*)W.sumsq}) (void)hipFree(p);
+    for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.zero8, (void*)W.sumsq, (void*)W.jobs_dev}) (void)hipFree(p);
+    if (W.jobs_host != nullptr) (void)hipHostFree(W.jobs_host);
+    if (W.jobs_copied != nullptr) (void)hipEventDestroy(W.jobs_copied);
     W = hn_ctx::TrainWs{};
 }
 
@@ -906,6 +1001,10 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     hipStream_t s = (hipStream_t)stream;
     auto& W = ctx->tr;
     const int n = ctx->tab.n, depth = ctx->depth;
+    if (W.jobs_in_flight) {   // the previous call's job tables have left the pinned buffer (normally long ago)
+        HN_HIP(ctx, hipEventSynchronize(W.jobs_copied));
+        W.jobs_in_flight = false;
+    }
     Trainer tr{ctx, s, weights, raw_layout(depth), batch, n, depth, ctx->act_kind, (long)ctx->state_len};
     const size_t fwf = (size_t)batch * 2 * n * n, fst = (size_t)batch * kState * ctx->state_len;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
@@ -954,6 +1053,8 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         const float* st_in = t == 0 ? states : st_hist + (size_t)(t - 1) * fst;
         if ((rc = tr.backward_step(t, wf_in, res_in, st_in, res_hist + (size_t)t * fwf, k_sq, loss_c, cur_wf, cur_st)) != HN_OK) return rc;
     }
+    HN_HIP(ctx, hipEventRecord(W.jobs_copied, s));
+    W.jobs_in_flight = true;
     // the table's rows -> the gradient blob, then the slope entries from their own per-block sums
     hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv((int)tr.L.total, 256)), dim3(256), 0, s, W.part, kPartRows, (int)tr.L.total, grad);
     if (ctx->act_kind == HN_ACT_PRELU) {
