@@ -186,7 +186,8 @@ int hn_create(hn_ctx** out, int device_id) {
         if (hn_set_unet_precision(c, mode) != HN_OK) return bad_env("HN_UNET_IMPL", v);
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
-                                                            {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP}};
+                                                            {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
+                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) c->opt_side_low_priority = std::atoi(v) != 0;
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -246,6 +247,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_SPECTRAL_COLS:
             if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_SPECTRAL_COLS must be 0, 1 or 2 (got %d)", value);
             ctx->opt_cols_t = value;
+            break;
+        case HN_OPT_TRAIN_LANES:
+            if (value < 1 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_LANES must be 1 or 2 (got %d)", value);
+            ctx->opt_train_lanes = value;
             break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }

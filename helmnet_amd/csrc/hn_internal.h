@@ -183,7 +183,7 @@ struct hn_ctx {
         float* gbuf = nullptr;       // gradient buffers, carved below
         float *g_x[hn::kMaxDepth + 1]{}, *g_out[hn::kMaxDepth]{}, *g_u[hn::kMaxDepth]{}, *g_y[hn::kMaxDepth + 1]{};
         float *gz[3 * hn::kMaxDepth + 2]{};   // gradient of every DoubleConv's mid tensor (it feeds conv1's weight gradient at the end of the iteration)
-        float *tmp8 = nullptr, *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
+        float *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
         float* part = nullptr;       // [640 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
         size_t part_floats = 0;
         double* slope_part = nullptr; // [3 depth + 2 DoubleConvs][slope_stride]: per-block sums of the PReLU-slope gradients (float64)
@@ -196,9 +196,18 @@ struct hn_ctx {
         // behind the iteration's backward-data chain, read by the three launches that follow the copy
         unsigned char *jobs_host = nullptr, *jobs_dev = nullptr;
         size_t jobs_region = 0;      // bytes per iteration
-        hipEvent_t jobs_copied = nullptr;   // the last call's last copy (the host side is not rewritten before it has happened)
-        bool jobs_in_flight = false;
-    } tr;
+        // the pinned side rotates over kJobSets copies, one per call: the host may enqueue that many calls ahead of the GPU before it
+        // has to wait for a table to have been copied out (a single copy made every call wait for the previous call's LAST launch)
+        static constexpr int kJobSets = 4;
+        hipEvent_t jobs_copied[kJobSets]{};   // recorded behind the last copy of the call that used the set
+        bool jobs_in_flight[kJobSets]{};
+        int jobs_set = 0, jobs_rows = 0;      // set of the current call; iterations per set
+        int last_batch = 0;          // samples of the last hn_train_grad call in this workspace (hn_train_peek)
+        int sumsq_batch = 0;         // samples per row of sumsq (lane 0 holds the whole batch's rows)
+    } tr, tr_b;                      // tr_b: the second half of the batch when hn_train_grad runs as two lanes
+    int opt_train_lanes = 1;       // HN_OPT_TRAIN_LANES: 2 = the halves of the batch as two chains on two streams (measured: no gain)
+    hipStream_t train_stream = nullptr;            // lane 1 (created on first use)
+    hipEvent_t train_fork = nullptr, train_join = nullptr;
     // optional per-kernel timing with HIP events on the caller's stream (hn_profile_*)
     uint64_t prof_mask = 0;
     int prof_stride = 1;          // bracket every prof_stride-th launch of a selected kernel
@@ -295,7 +304,7 @@ void pack_frag_up_x16(const float* w_iohw, float* dst_split, float* dst_half);
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
 void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
-void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
+void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate = false);
 
 // ---- vector-pipe DoubleConv of the big levels (hn_dcv.hip) ----
 void pack_valu_q(const float* w_oihw, int cin, float* dst);            // conv1 [8][cin][3][3] -> [cin][2][9][4]

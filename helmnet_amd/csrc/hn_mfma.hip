@@ -1540,7 +1540,7 @@ struct UpCfg2 {
 };
 
 // Staging follows k_down_mfma: zero the out-of-image positions once, no predicates in the (unrolled) loop.
-template <int WX, int R_, bool ALL>
+template <int WX, int R_, bool ALL, bool ACC = false>   // ACC: out += (the training step's backward pass adds `down`'s input gradient to the skip gradient)
 __global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][2][4][64]*/,
                                                   const float* __restrict__ bias, int Hin, int Win) {
     using C = UpCfg2<WX, R_>;
@@ -1665,8 +1665,14 @@ __global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float
                 const int y = 2 * Y + 1 + py;
                 if (y >= 0 && y < Hout) {
                     float* p = out.p + (long)b * out.sb + (long)(2 * q) * out.sc + (long)y * Wout + 2 * X;
-                    *reinterpret_cast<float2*>(p) = make_float2(acc[wr][0][py] + b0, acc[wr][1][py] + b0);
-                    *reinterpret_cast<float2*>(p + out.sc) = make_float2(acc[wr][0][2 + py] + b1, acc[wr][1][2 + py] + b1);
+                    float2 o0 = make_float2(acc[wr][0][py] + b0, acc[wr][1][py] + b0);
+                    float2 o1 = make_float2(acc[wr][0][2 + py] + b1, acc[wr][1][2 + py] + b1);
+                    if (ACC) {
+                        const float2 c0 = *reinterpret_cast<const float2*>(p), c1 = *reinterpret_cast<const float2*>(p + out.sc);
+                        o0.x += c0.x; o0.y += c0.y; o1.x += c1.x; o1.y += c1.y;
+                    }
+                    *reinterpret_cast<float2*>(p) = o0;
+                    *reinterpret_cast<float2*>(p + out.sc) = o1;
                 }
             }
         }
@@ -2133,7 +2139,7 @@ void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const fl
     }
 }
 
-void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
+void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate) {
     // window rows -1 .. Hin-1
     if (const int mode = ctx->precision; mode >= HN_PREC_BF16X3 && mode <= HN_PREC_BF16X2 && Win >= 64) {
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
@@ -2148,10 +2154,14 @@ void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const floa
     // 22 window rows per block: the Hin + 1 = 129 (257) window rows of a 128^2 (256^2) input split into 6 (12)
     // row blocks with 2 % padding instead of 9 x 16 with 10 %, and 4 x 6 x 32 = 768 blocks are exactly one
     // round of 3 resident blocks per CU at 256^2 x 32 (16-row blocks: 1152 = 1.5 rounds)
-    if (Win > up_small) hipLaunchKernelGGL((k_up_mfma<2, 11, false>), dim3(cdiv_(Win, 32), cdiv_(Hin + 1, 22), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
-    else {
+    if (Win > up_small) {
+        const dim3 g(cdiv_(Win, 32), cdiv_(Hin + 1, 22), batch);
+        if (accumulate) hipLaunchKernelGGL((k_up_mfma<2, 11, false, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+        else hipLaunchKernelGGL((k_up_mfma<2, 11, false>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    } else {
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
-        hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+        if (accumulate) hipLaunchKernelGGL((k_up_mfma<1, 5, true, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+        else hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
     }
 }
 

@@ -199,13 +199,13 @@ struct Conv3Args {
 };
 constexpr int kC3TH = 16, kC3TW = 32, kC3PI = 36;
 
+// one 16 x 32 tile of sample b; `a` lives in the kernel-argument segment (scalar loads, also where it is indexed)
 template <int CO, bool EPI_ACT>
-__global__ __launch_bounds__(512) void k_conv3(Conv3Args a) {
+__device__ __forceinline__ void conv3_tile(const Conv3Args& a, int x0, int y0, int b, int block_in_layer) {
     constexpr int TH = kC3TH, TW = kC3TW, PI = kC3PI, IR = TH + 2, IC = TW + 2;
     extern __shared__ __attribute__((aligned(16))) float s_in[];   // [CI][IR][PI] + 8
     __shared__ double s_red[8];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const int CI = a.src[0].nch + a.src[1].nch + a.src[2].nch;
     const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
     {
@@ -264,9 +264,31 @@ __global__ __launch_bounds__(512) void k_conv3(Conv3Args a) {
             double tot = 0.0;
 #pragma unroll
             for (int wv = 0; wv < 8; ++wv) tot += s_red[wv];
-            a.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] += tot;
+            a.slope_part[block_in_layer] += tot;
         }
     }
+}
+
+template <int CO, bool EPI_ACT>
+__global__ __launch_bounds__(512) void k_conv3(Conv3Args a) {
+    conv3_tile<CO, EPI_ACT>(a, blockIdx.x * kC3TW, blockIdx.y * kC3TH, blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+}
+
+// The same layer type at several levels of the UNet in ONE launch (the hidden-state DoubleConvs: off the chain within an
+// iteration, so the levels' instances are independent): job j owns blocks [blk0[j], blk0[j + 1]), tiles in (x, y, sample) order.
+struct Conv3Batch {
+    Conv3Args job[kMaxDepth];
+    int blk0[kMaxDepth + 1];
+    int tiles_x[kMaxDepth], tiles_y[kMaxDepth];
+    int njobs;
+};
+template <int CO, bool EPI_ACT>
+__global__ __launch_bounds__(512) void k_conv3_batch(Conv3Batch q) {
+    int j = 0;
+    while (j + 1 < q.njobs && (int)blockIdx.x >= q.blk0[j + 1]) ++j;
+    const int bid = (int)blockIdx.x - q.blk0[j];
+    const int tx = bid % q.tiles_x[j], r = bid / q.tiles_x[j], ty = r % q.tiles_y[j], b = r / q.tiles_y[j];
+    conv3_tile<CO, EPI_ACT>(q.job[j], tx * kC3TW, ty * kC3TH, b, bid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -484,7 +506,7 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(const Wg8Args* __restrict__
 }
 
 // grad[j] = sum over the rows of the table, in a fixed order (every weight-gradient kernel of the call has added to its row)
-__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int rows, int count, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ part, int rows, int count, float* __restrict__ out, int accumulate) {
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= count) return;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -496,15 +518,19 @@ __global__ __launch_bounds__(256) void k_reduce_rows(const float* __restrict__ p
         s3 += part[(size_t)(r + 3) * count + j];
     }
     for (; r < rows; ++r) s0 += part[(size_t)r * count + j];
-    out[j] = (s0 + s1) + (s2 + s3);
+    const float v = (s0 + s1) + (s2 + s3);
+    out[j] = accumulate ? out[j] + v : v;   // the second lane's table is added to the first lane's sums
 }
 // PReLU slope gradients: block j sums the rows[j] per-block partial sums of DoubleConv j (fixed order) into grad[off[j]]
 struct SlopeJobs { int rows[3 * kMaxDepth + 2]; int off[3 * kMaxDepth + 2]; };
-__global__ __launch_bounds__(256) void k_reduce_slopes(const double* __restrict__ part, int stride, SlopeJobs jobs, float* __restrict__ grad) {
+__global__ __launch_bounds__(256) void k_reduce_slopes(const double* __restrict__ part, int stride, SlopeJobs jobs, const double* __restrict__ part_b,
+                                                       int stride_b, SlopeJobs jobs_b, float* __restrict__ grad) {
     __shared__ double s_red[4];
     const int j = blockIdx.x;
     double s = 0.0;
     for (int r = threadIdx.x; r < jobs.rows[j]; r += 256) s += part[(size_t)j * stride + r];
+    if (part_b != nullptr)   // second lane (kept in float64 to the end: the slope gradient is a sum with both signs)
+        for (int r = threadIdx.x; r < jobs_b.rows[j]; r += 256) s += part_b[(size_t)j * stride_b + r];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
     if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = s;
@@ -568,10 +594,6 @@ __global__ __launch_bounds__(256) void k_loss_seed(float* __restrict__ g, const 
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < total) g[i] = has_in ? fmaf(c, res[i], g[i]) : c * res[i];
 }
-__global__ __launch_bounds__(256) void k_add(float* __restrict__ y, const float* __restrict__ x, long total) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < total) y[i] += x[i];
-}
 // loss = scale * sum(sumsq) / count, summed in a fixed order by one wavefront
 __global__ void k_loss_finalize(const float* __restrict__ sumsq, int n, float scale_over_count, float* __restrict__ loss) {
     float s = 0.f;
@@ -583,12 +605,16 @@ __global__ void k_loss_finalize(const float* __restrict__ sumsq, int n, float sc
 // A-operand fragments of the fp32 matrix-core 8x8 kernels (hn_mfma.hip: pack_frag_down / pack_frag_up), built on the device.
 //   up == 0: raw is [out][in][8][8] -> [in][kx][64 lanes]:      lane -> (co = (l & 15) >> 1, h = l & 1, k = l >> 4): raw[co][ci][4h + k][kx]
 //   up == 1: raw is [in][out][8][8] -> [in][px][bb][64 lanes]:  lane -> (co, py = l & 1, a = l >> 4): raw[ci][co][6 + py - 2a][7 - px - 2bb]
-__global__ __launch_bounds__(256) void k_pack_frag8(const float* __restrict__ raw, float* __restrict__ dst, int up) {
+// One launch for every level: blockIdx.y = 4 level + which (0 down forward, 1 down backward-data, 2 up forward, 3 up backward-data).
+struct PackK8Jobs { int off[4 * kMaxDepth]; int up[4 * kMaxDepth]; };   // blob offset of the raw weight; read as a transposed convolution
+__global__ __launch_bounds__(256) void k_pack_frag8(const float* __restrict__ blob, float* __restrict__ k8, PackK8Jobs jobs) {
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= kFeat * kFeat * 64) return;
+    const float* raw = blob + jobs.off[blockIdx.y];
+    float* dst = k8 + (size_t)blockIdx.y * 4096;
     const int l = e & 63, blk = (e >> 6) & 7, ci = e >> 9;
     const int co = (l & 15) >> 1, j = l & 1, q = l >> 4;
-    if (!up) dst[e] = raw[((co * kFeat + ci) * 8 + 4 * j + q) * 8 + blk];
+    if (!jobs.up[blockIdx.y]) dst[e] = raw[((co * kFeat + ci) * 8 + 4 * j + q) * 8 + blk];
     else {
         const int px = blk >> 2, bb = blk & 3;
         dst[e] = raw[((ci * kFeat + co) * 8 + (6 + j - 2 * q)) * 8 + (7 - px - 2 * bb)];
@@ -648,6 +674,29 @@ int launch_conv3(hn_ctx* ctx, int co, bool epi, const Conv3Args& a, int batch, h
     return HN_OK;
 }
 
+// q.job[0 .. njobs) filled by the caller; block runs, tile counts and the LDS size here
+int launch_conv3_batch(hn_ctx* ctx, int co, bool epi, Conv3Batch& q, int batch, hipStream_t s) {
+    int total = 0;
+    size_t lds = 0;
+    for (int j = 0; j < q.njobs; ++j) {
+        const Conv3Args& a = q.job[j];
+        q.tiles_x[j] = cdiv(a.W, kC3TW);
+        q.tiles_y[j] = cdiv(a.H, kC3TH);
+        q.blk0[j] = total;
+        total += q.tiles_x[j] * q.tiles_y[j] * batch;
+        const int ci = a.src[0].nch + a.src[1].nch + a.src[2].nch;
+        const size_t l = sizeof(float) * ((size_t)ci * (kC3TH + 2) * kC3PI + 8);
+        if (l > lds) lds = l;
+    }
+    q.blk0[q.njobs] = total;
+    if (total == 0) return HN_OK;
+    if (co == 2 && !epi) hipLaunchKernelGGL((k_conv3_batch<2, false>), dim3(total), dim3(512), lds, s, q);
+    else if (co == 2 && epi) hipLaunchKernelGGL((k_conv3_batch<2, true>), dim3(total), dim3(512), lds, s, q);
+    else if (co == 10 && !epi) hipLaunchKernelGGL((k_conv3_batch<10, false>), dim3(total), dim3(512), lds, s, q);
+    else return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no batched 3x3 kernel for %d output channels (epilogue %d)", co, (int)epi);
+    return HN_OK;
+}
+
 constexpr int kPartRows = 640;   // rows of the partials table = the most blocks a weight-gradient launch uses (96^2 x 32: 576 tiles of 16 x 32, one each)
 
 struct Trainer {
@@ -657,10 +706,13 @@ struct Trainer {
     RawLayout L;
     int B, n, depth, act;
     long Lst;            // flat state length per channel
+    hn_ctx::TrainWs* ws; // this lane's workspace (tape, gradient buffers, partial-sum tables, job tables)
+    float* sumsq0;       // &sumsq[0][first sample of this lane]; rows are sumsq_stride floats apart
+    int sumsq_stride;
 
     int side(int d) const { return n >> d; }
     long plane(int d) const { return (long)side(d) * side(d); }
-    hn_ctx::TrainWs& T() const { return ctx->tr; }
+    hn_ctx::TrainWs& T() const { return *ws; }
     float* tape(int t, size_t off) const { return T().tape + (size_t)t * T().step_floats + off; }
     TSrc feat(const float* p, int d, int nch = kFeat, int act_on_load = 0) const { return TSrc{p, nch * plane(d), plane(d), nch, 1.f, act_on_load}; }
     TDst featdst(float* p, int d, int nch = kFeat, int accum = 0) const { return TDst{p, nch * plane(d), plane(d), nch, 1.f, accum}; }
@@ -670,19 +722,22 @@ struct Trainer {
     TDst state_dst(float* flat, int d, int accum = 0) const { return TDst{flat + ctx->state_off[d], 2 * Lst, Lst, kState, 1.f, accum}; }
     Src msrc(const float* p, int d) const { return Src{p, kFeat * plane(d), plane(d), 1.f}; }
     Dst mdst(float* p, int d) const { return Dst{p, kFeat * plane(d), plane(d)}; }
-    const float* wfwd(size_t off) const { return T().w3 + off; }                // k_pack3: forward arrangement at the raw offset
-    const float* wbwd(size_t off) const { return T().w3 + L.total + off; }      // backward-data arrangement behind it
+    const float* wfwd(size_t off) const { return ctx->tr.w3 + off; }            // (packed weights: one copy, in the first lane's workspace)                // k_pack3: forward arrangement at the raw offset
+    const float* wbwd(size_t off) const { return ctx->tr.w3 + L.total + off; }      // backward-data arrangement behind it
     float* table(size_t col) const { return T().part + col; }                   // &table[0][col]; rows are L.total floats apart
-    const float* frag8(int d, int which) const { return T().k8 + ((size_t)d * 4 + which) * 4096; }   // 0 down fwd, 1 down bwd-data, 2 up fwd, 3 up bwd-data
+    const float* frag8(int d, int which) const { return ctx->tr.k8 + ((size_t)d * 4 + which) * 4096; }   // 0 down fwd, 1 down bwd-data, 2 up fwd, 3 up bwd-data
 
-    int conv_fwd(const TSrc (&src)[3], size_t w_off, size_t b_off, int w_o, size_t slope_off, TDst dst, int d) {
+    Conv3Args fwd_args(const TSrc (&src)[3], size_t w_off, size_t b_off, size_t slope_off, TDst dst, int d) const {
         Conv3Args a{};
         for (int i = 0; i < 3; ++i) a.src[i] = src[i];
         a.dst[0] = dst; a.dst[1] = nodst(); a.dst[2] = nodst();
         a.wpk = wfwd(w_off); a.bias = w + b_off;
         a.H = a.W = side(d);
         a.act_kind = act; a.slope = w + slope_off;
-        return launch_conv3(ctx, w_o, false, a, B, s);
+        return a;
+    }
+    int conv_fwd(const TSrc (&src)[3], size_t w_off, size_t b_off, int w_o, size_t slope_off, TDst dst, int d) {
+        return launch_conv3(ctx, w_o, false, fwd_args(src, w_off, b_off, slope_off, dst, d), B, s);
     }
     // DoubleConv forward with tape: z = conv1(in) (stored), out = conv2(act(z))
     int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d) {
@@ -730,7 +785,7 @@ struct Trainer {
         const size_t b8 = jobs8.size() * sizeof(Wg3Args), b2 = jobs2.size() * sizeof(Wg3Args), bk = jobsk.size() * sizeof(Wg8Args);
         if (b8 + b2 + bk > W.jobs_region) return fail(ctx, HN_ERR_STATE, "internal: weight-gradient job table overflow (%zu > %zu bytes)", b8 + b2 + bk, W.jobs_region);
         const int n8 = number_blocks(jobs8), n2 = number_blocks(jobs2), nk = number_blocks(jobsk);
-        unsigned char* h = W.jobs_host + (size_t)t * W.jobs_region;
+        unsigned char* h = W.jobs_host + ((size_t)W.jobs_set * W.jobs_rows + t) * W.jobs_region;
         unsigned char* dv = W.jobs_dev + (size_t)t * W.jobs_region;
         if (b8) std::memcpy(h, jobs8.data(), b8);
         if (b2) std::memcpy(h + b8, jobs2.data(), b2);
@@ -743,36 +798,40 @@ struct Trainer {
         return HN_OK;
     }
     // DoubleConv backward: g_out (co channels) -> weight gradients, gradients of the inputs into `gin` (channel groups of the concatenation)
+    // the two backward-data convolutions of a DoubleConv: g_z = conv2^T(g_out) * act'(z) (+ d slope), g_in = conv1^T(g_z)
+    Conv3Args bwd2_args(const RawDc& dc, int slot, const float* z, TSrc g_out, int d) const {
+        Conv3Args a{};
+        a.src[0] = g_out; a.src[1] = nosrc(); a.src[2] = nosrc();
+        a.dst[0] = featdst(T().gz[slot], d, dc.cm); a.dst[1] = nodst(); a.dst[2] = nodst();
+        a.wpk = wbwd(dc.w2); a.bias = nullptr;
+        a.H = a.W = side(d);
+        a.act_kind = act; a.slope = w + dc.slope;
+        a.z = z; a.z_sb = dc.cm * plane(d); a.z_sc = plane(d);
+        a.slope_part = act == HN_ACT_PRELU ? T().slope_part + (size_t)slot * T().slope_stride : nullptr;
+        return a;
+    }
+    Conv3Args bwd1_args(const RawDc& dc, int slot, const TDst (&gin)[3], int d) const {
+        Conv3Args a{};
+        a.src[0] = feat(T().gz[slot], d, dc.cm); a.src[1] = nosrc(); a.src[2] = nosrc();
+        for (int i = 0; i < 3; ++i) a.dst[i] = gin[i];
+        a.wpk = wbwd(dc.w1); a.bias = nullptr;
+        a.H = a.W = side(d);
+        a.act_kind = act; a.slope = nullptr;
+        return a;
+    }
+    // both weight gradients of a DoubleConv (filed; gz[slot] -- its own buffer per DoubleConv -- is read at the end of the iteration)
+    int dc_wgrads(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, int d) {
+        const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
+        int rc = wgrad3(mid, g_out, dc.co, dc.w2, d, dc.slope);                              // dW2, db2 from (act(z), g_out)
+        if (rc != HN_OK) return rc;
+        return wgrad3(in, feat(T().gz[slot], d, dc.cm), dc.cm, dc.w1, d, dc.slope);          // dW1, db1 from (in, g_z)
+    }
+    // DoubleConv backward: g_out (co channels) -> weight gradients, gradients of the inputs into `gin` (channel groups of the concatenation)
     int dc_bwd(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
         int rc;
-        float* const gz = T().gz[slot];   // its own buffer per DoubleConv: the filed weight-gradient job reads it at the end of the iteration
-        {   // conv2: dW2, db2 from (act(z), g_out)
-            const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
-            if ((rc = wgrad3(mid, g_out, dc.co, dc.w2, d, dc.slope)) != HN_OK) return rc;
-        }
-        {   // g_z = conv2^T(g_out) * act'(z);  d slope
-            Conv3Args a{};
-            a.src[0] = g_out; a.src[1] = nosrc(); a.src[2] = nosrc();
-            a.dst[0] = featdst(gz, d, dc.cm); a.dst[1] = nodst(); a.dst[2] = nodst();
-            a.wpk = wbwd(dc.w2); a.bias = nullptr;
-            a.H = a.W = side(d);
-            a.act_kind = act; a.slope = w + dc.slope;
-            a.z = z; a.z_sb = dc.cm * plane(d); a.z_sc = plane(d);
-            a.slope_part = act == HN_ACT_PRELU ? T().slope_part + (size_t)slot * T().slope_stride : nullptr;
-            if ((rc = launch_conv3(ctx, dc.cm, true, a, B, s)) != HN_OK) return rc;
-        }
-        // conv1: dW1, db1 from (in, g_z)
-        if ((rc = wgrad3(in, feat(gz, d, dc.cm), dc.cm, dc.w1, d, dc.slope)) != HN_OK) return rc;
-        {   // g_in = conv1^T(g_z)
-            Conv3Args a{};
-            a.src[0] = feat(gz, d, dc.cm); a.src[1] = nosrc(); a.src[2] = nosrc();
-            for (int i = 0; i < 3; ++i) a.dst[i] = gin[i];
-            a.wpk = wbwd(dc.w1); a.bias = nullptr;
-            a.H = a.W = side(d);
-            a.act_kind = act; a.slope = nullptr;
-            if ((rc = launch_conv3(ctx, dc.cin, false, a, B, s)) != HN_OK) return rc;
-        }
-        return HN_OK;
+        if ((rc = dc_wgrads(dc, slot, in, z, g_out, d)) != HN_OK) return rc;
+        if ((rc = launch_conv3(ctx, dc.cm, true, bwd2_args(dc, slot, z, g_out, d), B, s)) != HN_OK) return rc;
+        return launch_conv3(ctx, dc.cin, false, bwd1_args(dc, slot, gin, d), B, s);
     }
     int slot_inc() const { return 0; }
     int slot_sig(int d) const { return 1 + d; }
@@ -804,9 +863,21 @@ struct Trainer {
         for (int d = 0; d < depth; ++d) {
             const TSrc in_sig[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
             if ((rc = dc_fwd(L.sig[d], in_sig, tape(t, W.o_zsig[d]), featdst(tape(t, W.o_out[d]), d), d)) != HN_OK) return rc;
-            const TSrc in_st[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
-            if ((rc = dc_fwd(L.st[d], in_st, tape(t, W.o_zst[d]), state_dst(st_next, d), d)) != HN_OK) return rc;
             launch_down(ctx, msrc(tape(t, W.o_out[d]), d), mdst(tape(t, W.o_x[d + 1]), d + 1), frag8(d, 0), w + L.down[d].b, side(d), side(d), B, s);
+        }
+        {   // new_state_d = conv_state_d(cat[out_d, state_d]) (architectures.py:248) for every level at once: nothing of this iteration
+            // reads the new states, so the levels' DoubleConvs are two launches (first convolutions, second convolutions) instead of 2 depth
+            Conv3Batch q1{}, q2{};
+            q1.njobs = q2.njobs = depth;
+            for (int d = 0; d < depth; ++d) {
+                const RawDc& dc = L.st[d];
+                const TSrc in_st[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
+                q1.job[d] = fwd_args(in_st, dc.w1, dc.b1, dc.slope, featdst(tape(t, W.o_zst[d]), d, dc.cm), d);
+                const TSrc mid[3] = {feat(tape(t, W.o_zst[d]), d, dc.cm, 1), nosrc(), nosrc()};
+                q2.job[d] = fwd_args(mid, dc.w2, dc.b2, dc.slope, state_dst(st_next, d), d);
+            }
+            if ((rc = launch_conv3_batch(ctx, kState, false, q1, B, s)) != HN_OK) return rc;
+            if ((rc = launch_conv3_batch(ctx, kState, false, q2, B, s)) != HN_OK) return rc;
         }
         {
             const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
@@ -819,7 +890,7 @@ struct Trainer {
         }
         const long total = (long)B * p0;
         hipLaunchKernelGGL(k_outc_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tape(t, W.o_y[0]), w + L.outc_w, w + L.outc_b, wf, wf_next, p0, total);
-        return spec_apply(ctx, wf_next, res_next, ksq, src, src_batch, B, W.sumsq + (size_t)t * B, s);
+        return spec_apply(ctx, wf_next, res_next, ksq, src, src_batch, B, sumsq0 + (size_t)t * sumsq_stride, s);
     }
 
     // backward of iteration t.  On entry g_wf[cur_wf] / g_res / g_st[cur_st] hold d loss / d (wf, res, states) AFTER iteration t without
@@ -840,12 +911,28 @@ struct Trainer {
             const int blocks = (int)((total + 255) / 256) < kPartRows ? (int)((total + 255) / 256) : kPartRows;
             hipLaunchKernelGGL(k_outc_bwd, dim3(blocks), dim3(256), 0, s, G, tape(t, W.o_y[0]), w + L.outc_w, W.g_y[0], table(L.outc_w), (long)L.total, p0, total);
         }
+        {   // conv_state of every level first (new_state = DC(cat[out, state]): its gradient arrives from iteration t + 1 alone), as two
+            // batched launches; it OPENS the sums g_out[d] and g_st[.][d] that the decoder, `down` and conv_signal then add to
+            Conv3Batch q2{}, q1{};
+            q2.njobs = q1.njobs = depth;
+            for (int d = 0; d < depth; ++d) {
+                const RawDc& dc = L.st[d];
+                const TSrc in[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
+                const TSrc g_new = state_src(W.g_st[cur_st], d);
+                if ((rc = dc_wgrads(dc, slot_st(d), in, tape(t, W.o_zst[d]), g_new, d)) != HN_OK) return rc;
+                q2.job[d] = bwd2_args(dc, slot_st(d), tape(t, W.o_zst[d]), g_new, d);
+                const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 0), state_dst(W.g_st[cur_st ^ 1], d, 0), nodst()};
+                q1.job[d] = bwd1_args(dc, slot_st(d), gin, d);
+            }
+            if ((rc = launch_conv3_batch(ctx, kState, true, q2, B, s)) != HN_OK) return rc;
+            if ((rc = launch_conv3_batch(ctx, kFeat + kState, false, q1, B, s)) != HN_OK) return rc;
+        }
         for (int d = 0; d < depth; ++d) {   // decoder, top down
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
-            const TDst gin[3] = {featdst(W.g_u[d], d), featdst(W.g_out[d], d), nodst()};
+            const TDst gin[3] = {featdst(W.g_u[d], d), featdst(W.g_out[d], d, kFeat, 1), nodst()};
             if ((rc = dc_bwd(L.dec[d], slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d)) != HN_OK) return rc;
             // up[d]: backward-data = the stride-2 convolution kernel on the transposed-convolution weights read as [out, in, kh, kw]
-            launch_down(ctx, msrc(W.g_u[d], d), mdst(W.g_y[d + 1], d + 1), frag8(d, 3), W.zero8, side(d), side(d), B, s);
+            launch_down(ctx, msrc(W.g_u[d], d), mdst(W.g_y[d + 1], d + 1), frag8(d, 3), ctx->tr.zero8, side(d), side(d), B, s);
             wgrad8(tape(t, W.o_y[d + 1]), d + 1, W.g_u[d], L.up[d].w, 1);
         }
         {
@@ -856,15 +943,8 @@ struct Trainer {
         for (int d = depth - 1; d >= 0; --d) {   // encoder, bottom up
             // down[d]: backward-data = the transposed-convolution kernel on the convolution weights read as [in, out, kh, kw];
             // added to the skip gradient
-            launch_up(ctx, msrc(W.g_x[d + 1], d + 1), mdst(W.tmp8, d), frag8(d, 1), W.zero8, side(d + 1), side(d + 1), B, s);
-            const long tot8 = (long)B * kFeat * plane(d);
-            hipLaunchKernelGGL(k_add, dim3((unsigned)((tot8 + 255) / 256)), dim3(256), 0, s, W.g_out[d], W.tmp8, tot8);
+            launch_up(ctx, msrc(W.g_x[d + 1], d + 1), mdst(W.g_out[d], d), frag8(d, 1), ctx->tr.zero8, side(d + 1), side(d + 1), B, s, true);
             wgrad8(W.g_x[d + 1], d + 1, tape(t, W.o_out[d]), L.down[d].w, 0);
-            {   // conv_state: new_state = DC(cat[out, state])
-                const TSrc in[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
-                const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 1), state_dst(W.g_st[cur_st ^ 1], d, 0), nodst()};
-                if ((rc = dc_bwd(L.st[d], slot_st(d), in, tape(t, W.o_zst[d]), state_src(W.g_st[cur_st], d), gin, d)) != HN_OK) return rc;
-            }
             {   // conv_signal: out = DC(cat[x, state])
                 const TSrc in[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
                 const TDst gin[3] = {featdst(W.g_x[d], d), state_dst(W.g_st[cur_st ^ 1], d, 1), nodst()};
@@ -883,14 +963,24 @@ struct Trainer {
     }
 };
 
-int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
-    auto& W = ctx->tr;
+void train_free_ws(hn_ctx::TrainWs& W) {
+    for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.zero8, (void*)W.sumsq, (void*)W.jobs_dev}) (void)hipFree(p);
+    if (W.jobs_host != nullptr) (void)hipHostFree(W.jobs_host);
+    for (hipEvent_t e : W.jobs_copied)
+        if (e != nullptr) (void)hipEventDestroy(e);
+    W = hn_ctx::TrainWs{};
+}
+
+// workspace W for `batch` samples x n_unroll iterations; sumsq rows of `sumsq_batch` samples (the first lane keeps the whole batch's)
+int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int sumsq_batch) {
     const int n = ctx->tab.n, depth = ctx->depth;
-    if (W.tape != nullptr && W.n == n && W.depth == depth && batch <= W.batch && n_unroll <= W.n_unroll) return HN_OK;
+    if (W.tape != nullptr && W.n == n && W.depth == depth && batch <= W.batch && n_unroll <= W.n_unroll && sumsq_batch <= W.sumsq_batch) return HN_OK;
     HN_HIP(ctx, hipDeviceSynchronize());
-    const int nb = batch > W.batch || W.n != n || W.depth != depth ? batch : W.batch;
-    const int nu = n_unroll > W.n_unroll ? n_unroll : W.n_unroll;
-    train_free(ctx);
+    const bool fresh = W.n != n || W.depth != depth;
+    const int nb = fresh || batch > W.batch ? batch : W.batch;
+    const int nu = !fresh && n_unroll < W.n_unroll ? W.n_unroll : n_unroll;
+    const int nsq = !fresh && sumsq_batch < W.sumsq_batch ? W.sumsq_batch : sumsq_batch;
+    train_free_ws(W);
     auto plane = [&](int d) { return (size_t)(n >> d) * (n >> d); };
     size_t pos = 0;
     auto take = [&](size_t ch, int d) { const size_t o = pos; pos += (size_t)nb * ch * plane(d); return o; };
@@ -916,7 +1006,6 @@ int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
         o_gy[d] = gtake((size_t)nb * kFeat * plane(d));
         if (d < depth) { o_go[d] = gtake((size_t)nb * kFeat * plane(d)); o_gu[d] = gtake((size_t)nb * kFeat * plane(d)); }
     }
-    const size_t o_tmp = gtake((size_t)nb * kFeat * plane(0));
     size_t o_gz[3 * kMaxDepth + 2];   // slots as Trainer::slot_*: inc, sig[d], st[d], dec[d]
     o_gz[0] = gtake((size_t)nb * kFeat * plane(0));
     for (int d = 0; d < depth; ++d) {
@@ -933,7 +1022,6 @@ int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
         if (d < depth) { W.g_out[d] = W.gbuf + o_go[d]; W.g_u[d] = W.gbuf + o_gu[d]; }
     }
     for (int i = 0; i < 3 * depth + 2; ++i) W.gz[i] = W.gbuf + o_gz[i];
-    W.tmp8 = W.gbuf + o_tmp;
     W.g_wf[0] = W.gbuf + o_wf0; W.g_wf[1] = W.gbuf + o_wf1; W.g_res = W.gbuf + o_res;
     W.g_st[0] = W.gbuf + o_st0; W.g_st[1] = W.gbuf + o_st1;
     const size_t total = raw_layout(depth).total;
@@ -945,12 +1033,14 @@ int train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
     HN_HIP(ctx, hipMalloc((void**)&W.k8, sizeof(float) * (size_t)depth * 4 * 4096));
     HN_HIP(ctx, hipMalloc((void**)&W.zero8, sizeof(float) * 8));
     HN_HIP(ctx, hipMemset(W.zero8, 0, sizeof(float) * 8));
-    HN_HIP(ctx, hipMalloc((void**)&W.sumsq, sizeof(float) * (size_t)nu * nb));
+    HN_HIP(ctx, hipMalloc((void**)&W.sumsq, sizeof(float) * (size_t)nu * nsq));
+    W.sumsq_batch = nsq;
     // per iteration: 2 jobs per DoubleConv (3 depth + 2 of them) + 2 depth 8x8 jobs
     W.jobs_region = (size_t)(6 * depth + 4) * sizeof(Wg3Args) + (size_t)2 * depth * sizeof(Wg8Args);
-    HN_HIP(ctx, hipHostMalloc((void**)&W.jobs_host, W.jobs_region * nu, hipHostMallocDefault));
+    W.jobs_rows = nu;
+    HN_HIP(ctx, hipHostMalloc((void**)&W.jobs_host, W.jobs_region * nu * hn_ctx::TrainWs::kJobSets, hipHostMallocDefault));
     HN_HIP(ctx, hipMalloc((void**)&W.jobs_dev, W.jobs_region * nu));
-    HN_HIP(ctx, hipEventCreateWithFlags(&W.jobs_copied, hipEventDisableTiming));
+    for (hipEvent_t& e : W.jobs_copied) HN_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     W.batch = nb; W.n_unroll = nu; W.n = n; W.depth = depth;
     return HN_OK;
 }
@@ -968,11 +1058,13 @@ int train_ready(hn_ctx* ctx, int batch, int n_unroll) {
 }  // namespace
 
 void train_free(hn_ctx* ctx) {
-    auto& W = ctx->tr;
-    for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.zero8, (void*)W.sumsq, (void*)W.jobs_dev}) (void)hipFree(p);
-    if (W.jobs_host != nullptr) (void)hipHostFree(W.jobs_host);
-    if (W.jobs_copied != nullptr) (void)hipEventDestroy(W.jobs_copied);
-    W = hn_ctx::TrainWs{};
+    train_free_ws(ctx->tr);
+    train_free_ws(ctx->tr_b);
+    if (ctx->train_stream != nullptr) (void)hipStreamDestroy(ctx->train_stream);
+    if (ctx->train_fork != nullptr) (void)hipEventDestroy(ctx->train_fork);
+    if (ctx->train_join != nullptr) (void)hipEventDestroy(ctx->train_join);
+    ctx->train_stream = nullptr;
+    ctx->train_fork = ctx->train_join = nullptr;
 }
 
 }  // namespace hn
@@ -985,7 +1077,11 @@ int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
     int rc = train_ready(ctx, batch, n_unroll);
     if (rc != HN_OK) return rc;
     DeviceGuard guard(ctx);
-    return train_reserve(ctx, batch, n_unroll);
+    const int lanes = ctx->opt_train_lanes >= 2 && batch >= 2 ? 2 : 1;
+    const int b0 = lanes == 2 ? (batch + 1) / 2 : batch;
+    rc = train_reserve(ctx, ctx->tr, b0, n_unroll, batch);
+    if (rc == HN_OK && lanes == 2) rc = train_reserve(ctx, ctx->tr_b, batch - b0, n_unroll, 1);
+    return rc;
 }
 
 int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const float* res, const float* states, const float* k_sq,
@@ -997,77 +1093,127 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     if (rc != HN_OK) return rc;
     if (src_batch != 1 && src_batch != batch) return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
     DeviceGuard guard(ctx);
-    if ((rc = train_reserve(ctx, batch, n_unroll)) != HN_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    auto& W = ctx->tr;
     const int n = ctx->tab.n, depth = ctx->depth;
-    if (W.jobs_in_flight) {   // the previous call's job tables have left the pinned buffer (normally long ago)
-        HN_HIP(ctx, hipEventSynchronize(W.jobs_copied));
-        W.jobs_in_flight = false;
+    // Two lanes: samples are independent (hybridnet.py:399-409 is a batched call), and at the training size the chain of ~800 launches
+    // is latency-bound (a step of 16 samples takes 0.83 of the time of 32), so the two halves of the batch run as two chains on
+    // two streams.  Each lane has its own workspace and partial-sum tables; the packed weights and the sumsq rows are shared.
+    const int lanes = ctx->opt_train_lanes >= 2 && batch >= 2 ? 2 : 1;
+    const int lane_b0[2] = {0, lanes == 2 ? (batch + 1) / 2 : batch};
+    const int lane_nb[2] = {lane_b0[1], batch - lane_b0[1]};
+    hn_ctx::TrainWs* const ws[2] = {&ctx->tr, &ctx->tr_b};
+    if ((rc = train_reserve(ctx, ctx->tr, lane_nb[0], n_unroll, batch)) != HN_OK) return rc;
+    if (lanes == 2 && (rc = train_reserve(ctx, ctx->tr_b, lane_nb[1], n_unroll, 1)) != HN_OK) return rc;
+    if (lanes == 2 && ctx->train_stream == nullptr) {
+        HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->train_stream, hipStreamNonBlocking));
+        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->train_fork, hipEventDisableTiming));
+        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->train_join, hipEventDisableTiming));
     }
-    Trainer tr{ctx, s, weights, raw_layout(depth), batch, n, depth, ctx->act_kind, (long)ctx->state_len};
-    const size_t fwf = (size_t)batch * 2 * n * n, fst = (size_t)batch * kState * ctx->state_len;
+    const hipStream_t ls[2] = {s, lanes == 2 ? ctx->train_stream : s};
+    for (int l = 0; l < lanes; ++l) {
+        auto& W = *ws[l];
+        W.jobs_set = (W.jobs_set + 1) % hn_ctx::TrainWs::kJobSets;
+        if (W.jobs_in_flight[W.jobs_set]) {   // the tables of the call that last used this set have left the pinned buffer (normally long ago)
+            HN_HIP(ctx, hipEventSynchronize(W.jobs_copied[W.jobs_set]));
+            W.jobs_in_flight[W.jobs_set] = false;
+        }
+        W.last_batch = lane_nb[l];
+    }
+    if (lanes == 1) ctx->tr_b.last_batch = 0;
+    const RawLayout L = raw_layout(depth);
+    const long p2 = 2L * n * n, pst = (long)kState * ctx->state_len;   // floats per sample of a wavefield / of the flat states
+    Trainer tr[2] = {
+        Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
+        Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
+    const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
     struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};
     ctx->precision = HN_PREC_FP32;
     {   // weights in the layouts the kernels read: 3x3 both arrangements (one launch), 8x8 matrix-core fragments
+        auto& W = ctx->tr;
         Pack3Jobs jobs{};
         auto add = [&](const RawDc& dc) {
             jobs.off[jobs.n] = (int)dc.w1; jobs.o[jobs.n] = (short)dc.cm; jobs.i[jobs.n] = (short)dc.cin; ++jobs.n;
             jobs.off[jobs.n] = (int)dc.w2; jobs.o[jobs.n] = (short)dc.co; jobs.i[jobs.n] = (short)dc.cm; ++jobs.n;
         };
-        add(tr.L.inc);
-        for (int d = 0; d < depth; ++d) { add(tr.L.sig[d]); add(tr.L.st[d]); }
-        for (int d = 0; d <= depth; ++d) add(tr.L.dec[d]);
-        hipLaunchKernelGGL(k_pack3, dim3(cdiv(16 * 9 * 8, 256), jobs.n), dim3(256), 0, s, weights, W.w3, (long)tr.L.total, jobs);
+        add(L.inc);
+        for (int d = 0; d < depth; ++d) { add(L.sig[d]); add(L.st[d]); }
+        for (int d = 0; d <= depth; ++d) add(L.dec[d]);
+        hipLaunchKernelGGL(k_pack3, dim3(cdiv(16 * 9 * 8, 256), jobs.n), dim3(256), 0, s, weights, W.w3, (long)L.total, jobs);
+        PackK8Jobs kj{};
         for (int d = 0; d < depth; ++d) {
-            const float* wd = weights + tr.L.down[d].w;
-            const float* wu = weights + tr.L.up[d].w;
-            float* k = W.k8 + (size_t)d * 4 * 4096;
-            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wd, k, 0);             // down, forward
-            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wd, k + 4096, 1);      // down, backward-data: [out, in] read as [in, out] by the transposed kernel
-            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wu, k + 2 * 4096, 1);  // up, forward
-            hipLaunchKernelGGL(k_pack_frag8, dim3(16), dim3(256), 0, s, wu, k + 3 * 4096, 0);  // up, backward-data: [in, out] read as [out, in] by the convolution kernel
+            kj.off[4 * d + 0] = (int)L.down[d].w; kj.up[4 * d + 0] = 0;   // down, forward
+            kj.off[4 * d + 1] = (int)L.down[d].w; kj.up[4 * d + 1] = 1;   // down, backward-data: [out, in] read as [in, out] by the transposed kernel
+            kj.off[4 * d + 2] = (int)L.up[d].w;   kj.up[4 * d + 2] = 1;   // up, forward
+            kj.off[4 * d + 3] = (int)L.up[d].w;   kj.up[4 * d + 3] = 0;   // up, backward-data: [in, out] read as [out, in] by the convolution kernel
         }
+        hipLaunchKernelGGL(k_pack_frag8, dim3(16, 4 * depth), dim3(256), 0, s, weights, W.k8, kj);
+        HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));
     }
-    HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));
-    HN_HIP(ctx, hipMemsetAsync(W.part, 0, sizeof(float) * W.part_floats, s));
-    HN_HIP(ctx, hipMemsetAsync(W.slope_part, 0, sizeof(double) * W.slope_stride * (3 * depth + 2), s));
-    for (int t = 0; t < n_unroll; ++t) {
-        const float* wf_in = t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf;
-        const float* res_in = t == 0 ? res : res_hist + (size_t)(t - 1) * fwf;
-        const float* st_in = t == 0 ? states : st_hist + (size_t)(t - 1) * fst;
-        if ((rc = tr.forward_step(t, wf_in, res_in, st_in, wf_hist + (size_t)t * fwf, res_hist + (size_t)t * fwf, st_hist + (size_t)t * fst, k_sq, src, src_batch)) != HN_OK) return rc;
+    if (lanes == 2) {   // the second lane starts behind the packed weights (and whatever the caller's stream held before)
+        HN_HIP(ctx, hipEventRecord(ctx->train_fork, s));
+        HN_HIP(ctx, hipStreamWaitEvent(ctx->train_stream, ctx->train_fork, 0));
+    }
+    for (int l = 0; l < lanes; ++l) {
+        auto& W = *ws[l];
+        HN_HIP(ctx, hipMemsetAsync(W.part, 0, sizeof(float) * W.part_floats, ls[l]));
+        HN_HIP(ctx, hipMemsetAsync(W.slope_part, 0, sizeof(double) * W.slope_stride * (3 * depth + 2), ls[l]));
+    }
+    // per-lane views of the caller's tensors: sample b0 of a [batch][...] tensor
+    auto in_wf = [&](int t, int l) { return (t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf) + (size_t)lane_b0[l] * p2; };
+    auto in_res = [&](int t, int l) { return (t == 0 ? res : res_hist + (size_t)(t - 1) * fwf) + (size_t)lane_b0[l] * p2; };
+    auto in_st = [&](int t, int l) { return (t == 0 ? states : st_hist + (size_t)(t - 1) * fst) + (size_t)lane_b0[l] * pst; };
+    for (int t = 0; t < n_unroll; ++t)
+        for (int l = 0; l < lanes; ++l) {   // the lanes' launches are enqueued alternately, so both streams always hold work
+            const size_t o2 = (size_t)t * fwf + (size_t)lane_b0[l] * p2, ost = (size_t)t * fst + (size_t)lane_b0[l] * pst;
+            if ((rc = tr[l].forward_step(t, in_wf(t, l), in_res(t, l), in_st(t, l), wf_hist + o2, res_hist + o2, st_hist + ost,
+                                         k_sq + (size_t)lane_b0[l] * n * n, src + (src_batch == 1 ? 0 : (size_t)lane_b0[l] * p2), src_batch == 1 ? 1 : lane_nb[l])) != HN_OK)
+                return rc;
+        }
+    // backward sweep
+    int cur_wf[2] = {0, 0}, cur_st[2] = {0, 0};
+    for (int l = 0; l < lanes; ++l) {
+        auto& W = *ws[l];
+        HN_HIP(ctx, hipMemsetAsync(W.g_wf[0], 0, sizeof(float) * (size_t)lane_nb[l] * p2, ls[l]));
+        HN_HIP(ctx, hipMemsetAsync(W.g_res, 0, sizeof(float) * (size_t)lane_nb[l] * p2, ls[l]));
+        HN_HIP(ctx, hipMemsetAsync(W.g_st[0], 0, sizeof(float) * (size_t)lane_nb[l] * pst, ls[l]));
     }
     const double count = (double)n_unroll * batch * 2.0 * n * n;
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, s, W.sumsq, n_unroll * batch, (float)((double)loss_scale / count), loss);
-    // backward sweep
-    HN_HIP(ctx, hipMemsetAsync(W.g_wf[0], 0, sizeof(float) * fwf, s));
-    HN_HIP(ctx, hipMemsetAsync(W.g_res, 0, sizeof(float) * fwf, s));
-    HN_HIP(ctx, hipMemsetAsync(W.g_st[0], 0, sizeof(float) * fst, s));
-    int cur_wf = 0, cur_st = 0;
     const float loss_c = (float)(2.0 * (double)loss_scale / count);
-    for (int t = n_unroll - 1; t >= 0; --t) {
-        const float* wf_in = t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf;
-        const float* res_in = t == 0 ? res : res_hist + (size_t)(t - 1) * fwf;
-        const float* st_in = t == 0 ? states : st_hist + (size_t)(t - 1) * fst;
-        if ((rc = tr.backward_step(t, wf_in, res_in, st_in, res_hist + (size_t)t * fwf, k_sq, loss_c, cur_wf, cur_st)) != HN_OK) return rc;
+    for (int t = n_unroll - 1; t >= 0; --t)
+        for (int l = 0; l < lanes; ++l)
+            if ((rc = tr[l].backward_step(t, in_wf(t, l), in_res(t, l), in_st(t, l), res_hist + (size_t)t * fwf + (size_t)lane_b0[l] * p2,
+                                          k_sq + (size_t)lane_b0[l] * n * n, loss_c, cur_wf[l], cur_st[l])) != HN_OK)
+                return rc;
+    for (int l = 0; l < lanes; ++l) {
+        auto& W = *ws[l];
+        HN_HIP(ctx, hipEventRecord(W.jobs_copied[W.jobs_set], ls[l]));
+        W.jobs_in_flight[W.jobs_set] = true;
+        // gradients with respect to the inputs: each lane's samples, on its own stream
+        if (grad_wf0) HN_HIP(ctx, hipMemcpyAsync(grad_wf0 + (size_t)lane_b0[l] * p2, W.g_wf[cur_wf[l]], sizeof(float) * (size_t)lane_nb[l] * p2, hipMemcpyDeviceToDevice, ls[l]));
+        if (grad_res0) HN_HIP(ctx, hipMemcpyAsync(grad_res0 + (size_t)lane_b0[l] * p2, W.g_res, sizeof(float) * (size_t)lane_nb[l] * p2, hipMemcpyDeviceToDevice, ls[l]));
+        if (grad_st0) HN_HIP(ctx, hipMemcpyAsync(grad_st0 + (size_t)lane_b0[l] * pst, W.g_st[cur_st[l]], sizeof(float) * (size_t)lane_nb[l] * pst, hipMemcpyDeviceToDevice, ls[l]));
     }
-    HN_HIP(ctx, hipEventRecord(W.jobs_copied, s));
-    W.jobs_in_flight = true;
-    // the table's rows -> the gradient blob, then the slope entries from their own per-block sums
-    hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv((int)tr.L.total, 256)), dim3(256), 0, s, W.part, kPartRows, (int)tr.L.total, grad);
+    if (lanes == 2) {
+        HN_HIP(ctx, hipEventRecord(ctx->train_join, ctx->train_stream));
+        HN_HIP(ctx, hipStreamWaitEvent(s, ctx->train_join, 0));
+    }
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(64), 0, s, ctx->tr.sumsq, n_unroll * batch, (float)((double)loss_scale / count), loss);
+    // the tables' rows -> the gradient blob (first lane, then the second lane added: a fixed order), then the slope entries from their
+    // own per-block sums
+    for (int l = 0; l < lanes; ++l)
+        hipLaunchKernelGGL(k_reduce_rows, dim3(cdiv((int)L.total, 256)), dim3(256), 0, s, ws[l]->part, kPartRows, (int)L.total, grad, l);
     if (ctx->act_kind == HN_ACT_PRELU) {
-        SlopeJobs sj{};
-        auto put = [&](int slot, const RawDc& dc, int d) { sj.rows[slot] = tr.slope_rows(d); sj.off[slot] = (int)dc.slope; };
-        put(tr.slot_inc(), tr.L.inc, 0);
-        for (int d = 0; d < depth; ++d) { put(tr.slot_sig(d), tr.L.sig[d], d); put(tr.slot_st(d), tr.L.st[d], d); }
-        for (int d = 0; d <= depth; ++d) put(tr.slot_dec(d), tr.L.dec[d], d);
-        hipLaunchKernelGGL(k_reduce_slopes, dim3(3 * depth + 2), dim3(256), 0, s, W.slope_part, (int)W.slope_stride, sj, grad);
+        SlopeJobs sj[2] = {};
+        for (int l = 0; l < lanes; ++l) {
+            auto put = [&](int slot, const RawDc& dc, int d) { sj[l].rows[slot] = tr[l].slope_rows(d); sj[l].off[slot] = (int)dc.slope; };
+            put(tr[l].slot_inc(), L.inc, 0);
+            for (int d = 0; d < depth; ++d) { put(tr[l].slot_sig(d), L.sig[d], d); put(tr[l].slot_st(d), L.st[d], d); }
+            for (int d = 0; d <= depth; ++d) put(tr[l].slot_dec(d), L.dec[d], d);
+        }
+        hipLaunchKernelGGL(k_reduce_slopes, dim3(3 * depth + 2), dim3(256), 0, s, ws[0]->slope_part, (int)ws[0]->slope_stride, sj[0],
+                           lanes == 2 ? ws[1]->slope_part : nullptr, (int)ws[1]->slope_stride, sj[1], grad);
     }
-    if (grad_wf0) HN_HIP(ctx, hipMemcpyAsync(grad_wf0, W.g_wf[cur_wf], sizeof(float) * fwf, hipMemcpyDeviceToDevice, s));
-    if (grad_res0) HN_HIP(ctx, hipMemcpyAsync(grad_res0, W.g_res, sizeof(float) * fwf, hipMemcpyDeviceToDevice, s));
-    if (grad_st0) HN_HIP(ctx, hipMemcpyAsync(grad_st0, W.g_st[cur_st], sizeof(float) * fst, hipMemcpyDeviceToDevice, s));
     HN_HIP(ctx, hipGetLastError());
     return HN_OK;
 }
@@ -1089,38 +1235,43 @@ int hn_adam_step(hn_ctx* ctx, float* weights, const float* grad, float* exp_avg,
 
 int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_floats, void* stream) {
     if (!ctx || !out) return fail(ctx, HN_ERR_ARG, "hn_train_peek: NULL argument");
-    auto& W = ctx->tr;
-    if (W.tape == nullptr) return fail(ctx, HN_ERR_STATE, "hn_train_peek: hn_train_grad has not run");
-    const int depth = W.depth;
+    if (ctx->tr.tape == nullptr) return fail(ctx, HN_ERR_STATE, "hn_train_peek: hn_train_grad has not run");
+    const int depth = ctx->tr.depth;
     if (level < 0 || level > depth) return fail(ctx, HN_ERR_ARG, "hn_train_peek: level %d outside [0, %d]", level, depth);
-    const size_t plane = (size_t)(W.n >> level) * (W.n >> level);
-    const float* p = nullptr;
-    size_t ch = kFeat;
+    const size_t plane = (size_t)(ctx->tr.n >> level) * (ctx->tr.n >> level);
     const bool enc = level < depth;
-    switch (kind) {
-        case 0: p = W.tape + W.o_x[level]; break;
-        case 1: if (enc) p = W.tape + W.o_zsig[level]; break;
-        case 2: if (enc) p = W.tape + W.o_out[level]; break;
-        case 3: if (enc) { p = W.tape + W.o_zst[level]; ch = kState; } break;
-        case 4: if (enc) p = W.tape + W.o_u[level]; break;
-        case 5: p = W.tape + W.o_zdec[level]; break;
-        case 6: p = W.tape + W.o_y[level]; break;
-        case 7: if (level == 0) p = W.tape + W.o_zinc; break;
-        case 16: p = W.g_x[level]; break;
-        case 18: if (enc) p = W.g_out[level]; break;
-        case 20: if (enc) p = W.g_u[level]; break;
-        case 22: p = W.g_y[level]; break;
-        default: break;
-    }
-    if (p == nullptr) return fail(ctx, HN_ERR_ARG, "hn_train_peek: no tensor of kind %d at level %d", kind, level);
-    // NOTE: the workspace may have been reserved for a larger batch than the last call used; tensors are dense for the
-    // RESERVED batch only in their leading `batch` samples, which is what callers compare.
-    const int64_t count = (int64_t)((size_t)W.batch * ch * plane);
-    const int64_t ncopy = count < max_floats ? count : max_floats;
     DeviceGuard guard(ctx);
-    if (hipMemcpyAsync(out, p, sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
-        return fail(ctx, HN_ERR_HIP, "hn_train_peek: copy failed");
-    return count;
+    int64_t total = 0;
+    // the lanes of the last call hold consecutive runs of samples: first lane, then second
+    for (hn_ctx::TrainWs* wp : {&ctx->tr, &ctx->tr_b}) {
+        auto& W = *wp;
+        if (W.tape == nullptr || W.last_batch == 0) continue;
+        const float* p = nullptr;
+        size_t ch = kFeat;
+        switch (kind) {
+            case 0: p = W.tape + W.o_x[level]; break;
+            case 1: if (enc) p = W.tape + W.o_zsig[level]; break;
+            case 2: if (enc) p = W.tape + W.o_out[level]; break;
+            case 3: if (enc) { p = W.tape + W.o_zst[level]; ch = kState; } break;
+            case 4: if (enc) p = W.tape + W.o_u[level]; break;
+            case 5: p = W.tape + W.o_zdec[level]; break;
+            case 6: p = W.tape + W.o_y[level]; break;
+            case 7: if (level == 0) p = W.tape + W.o_zinc; break;
+            case 16: p = W.g_x[level]; break;
+            case 18: if (enc) p = W.g_out[level]; break;
+            case 20: if (enc) p = W.g_u[level]; break;
+            case 22: p = W.g_y[level]; break;
+            default: break;
+        }
+        if (p == nullptr) return fail(ctx, HN_ERR_ARG, "hn_train_peek: no tensor of kind %d at level %d", kind, level);
+        const int64_t count = (int64_t)((size_t)W.last_batch * ch * plane);
+        const int64_t room = max_floats - total;
+        const int64_t ncopy = count < room ? count : (room > 0 ? room : 0);
+        if (ncopy > 0 && hipMemcpyAsync(out + total, p, sizeof(float) * (size_t)ncopy, hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess)
+            return fail(ctx, HN_ERR_HIP, "hn_train_peek: copy failed");
+        total += count;
+    }
+    return total;
 }
 
 }  // extern "C"

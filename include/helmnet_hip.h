@@ -78,8 +78,12 @@ enum hn_option {
     HN_OPT_DC_VALU = 6,      /* fp32 DoubleConvs of the largest level (W >= 256) on the packed vector FMA (every FMA useful, same peak as the
                               * fp32 MFMA, whose 3x3 packing fills 75 % of its slots): 0 none (matrix core), 1 inc and the decoder
                               * (default; conv_signal stays on the matrix core: the vector kernels lower the sustained clock), 2 all three */
-    HN_OPT_SPECTRAL_COLS = 7 /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
+    HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
+    HN_OPT_TRAIN_LANES = 8   /* hn_train_grad: 1 (default) the whole batch as one chain of launches; 2: the two halves of the batch as
+                              * two chains on two streams (samples are independent).  Same gradient up to the order of the final
+                              * sum over the halves.  Measured equal to 1: two overlapping chains of 16 samples take as long as
+                              * one chain of 32                                                            */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };

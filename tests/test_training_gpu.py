@@ -253,6 +253,44 @@ def test_gradients_are_bit_reproducible_and_batch_independent(solver, weights, g
     assert torch.equal(one["wavefields"][-1][0], a["wavefields"][-1][1])
 
 
+def test_two_lanes_give_the_gradient_of_one_lane(solver, weights):
+    """HN_OPT_TRAIN_LANES: the halves of the batch as two chains on two streams.  Samples are independent, so everything per sample is
+    bit-identical to the single chain; the weight gradient differs only by the order of the sums over blocks and lanes."""
+    n, b = 64, 5   # odd batch: lanes of 3 and 2 samples
+    solver.set_domain_size(n, source_location=[50, 32])
+    eng = solver.engine()
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=3)).to(DEV)
+    out = solver.forward(sos, num_iterations=4, return_wavefields=True, return_states=True)
+    args = [out["wavefields"][-1].contiguous(), out["residuals"][-1].contiguous(), out["states"][-1].contiguous(),
+            ((1.0 / sos) ** 2).contiguous(), solver.source.detach().repeat(b, 1, 1, 1).contiguous()]
+    blob = torch.from_numpy(pack_weights(weights)).to(DEV)
+    res = {}
+    try:
+        for lanes in (1, 2):
+            eng.set_option("train_lanes", lanes)
+            res[lanes] = eng.train_grad(blob, *args, 3, 1e4, input_grads=True)
+            res[lanes]["peek"] = eng.train_peek("out", 1, b)
+            again = eng.train_grad(blob, *args, 3, 1e4, input_grads=True)
+            assert torch.equal(again["grad"], res[lanes]["grad"])   # reproducible in either mode
+    finally:
+        eng.set_option("train_lanes", 1)
+    one, two = res[1], res[2]
+    for k in ("wavefields", "residuals", "states"):
+        assert torch.equal(one[k], two[k]), k
+    for k in ("grad_wf", "grad_res", "grad_states", "peek"):
+        assert torch.equal(one[k], two[k]), k
+    assert abs(float(one["loss"][0]) - float(two["loss"][0])) <= 1e-6 * abs(float(one["loss"][0]))
+    assert rel(two["grad"], one["grad"]) <= 2e-6
+    # one source map for the whole batch (src_batch = 1) takes the same path
+    a1 = eng.train_grad(blob, *args[:4], args[4][:1].contiguous(), 2, 1e4)
+    eng.set_option("train_lanes", 2)
+    try:
+        a2 = eng.train_grad(blob, *args[:4], args[4][:1].contiguous(), 2, 1e4)
+    finally:
+        eng.set_option("train_lanes", 1)
+    assert torch.equal(a1["residuals"], a2["residuals"]) and rel(a1["grad"], a2["grad"]) <= 2e-6
+
+
 def test_adam_three_steps_match_the_reference_optimiser(solver, weights, g_train):
     n, b, k_sq, src, (wf0, res0, st0) = _fixture_inputs(g_train)
     solver.set_domain_size(n, source_location=[82, 48])

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--unroll", type=int, default=10)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--cpu", action="store_true")
+    ap.add_argument("--side-stream", action="store_true", help="run on a torch side stream instead of the default (null) stream")
+    ap.add_argument("--lanes", type=int, default=None, help="HN_OPT_TRAIN_LANES (1 or 2; default: the library's)")
     a = ap.parse_args()
     from helmnet_amd import IterativeSolver
     from helmnet_amd.engine import pack_weights
@@ -30,6 +32,8 @@ def main():
     loc = [a.n - 14, a.n // 2]
     s.set_domain_size(a.n, source_location=loc)
     eng = s.engine()
+    if a.lanes is not None:
+        eng.set_option("train_lanes", a.lanes)
     sos = torch.from_numpy(ring_sos_batch(a.n, a.batch, seed=5)).to(dev)
     out = s.forward(sos, num_iterations=5, return_wavefields=True, return_states=True)
     wf, res, st = out["wavefields"][-1].contiguous(), out["residuals"][-1].contiguous(), out["states"][-1].contiguous()
@@ -44,16 +48,19 @@ def main():
         eng.adam_step(w, g, m, v, i + 1, 1e-5, (0.9, 0.95), 1e-8, 1e-6, 1.0)
         return o
 
-    for i in range(3):
-        o = step(i)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        o = step(3 + i)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
+    import contextlib
+    with (torch.cuda.stream(torch.cuda.Stream()) if a.side_stream else contextlib.nullcontext()):
+        for i in range(3):
+            o = step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            o = step(3 + i)
+        host = (time.perf_counter() - t0) / a.steps      # the host's share: enqueueing the step's launches (no synchronisation inside)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / a.steps
     fwd_flop = 1055342592.0 * (a.n / 256.0) ** 2 * a.batch * a.unroll
-    line = {"what": "training step (hn_train_grad + hn_adam_step)", "n": a.n, "batch": a.batch, "unroll": a.unroll, "ms_per_step": dt * 1e3,
+    line = {"what": "training step (hn_train_grad + hn_adam_step)", "n": a.n, "batch": a.batch, "unroll": a.unroll, "lanes": a.lanes, "ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": host * 1e3,
             "sample_iterations_per_s": a.batch * a.unroll / dt, "approx_tflops_fwd_plus_bwd": 3 * fwd_flop / dt / 1e12, "loss": float(o["loss"][0])}
     if a.cpu:
         from oracle import helmnet_oracle as O
