@@ -72,11 +72,17 @@ RawLayout raw_layout(int depth) {
 }
 
 // ---- activations and their derivatives (architectures.py:5-44) ---------------------------------------------------------
+// GEN = false: the piecewise-linear activations only (prelu / relu / leakyrelu -- the shipped network).  The kernels are instantiated
+// for both: the smooth activations' code (expm1f, tanhf, erff, log1pf inlined at every staged element) made a 3x3 kernel 35 KB of
+// instructions, which every launch of the latency-bound training step fetched cold.
+template <bool GEN>
 __device__ __forceinline__ float act_fwd(float x, int kind, float slope) {
-    if (kind <= HN_ACT_LEAKYRELU) return x > 0.f ? x : slope * x;
+    if (!GEN || kind <= HN_ACT_LEAKYRELU) return x > 0.f ? x : slope * x;
     return act_general(x, kind);
 }
+template <bool GEN>
 __device__ __forceinline__ float act_grad(float x, int kind, float slope) {
+    if (!GEN) return x > 0.f ? 1.f : slope;
     switch (kind) {
         case HN_ACT_CELU: return x > 0.f ? 1.f : expf(x);
         case HN_ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
@@ -113,6 +119,7 @@ struct WindowStager {
         }
     }
     // channels [0, nch) of the concatenation src[0..2]; `slope` / `act_kind` for groups staged through the activation
+    template <bool GEN>
     __device__ __forceinline__ void stage(const TSrc (&src)[3], int nch, int b, float* dst, int cstride, int act_kind, float slope) const {
         // the three groups' fields as plain values (statically indexed reads, once): a job-table copy of `src` then lives in registers --
         // selecting among src[k].field inside the loop is turned back into an indexed access of the struct in scratch memory
@@ -121,25 +128,41 @@ struct WindowStager {
         const float f0 = src[0].scale, f1 = src[1].scale, f2 = src[2].scale;
         const int a0 = src[0].act, a1 = src[1].act, a2 = src[2].act;
         const int n0 = src[0].nch, n01 = n0 + src[1].nch;
-#pragma unroll 8
-        for (int c = 0; c < nch; ++c) {
-            const bool g1 = c >= n0, g2 = c >= n01;
-            const int cs = g2 ? c - n01 : g1 ? c - n0 : c;
-            const float* sp = g2 ? p2 : g1 ? p1 : p0;
-            const long ssb = g2 ? sb2 : g1 ? sb1 : sb0, ssc = g2 ? sc2 : g1 ? sc1 : sc0;
-            const float sscale = g2 ? f2 : g1 ? f1 : f0;
-            const int sact = g2 ? a2 : g1 ? a1 : a0;
-            const float* p = sp + (long)b * ssb + (long)cs * ssc;
-            float v[NE];
+        // Two phases per group of 8 channels, written out so that the compiler cannot interleave them: first EVERY load of the group
+        // (clamped channel index: no branch between the loads), then the activation / masking / LDS stores.  With the per-channel
+        // branches of the activation between one channel's loads and the next channel's, the loads were issued one channel at a time:
+        // a launch paid `nch` dependent global-memory round trips before its barrier (r3: 10-14 us per small launch).
+        constexpr int G = 8;
+        for (int c0 = 0; c0 < nch; c0 += G) {
+            float v[G][NE];
 #pragma unroll
-            for (int i = 0; i < NE; ++i) v[i] = p[goff[i]];
+            for (int k = 0; k < G; ++k) {
+                const int c = c0 + k < nch ? c0 + k : nch - 1;
+                const bool g1 = c >= n0, g2 = c >= n01;
+                const int cs = g2 ? c - n01 : g1 ? c - n0 : c;
+                const float* sp = g2 ? p2 : g1 ? p1 : p0;
+                const long ssb = g2 ? sb2 : g1 ? sb1 : sb0, ssc = g2 ? sc2 : g1 ? sc1 : sc0;
+                const float* p = sp + (long)b * ssb + (long)cs * ssc;
 #pragma unroll
-            for (int i = 0; i < NE; ++i)
-                if (inmask >> i & 1u) {
-                    float x = v[i];
-                    if (sact) x = act_fwd(x, act_kind, slope);
-                    dst[c * cstride + lidx[i]] = (okmask >> i & 1u) ? x * sscale : 0.f;
+                for (int i = 0; i < NE; ++i) v[k][i] = p[goff[i]];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < G; ++k) {
+                const int c = c0 + k;
+                if (c < nch) {
+                    const bool g1 = c >= n0, g2 = c >= n01;
+                    const float sscale = g2 ? f2 : g1 ? f1 : f0;
+                    const int sact = g2 ? a2 : g1 ? a1 : a0;
+#pragma unroll
+                    for (int i = 0; i < NE; ++i)
+                        if (inmask >> i & 1u) {
+                            float x = v[k][i];
+                            if (sact) x = act_fwd<GEN>(x, act_kind, slope);
+                            dst[c * cstride + lidx[i]] = (okmask >> i & 1u) ? x * sscale : 0.f;
+                        }
                 }
+            }
         }
     }
 };
@@ -200,7 +223,7 @@ struct Conv3Args {
 constexpr int kC3TH = 16, kC3TW = 32, kC3PI = 36;
 
 // one 16 x 32 tile of sample b; `a` lives in the kernel-argument segment (scalar loads, also where it is indexed)
-template <int CO, bool EPI_ACT>
+template <int CO, bool EPI_ACT, bool GEN>
 __device__ __forceinline__ void conv3_tile(const Conv3Args& a, int x0, int y0, int b, int block_in_layer) {
     constexpr int TH = kC3TH, TW = kC3TW, PI = kC3PI, IR = TH + 2, IC = TW + 2;
     extern __shared__ __attribute__((aligned(16))) float s_in[];   // [CI][IR][PI] + 8
@@ -211,10 +234,40 @@ __device__ __forceinline__ void conv3_tile(const Conv3Args& a, int x0, int y0, i
     {
         WindowStager<IR, IC, 512> st;
         st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
-        st.stage(a.src, CI, b, s_in, IR * PI, a.act_kind, slope);
+        st.template stage<GEN>(a.src, CI, b, s_in, IR * PI, a.act_kind, slope);
+    }
+    const int ry = tid >> 5, cx = tid & 31;   // one output pixel per thread: (y0 + ry, x0 + cx), all CO channels
+    const int y = y0 + ry, x = x0 + cx;
+    const bool live = y < a.H && x < a.W;
+    const long pix = live ? (long)y * a.W + x : 0;
+    // Everything the epilogue needs from memory is requested HERE, behind the staging loads and in front of the barrier, so that it
+    // arrives while the FMA loop runs: the biases (scalar loads), z (EPI_ACT) and the old values of accumulated destinations.  (As
+    // part of the epilogue they were CO dependent round trips -- a vector load of bias[c], scalar loads of dst[.], a
+    // read-modify-write -- one after the other: most of what a small launch cost, r3.)
+    const float *dp0 = a.dst[0].p, *dp1 = a.dst[1].p, *dp2 = a.dst[2].p;   // the groups' fields as values: no indexed access of `a`
+    const long dsb0 = a.dst[0].sb, dsb1 = a.dst[1].sb, dsb2 = a.dst[2].sb, dsc0 = a.dst[0].sc, dsc1 = a.dst[1].sc, dsc2 = a.dst[2].sc;
+    const float df0 = a.dst[0].scale, df1 = a.dst[1].scale, df2 = a.dst[2].scale;
+    const int da0 = a.dst[0].accum, da1 = a.dst[1].accum, da2 = a.dst[2].accum;
+    const int dn0 = a.dst[0].nch, dn01 = dn0 + a.dst[1].nch;
+    float bias[CO], zz[CO], old[CO];
+    {
+        const CfPtr bp = cf(a.bias);
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            bias[c] = a.bias != nullptr ? bp[c] : 0.f;
+            zz[c] = 0.f;
+            if (EPI_ACT) zz[c] = a.z[(long)b * a.z_sb + (long)c * a.z_sc + pix];
+            const bool g1 = c >= dn0, g2 = c >= dn01;
+            const float* dp = g2 ? dp2 : g1 ? dp1 : dp0;
+            const int acc_on = g2 ? da2 : g1 ? da1 : da0;
+            old[c] = 0.f;
+            if (dp != nullptr && acc_on) {
+                const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
+                old[c] = dp[(long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix];
+            }
+        }
     }
     __syncthreads();
-    const int ry = tid >> 5, cx = tid & 31;   // one output pixel per thread: (y0 + ry, x0 + cx), all CO channels
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
@@ -233,25 +286,21 @@ __device__ __forceinline__ void conv3_tile(const Conv3Args& a, int x0, int y0, i
 #pragma unroll
             for (int c = 0; c < CO; ++c) acc[c] = fmaf(wq[k * CO + c], v[k], acc[c]);
     }
-    const int y = y0 + ry, x = x0 + cx;
     double sp = 0.0;   // the slope gradient is ONE number summed over every pixel of the layer with both signs: kept in float64
-    if (y < a.H && x < a.W) {
+    if (live) {
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
-            const float bias = a.bias != nullptr ? a.bias[c] : 0.f;
-            int cd = c, di = 0;
-            if (cd >= a.dst[0].nch) { cd -= a.dst[0].nch; di = 1; if (cd >= a.dst[1].nch) { cd -= a.dst[1].nch; di = 2; } }
-            const TDst& ds = a.dst[di];
-            float v = acc[c] + bias;
+            float v = acc[c] + bias[c];
             if (EPI_ACT) {
-                const float zz = a.z[(long)b * a.z_sb + (long)c * a.z_sc + (long)y * a.W + x];
-                if (zz <= 0.f) sp += (double)v * (double)zz;
-                v *= act_grad(zz, a.act_kind, slope);
+                if (zz[c] <= 0.f) sp += (double)v * (double)zz[c];
+                v *= act_grad<GEN>(zz[c], a.act_kind, slope);
             }
-            if (ds.p != nullptr) {
-                float* q = ds.p + (long)b * ds.sb + (long)cd * ds.sc + (long)y * a.W + x;
-                v *= ds.scale;
-                *q = ds.accum ? *q + v : v;
+            const bool g1 = c >= dn0, g2 = c >= dn01;
+            float* dp = const_cast<float*>(g2 ? dp2 : g1 ? dp1 : dp0);
+            if (dp != nullptr) {
+                const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
+                float* q = dp + (long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix;
+                *q = fmaf(v, g2 ? df2 : g1 ? df1 : df0, 0.f) + old[c];
             }
         }
     }
@@ -269,9 +318,9 @@ __device__ __forceinline__ void conv3_tile(const Conv3Args& a, int x0, int y0, i
     }
 }
 
-template <int CO, bool EPI_ACT>
+template <int CO, bool EPI_ACT, bool GEN>
 __global__ __launch_bounds__(512) void k_conv3(Conv3Args a) {
-    conv3_tile<CO, EPI_ACT>(a, blockIdx.x * kC3TW, blockIdx.y * kC3TH, blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+    conv3_tile<CO, EPI_ACT, GEN>(a, blockIdx.x * kC3TW, blockIdx.y * kC3TH, blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
 }
 
 // The same layer type at several levels of the UNet in ONE launch (the hidden-state DoubleConvs: off the chain within an
@@ -282,13 +331,13 @@ struct Conv3Batch {
     int tiles_x[kMaxDepth], tiles_y[kMaxDepth];
     int njobs;
 };
-template <int CO, bool EPI_ACT>
+template <int CO, bool EPI_ACT, bool GEN>
 __global__ __launch_bounds__(512) void k_conv3_batch(Conv3Batch q) {
     int j = 0;
     while (j + 1 < q.njobs && (int)blockIdx.x >= q.blk0[j + 1]) ++j;
     const int bid = (int)blockIdx.x - q.blk0[j];
     const int tx = bid % q.tiles_x[j], r = bid / q.tiles_x[j], ty = r % q.tiles_y[j], b = r / q.tiles_y[j];
-    conv3_tile<CO, EPI_ACT>(q.job[j], tx * kC3TW, ty * kC3TH, b, bid);
+    conv3_tile<CO, EPI_ACT, GEN>(q.job[j], tx * kC3TW, ty * kC3TH, b, bid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -311,7 +360,7 @@ struct Wg3Args {
 };
 
 constexpr int kWgTH = 16;  // tile rows of the weight-gradient kernel (8-row tiles, twice the blocks: measured the same, r3)
-template <int CO>
+template <int CO, bool GEN>
 __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__ jobs, int njobs) {
     const Wg3Args a = load_job(jobs, find_job(jobs, njobs, (int)blockIdx.x));
     const int bid = (int)blockIdx.x - a.blk0;
@@ -351,7 +400,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
                 }
             WindowStager<IR, IC, 256> st;
             st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
-            st.stage(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);
+            st.template stage<GEN>(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);
 #pragma unroll
             for (int c = 0; c < CO; ++c)
 #pragma unroll
@@ -444,7 +493,7 @@ __global__ __launch_bounds__(512) void k_conv8_wgrad(const Wg8Args* __restrict__
             const TSrc big[3] = {TSrc{a.bg, a.bg_sb, a.bg_sc, kFeat, 1.f, 0}, TSrc{nullptr, 0, 0, 0, 1.f, 0}, TSrc{nullptr, 0, 0, 0, 1.f, 0}};
             WindowStager<BR, BC, 512> st;
             st.setup(tid, 2 * Y0 - 3, 2 * X0 - 3, hb, wb, PB);
-            st.stage(big, kFeat, n, s_b, BR * PB, 0, 0.f);
+            st.template stage<false>(big, kFeat, n, s_b, BR * PB, 0, 0.f);
         }
         {   // small tensor tile, channel-interleaved: s_s[(Y * TX + X) * 8 + c]; 128 positions x 8 channels = 2 per thread
             float sv[2];
@@ -656,8 +705,11 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
 // ---- host-side drivers -------------------------------------------------------------------------------------------------
 template <int CO>
 void launch_conv3_co(const Conv3Args& a, bool epi, dim3 grid, size_t lds, hipStream_t s) {
-    if (epi) hipLaunchKernelGGL((k_conv3<CO, true>), grid, dim3(512), lds, s, a);
-    else hipLaunchKernelGGL((k_conv3<CO, false>), grid, dim3(512), lds, s, a);
+    const bool gen = a.act_kind > HN_ACT_LEAKYRELU;
+    if (epi && gen) hipLaunchKernelGGL((k_conv3<CO, true, true>), grid, dim3(512), lds, s, a);
+    else if (epi) hipLaunchKernelGGL((k_conv3<CO, true, false>), grid, dim3(512), lds, s, a);
+    else if (gen) hipLaunchKernelGGL((k_conv3<CO, false, true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((k_conv3<CO, false, false>), grid, dim3(512), lds, s, a);
 }
 int launch_conv3(hn_ctx* ctx, int co, bool epi, const Conv3Args& a, int batch, hipStream_t s) {
     const dim3 grid(cdiv(a.W, kC3TW), cdiv(a.H, kC3TH), batch);
@@ -690,9 +742,13 @@ int launch_conv3_batch(hn_ctx* ctx, int co, bool epi, Conv3Batch& q, int batch, 
     }
     q.blk0[q.njobs] = total;
     if (total == 0) return HN_OK;
-    if (co == 2 && !epi) hipLaunchKernelGGL((k_conv3_batch<2, false>), dim3(total), dim3(512), lds, s, q);
-    else if (co == 2 && epi) hipLaunchKernelGGL((k_conv3_batch<2, true>), dim3(total), dim3(512), lds, s, q);
-    else if (co == 10 && !epi) hipLaunchKernelGGL((k_conv3_batch<10, false>), dim3(total), dim3(512), lds, s, q);
+    const bool gen = q.job[0].act_kind > HN_ACT_LEAKYRELU;
+    if (co == 2 && !epi && !gen) hipLaunchKernelGGL((k_conv3_batch<2, false, false>), dim3(total), dim3(512), lds, s, q);
+    else if (co == 2 && !epi) hipLaunchKernelGGL((k_conv3_batch<2, false, true>), dim3(total), dim3(512), lds, s, q);
+    else if (co == 2 && epi && !gen) hipLaunchKernelGGL((k_conv3_batch<2, true, false>), dim3(total), dim3(512), lds, s, q);
+    else if (co == 2 && epi) hipLaunchKernelGGL((k_conv3_batch<2, true, true>), dim3(total), dim3(512), lds, s, q);
+    else if (co == 10 && !epi && !gen) hipLaunchKernelGGL((k_conv3_batch<10, false, false>), dim3(total), dim3(512), lds, s, q);
+    else if (co == 10 && !epi) hipLaunchKernelGGL((k_conv3_batch<10, false, true>), dim3(total), dim3(512), lds, s, q);
     else return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no batched 3x3 kernel for %d output channels (epilogue %d)", co, (int)epi);
     return HN_OK;
 }
@@ -791,8 +847,13 @@ struct Trainer {
         if (b2) std::memcpy(h + b8, jobs2.data(), b2);
         if (bk) std::memcpy(h + b8 + b2, jobsk.data(), bk);
         HN_HIP(ctx, hipMemcpyAsync(dv, h, b8 + b2 + bk, hipMemcpyHostToDevice, s));
-        if (n8) hipLaunchKernelGGL(k_conv3_wgrad<8>, dim3(n8), dim3(256), lds8, s, reinterpret_cast<const Wg3Args*>(dv), (int)jobs8.size());
-        if (n2) hipLaunchKernelGGL(k_conv3_wgrad<2>, dim3(n2), dim3(256), lds2, s, reinterpret_cast<const Wg3Args*>(dv + b8), (int)jobs2.size());
+        const bool gen = act > HN_ACT_LEAKYRELU;
+        const Wg3Args* d8 = reinterpret_cast<const Wg3Args*>(dv);
+        const Wg3Args* d2 = reinterpret_cast<const Wg3Args*>(dv + b8);
+        if (n8 && gen) hipLaunchKernelGGL((k_conv3_wgrad<8, true>), dim3(n8), dim3(256), lds8, s, d8, (int)jobs8.size());
+        else if (n8) hipLaunchKernelGGL((k_conv3_wgrad<8, false>), dim3(n8), dim3(256), lds8, s, d8, (int)jobs8.size());
+        if (n2 && gen) hipLaunchKernelGGL((k_conv3_wgrad<2, true>), dim3(n2), dim3(256), lds2, s, d2, (int)jobs2.size());
+        else if (n2) hipLaunchKernelGGL((k_conv3_wgrad<2, false>), dim3(n2), dim3(256), lds2, s, d2, (int)jobs2.size());
         if (nk) hipLaunchKernelGGL(k_conv8_wgrad, dim3(nk), dim3(512), 0, s, reinterpret_cast<const Wg8Args*>(dv + b8 + b2), (int)jobsk.size());
         jobs8.clear(); jobs2.clear(); jobsk.clear();
         return HN_OK;
