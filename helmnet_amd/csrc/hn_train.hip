@@ -341,6 +341,121 @@ __global__ __launch_bounds__(512) void k_conv3_batch(Conv3Batch q) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// A whole DoubleConv (or its backward-data pass) of a SMALL level as one launch: one workgroup per sample, the S x S image
+// (S <= 32) entirely in LDS.  At the training size the three deepest levels are 24^2, 12^2 and 6^2: a 3x3 launch there is 32
+// workgroups and costs its 10 us floor whatever it computes (tools/ubench_launch_floor.hip), so two convolutions in one launch
+// are one floor instead of two.
+//   first : C1 channels = conv(a1.src) (+ bias, EPI: * act'(z), slope sum)  -> a1.dst[0] (global: the tape's z, or g_z) and the
+//           LDS mid planes (through the activation when a2.src[0].act is set: the forward pass)
+//   second: C2 channels = conv(mid) (+ bias) -> a2.dst[0..2] (accumulating where asked)
+// ------------------------------------------------------------------------------------------------------------------
+struct DcSmallArgs { Conv3Args a1, a2; };
+constexpr int kSmallS = 32, kSmallR = kSmallS + 2, kSmallP = kSmallS + 3;   // planes of 34 rows x 35 floats: image + zero border
+constexpr int kSmallNT = 1024;   // one thread per pixel of the largest image: a convolution is ONE pass (with 512 threads 24^2 took two)
+
+template <int CO, bool EPI_ACT, bool GEN, bool FROM_LDS>
+__device__ __forceinline__ void small_conv(const Conv3Args& a, int CI, const float* s_in, float* s_mid, bool mid_act, int b, int S, float slope,
+                                           double& sp) {
+    constexpr int R = kSmallR, P = kSmallP;
+    const int tid = threadIdx.x;
+    const float *dp0 = a.dst[0].p, *dp1 = a.dst[1].p, *dp2 = a.dst[2].p;
+    const long dsb0 = a.dst[0].sb, dsb1 = a.dst[1].sb, dsb2 = a.dst[2].sb, dsc0 = a.dst[0].sc, dsc1 = a.dst[1].sc, dsc2 = a.dst[2].sc;
+    const float df0 = a.dst[0].scale, df1 = a.dst[1].scale, df2 = a.dst[2].scale;
+    const int da0 = a.dst[0].accum, da1 = a.dst[1].accum, da2 = a.dst[2].accum;
+    const int dn0 = a.dst[0].nch, dn01 = dn0 + a.dst[1].nch;
+    const CfPtr wc = cf(a.wpk), bp = cf(a.bias);
+    (void)FROM_LDS;
+    for (int p = tid; p < S * S; p += kSmallNT) {
+        const int y = p / S, x = p - y * S;
+        const long pix = (long)y * S + x;
+        float bias[CO], zz[CO], old[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {   // requested ahead of the FMA loop (see conv3_tile)
+            bias[c] = a.bias != nullptr ? bp[c] : 0.f;
+            zz[c] = 0.f;
+            if (EPI_ACT) zz[c] = a.z[(long)b * a.z_sb + (long)c * a.z_sc + pix];
+            const bool g1 = c >= dn0, g2 = c >= dn01;
+            const float* dp = g2 ? dp2 : g1 ? dp1 : dp0;
+            old[c] = 0.f;
+            if (dp != nullptr && (g2 ? da2 : g1 ? da1 : da0)) {
+                const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
+                old[c] = dp[(long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix];
+            }
+        }
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+#pragma unroll CO <= 8 ? 2 : 1
+        for (int ci = 0; ci < CI; ++ci) {
+            const float* t = &s_in[(ci * R + y) * P + x];
+            const CfPtr wq = wc + ci * 9 * CO;
+            float v[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = t[dy * P + dx];
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+#pragma unroll
+                for (int c = 0; c < CO; ++c) acc[c] = fmaf(wq[k * CO + c], v[k], acc[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < CO; ++c) {
+            float v = acc[c] + bias[c];
+            if (EPI_ACT) {
+                if (zz[c] <= 0.f) sp += (double)v * (double)zz[c];
+                v *= act_grad<GEN>(zz[c], a.act_kind, slope);
+            }
+            if (s_mid != nullptr) s_mid[(c * R + y + 1) * P + x + 1] = mid_act ? act_fwd<GEN>(v, a.act_kind, slope) : v;
+            const bool g1 = c >= dn0, g2 = c >= dn01;
+            float* dp = const_cast<float*>(g2 ? dp2 : g1 ? dp1 : dp0);
+            if (dp != nullptr) {
+                const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
+                float* q = dp + (long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix;
+                *q = fmaf(v, g2 ? df2 : g1 ? df1 : df0, 0.f) + old[c];
+            }
+        }
+    }
+}
+
+template <int C1, int C2, bool EPI_ACT, bool GEN>
+__global__ __launch_bounds__(kSmallNT) void k_dc_small(DcSmallArgs q) {
+    constexpr int R = kSmallR, P = kSmallP;
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // input planes [CI][34][35], then the mid planes [C1][34][35]
+    __shared__ double s_red[kSmallNT / 64];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const Conv3Args& a1 = q.a1;
+    const int S = a1.H;
+    const int CI = a1.src[0].nch + a1.src[1].nch + a1.src[2].nch;
+    const float slope = a1.slope != nullptr ? a1.slope[0] : 0.f;
+    float* const s_in = s_dyn;
+    float* const s_mid = s_dyn + CI * R * P;
+    {
+        WindowStager<R, R, kSmallNT> st;   // the 34 x 34 window around the image: zero outside it
+        st.setup(tid, -1, -1, S, S, P);
+        st.template stage<GEN>(a1.src, CI, b, s_in, R * P, a1.act_kind, slope);
+        for (int i = tid; i < C1 * R * P; i += kSmallNT) s_mid[i] = 0.f;   // zero border of the mid planes (the interior is overwritten)
+    }
+    __syncthreads();
+    double sp = 0.0;
+    small_conv<C1, EPI_ACT, GEN, false>(a1, CI, s_in, s_mid, q.a2.src[0].act != 0, b, S, slope, sp);
+    if (EPI_ACT && a1.slope_part != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
+        if ((tid & 63) == 0) s_red[tid >> 6] = sp;
+    }
+    __syncthreads();
+    if (EPI_ACT && a1.slope_part != nullptr && tid == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < kSmallNT / 64; ++wv) tot += s_red[wv];
+        a1.slope_part[b] += tot;
+    }
+    double unused = 0.0;
+    small_conv<C2, false, GEN, true>(q.a2, C1, s_mid, nullptr, false, b, S, slope, unused);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight + bias gradient of a 3x3 convolution:  dW[co][ci][ky][kx] = sum_{b,y,x} g[co](y, x) * in[ci](y + ky - 1, x + kx - 1),
 // db[co] = sum g[co].  Thread = one (ci, ky) row of taps (the bias is one more "row" with in == 1) x 3 kx x all CO channels x a
 // subset of the tile rows: walking along x it keeps a 3-wide sliding window of the input, so a pixel costs one LDS read of
@@ -753,6 +868,31 @@ int launch_conv3_batch(hn_ctx* ctx, int co, bool epi, Conv3Batch& q, int batch, 
     return HN_OK;
 }
 
+// C1 = channels of the first convolution's output (the mid tensor), C2 = of the second's
+int launch_dc_small(hn_ctx* ctx, int c1, int c2, bool epi, const DcSmallArgs& q, int batch, hipStream_t s) {
+    const int ci = q.a1.src[0].nch + q.a1.src[1].nch + q.a1.src[2].nch;
+    const size_t lds = sizeof(float) * (size_t)(ci + c1) * kSmallR * kSmallP;
+    const bool gen = q.a1.act_kind > HN_ACT_LEAKYRELU;
+    const void* fn = nullptr;
+#define HN_DCS(A, B, E) (gen ? reinterpret_cast<const void*>(k_dc_small<A, B, E, true>) : reinterpret_cast<const void*>(k_dc_small<A, B, E, false>))
+    if (c1 == 8 && c2 == 8 && !epi) fn = HN_DCS(8, 8, false);
+    else if (c1 == 8 && c2 == 8 && epi) fn = HN_DCS(8, 8, true);
+    else if (c1 == 8 && c2 == 10 && epi) fn = HN_DCS(8, 10, true);
+    else if (c1 == 8 && c2 == 16 && epi) fn = HN_DCS(8, 16, true);
+#undef HN_DCS
+    if (fn == nullptr) return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no small DoubleConv kernel for %d -> %d channels (epilogue %d)", c1, c2, (int)epi);
+    static bool attr_done[2][4] = {};   // the > 64 KB dynamic-LDS opt-in is per function (process-wide, idempotent)
+    const int slot = !epi ? 0 : c2 == 8 ? 1 : c2 == 10 ? 2 : 3;
+    if (!attr_done[gen][slot]) {
+        HN_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * (16 + 8) * kSmallR * kSmallP)));
+        attr_done[gen][slot] = true;
+    }
+    DcSmallArgs args = q;
+    void* params[] = {&args};
+    HN_HIP(ctx, hipLaunchKernel(fn, dim3(batch), dim3(kSmallNT), params, lds, s));
+    return HN_OK;
+}
+
 constexpr int kPartRows = 640;   // rows of the partials table = the most blocks a weight-gradient launch uses (96^2 x 32: 576 tiles of 16 x 32, one each)
 
 struct Trainer {
@@ -796,7 +936,13 @@ struct Trainer {
         return launch_conv3(ctx, w_o, false, fwd_args(src, w_off, b_off, slope_off, dst, d), B, s);
     }
     // DoubleConv forward with tape: z = conv1(in) (stored), out = conv2(act(z))
+    bool small_level(int d) const { return side(d) <= kSmallS; }
     int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d) {
+        if (small_level(d) && dc.cm == kFeat && dc.co == kFeat) {   // both convolutions in one launch (k_dc_small)
+            const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
+            const DcSmallArgs q{fwd_args(in, dc.w1, dc.b1, dc.slope, featdst(z, d, dc.cm), d), fwd_args(mid, dc.w2, dc.b2, dc.slope, out, d)};
+            return launch_dc_small(ctx, dc.cm, dc.co, false, q, B, s);
+        }
         int rc = conv_fwd(in, dc.w1, dc.b1, dc.cm, dc.slope, featdst(z, d, dc.cm), d);
         if (rc != HN_OK) return rc;
         const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
@@ -891,6 +1037,10 @@ struct Trainer {
     int dc_bwd(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
         int rc;
         if ((rc = dc_wgrads(dc, slot, in, z, g_out, d)) != HN_OK) return rc;
+        if (small_level(d) && dc.cm == kFeat && (dc.cin == kFeat || dc.cin == kFeat + kState || dc.cin == 2 * kFeat)) {
+            const DcSmallArgs q{bwd2_args(dc, slot, z, g_out, d), bwd1_args(dc, slot, gin, d)};
+            return launch_dc_small(ctx, dc.cm, dc.cin, true, q, B, s);
+        }
         if ((rc = launch_conv3(ctx, dc.cm, true, bwd2_args(dc, slot, z, g_out, d), B, s)) != HN_OK) return rc;
         return launch_conv3(ctx, dc.cin, false, bwd1_args(dc, slot, gin, d), B, s);
     }
