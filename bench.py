@@ -182,6 +182,37 @@ def secondary(solver, dev, n, B, precision, steps, warmup):
             "residual_rmse_max": float(rmse[steps - 1].max().item())}
 
 
+def secondary_train_step(solver, dev, n=96, B=32, unroll=10, steps=8, warmup=3):
+    """one training step (hn_train_grad + hn_adam_step) at the reference's training shape -- 96^2, batch 32, 10
+    unrolled iterations (hybridnet.py:385-413) -- from a realistic replay-buffer sample (5 solver iterations in)."""
+    from helmnet_amd.engine import pack_weights
+    solver.set_unet_precision("fp32")
+    eng, _, (wf, res, st, k_sq, src) = make_problem(solver, n, B, [n - 14, n // 2], 5, dev, False)
+    eng.step(wf, res, st, k_sq, src, 5)
+    src_b = src.repeat(B, 1, 1, 1).contiguous() if src.shape[0] == 1 else src
+    w = torch.from_numpy(pack_weights(dict(solver.f.state_dict()))).to(dev)
+    m, v, g = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
+
+    def step(i):
+        o = eng.train_grad(w, wf, res, st, k_sq, src_b, unroll, 1e4, grad=g)
+        eng.adam_step(w, g, m, v, i + 1, 1e-5, (0.9, 0.95), 1e-8, 1e-6, 1.0)
+        return o
+
+    for i in range(warmup):
+        o = step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        o = step(warmup + i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    fwd_flop = 2.0 * sum(kernel_macs(n).values()) * B * unroll
+    return {"workload": f"training step: {n}x{n}, batch={B}, {unroll} unrolled iterations, forward + backward + Adam (SURVEY 8 f4)",
+            "dtype": "f32", "value": round(dt * 1e3, 3), "unit": "ms per training step", "higher_is_better": False, "steps": steps,
+            "warmup": warmup, "sample_iterations_per_s": round(B * unroll / dt, 1),
+            "approx_tflops_forward_plus_backward": round(3 * fwd_flop / dt / 1e12, 2), "loss": float(o["loss"][0])}
+
+
 STEP_COMPULSORY_BYTES_256 = 3751936.0   # SURVEY.md 8(d): read 4[(2+2+1) N^2 + 2 sum N_d^2] + write 4[(2+2) N^2 + 2 sum N_d^2] at N = 256
 
 
@@ -412,7 +443,8 @@ def main():
             # driver-visible side measurements: same process, a few seconds each
             line["secondary"] = [secondary(solver, dev, 512, 16, "fp32", 40, 10),
                                  secondary(solver, dev, 256, 32, "bf16x3", 60, 10),
-                                 secondary(solver, dev, 512, 16, "fp16", 40, 10)]
+                                 secondary(solver, dev, 512, 16, "fp16", 40, 10),
+                                 secondary_train_step(solver, dev)]
             line["secondary_note"] = ("bf16x3 is an fp32-accurate EMULATION (3-term bf16 split, 6 product terms, fp32 accumulate), "
                                       "fp16 is the mixed-precision configuration of BASELINE configs[4]; neither replaces the fp32 headline")
         print(json.dumps(line), flush=True)

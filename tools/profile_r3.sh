@@ -21,5 +21,8 @@ python tools/bench_train.py --cpu > $O/bench_train.json 2>/dev/null
 python tools/bench_train.py --batch 128 --steps 5 > $O/bench_train_b128.json 2>/dev/null
 python tools/bench_train.py --n 256 --batch 8 --steps 5 > $O/bench_train_256.json 2>/dev/null
 python tools/ab_cols.py 2>/dev/null > $O/cols_ab.txt
+python tools/ab_512.py 2>/dev/null > $O/ab_512.txt
+tools/bin/ubench_launch_floor > $O/ubench_launch_floor.txt 2>/dev/null
+tools/bin/ubench_two_queues > $O/ubench_two_queues.txt 2>/dev/null
 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $O/pytest_gpu.txt
 du -sh $O; cat $O/pytest_gpu.txt; cat $O/bench_k20.json | cut -c1-400; cat $O/bench_train*.json
