@@ -474,7 +474,8 @@ struct Wg3Args {
     int blk0, nblk;     // this job's run of blocks within the batched launch
 };
 
-constexpr int kWgTH = 16;  // tile rows of the weight-gradient kernel (8-row tiles, twice the blocks: measured the same, r3)
+constexpr int kWgTH = 8;   // tile rows of the weight-gradient kernel: 32 KB of LDS per block, 4 blocks per CU (16-row tiles: 56 KB, 2 per CU; in the
+                           // batched launch 133 -> 118 us.  As one launch per layer the two measured the same: the launch floor hid it)
 template <int CO, bool GEN>
 __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__ jobs, int njobs) {
     const Wg3Args a = load_job(jobs, find_job(jobs, njobs, (int)blockIdx.x));
