@@ -22,8 +22,15 @@
 //     at the end of the call sums the rows in a fixed order into the gradient blob.  A table cell belongs to one block within a
 //     launch and launches are ordered by the stream, so the updates (plain read-modify-writes, or no-return atomics where they
 //     are coalesced) happen in a fixed order: gradients are bit-reproducible.
+//     Weight gradients are off the backward chain: the pass files them and runs the 36 of an iteration as three batched launches
+//     from a job table (flush_wgrads).
+//   * A small dependent launch costs ~10 us whatever it computes (tools/ubench_launch_floor.hip), and a step is one chain of them:
+//     launches that are not on the chain are batched (the hidden-state DoubleConvs of all levels: k_conv3_batch), and at the
+//     levels up to 32^2 a DoubleConv, or its backward-data pass, is ONE per-sample launch with the image in LDS (k_dc_small).
 //   * The spectral operator is linear: its backward is the adjoint pass spec_adjoint (hn_spectral.hip).
-//   * Everything is enqueued on the caller's stream; nothing synchronises with the host (except when the workspace has to grow).
+//   * Everything is enqueued on the caller's stream (HN_OPT_TRAIN_LANES 2: the second half of the batch on an internal stream,
+//     forked and joined with events); the host waits only when the workspace has to grow, or for a job table of four calls ago
+//     to have left its pinned buffer.
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -353,7 +360,7 @@ struct DcSmallArgs { Conv3Args a1, a2; };
 constexpr int kSmallS = 32, kSmallR = kSmallS + 2, kSmallP = kSmallS + 3;   // planes of 34 rows x 35 floats: image + zero border
 constexpr int kSmallNT = 1024;   // one thread per pixel of the largest image: a convolution is ONE pass (with 512 threads 24^2 took two)
 
-template <int CO, bool EPI_ACT, bool GEN, bool FROM_LDS>
+template <int CO, bool EPI_ACT, bool GEN>
 __device__ __forceinline__ void small_conv(const Conv3Args& a, int CI, const float* s_in, float* s_mid, bool mid_act, int b, int S, float slope,
                                            double& sp) {
     constexpr int R = kSmallR, P = kSmallP;
@@ -364,7 +371,6 @@ __device__ __forceinline__ void small_conv(const Conv3Args& a, int CI, const flo
     const int da0 = a.dst[0].accum, da1 = a.dst[1].accum, da2 = a.dst[2].accum;
     const int dn0 = a.dst[0].nch, dn01 = dn0 + a.dst[1].nch;
     const CfPtr wc = cf(a.wpk), bp = cf(a.bias);
-    (void)FROM_LDS;
     for (int p = tid; p < S * S; p += kSmallNT) {
         const int y = p / S, x = p - y * S;
         const long pix = (long)y * S + x;
@@ -438,7 +444,7 @@ __global__ __launch_bounds__(kSmallNT) void k_dc_small(DcSmallArgs q) {
     }
     __syncthreads();
     double sp = 0.0;
-    small_conv<C1, EPI_ACT, GEN, false>(a1, CI, s_in, s_mid, q.a2.src[0].act != 0, b, S, slope, sp);
+    small_conv<C1, EPI_ACT, GEN>(a1, CI, s_in, s_mid, q.a2.src[0].act != 0, b, S, slope, sp);
     if (EPI_ACT && a1.slope_part != nullptr) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
@@ -452,7 +458,7 @@ __global__ __launch_bounds__(kSmallNT) void k_dc_small(DcSmallArgs q) {
         a1.slope_part[b] += tot;
     }
     double unused = 0.0;
-    small_conv<C2, false, GEN, true>(q.a2, C1, s_mid, nullptr, false, b, S, slope, unused);
+    small_conv<C2, false, GEN>(q.a2, C1, s_mid, nullptr, false, b, S, slope, unused);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
