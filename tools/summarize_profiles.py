@@ -28,14 +28,25 @@ def short(name):
     return name.split("(")[0]
 
 
-ks = glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv"))
+def newest(paths):
+    """gpurun MERGES a run's files into the local directory: a directory that was used twice holds both runs' files."""
+    return max(paths, key=os.path.getmtime) if paths else None
+
+
+ks = newest(glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")))
 if ks:
-    shutil.copy(ks[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+    shutil.copy(ks, os.path.join(out, f"{tag}_kernel_stats.csv"))
+kt = newest(glob.glob(os.path.join(src, "kt_train", "*", "*_kernel_stats.csv")))
+if kt:
+    shutil.copy(kt, os.path.join(out, f"{tag}_train_kernel_stats.csv"))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(lambda: collections.defaultdict(set))
 dur = collections.defaultdict(lambda: collections.defaultdict(float))
+by_run = collections.defaultdict(list)
 for path in glob.glob(os.path.join(src, "*", "*", "*_counter_collection.csv")):
-    run = path.split(os.sep)[-3]
+    by_run[path.split(os.sep)[-3]].append(path)
+for run, paths in by_run.items():
+    path = newest(paths)   # one file per counter pass: the latest run's
     for r in csv.DictReader(open(path)):
         k = short(r["Kernel_Name"])
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
