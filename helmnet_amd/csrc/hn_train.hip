@@ -126,7 +126,7 @@ struct WindowStager {
         }
     }
     // channels [0, nch) of the concatenation src[0..2]; `slope` / `act_kind` for groups staged through the activation
-    template <bool GEN>
+    template <bool GEN, int G = 8>   // G: channels whose loads are in flight together (one global-memory round trip per group)
     __device__ __forceinline__ void stage(const TSrc (&src)[3], int nch, int b, float* dst, int cstride, int act_kind, float slope) const {
         // the three groups' fields as plain values (statically indexed reads, once): a job-table copy of `src` then lives in registers --
         // selecting among src[k].field inside the loop is turned back into an indexed access of the struct in scratch memory
@@ -139,7 +139,6 @@ struct WindowStager {
         // (clamped channel index: no branch between the loads), then the activation / masking / LDS stores.  With the per-channel
         // branches of the activation between one channel's loads and the next channel's, the loads were issued one channel at a time:
         // a launch paid `nch` dependent global-memory round trips before its barrier (r3: 10-14 us per small launch).
-        constexpr int G = 8;
         for (int c0 = 0; c0 < nch; c0 += G) {
             float v[G][NE];
 #pragma unroll
@@ -487,7 +486,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
     const Wg3Args a = load_job(jobs, find_job(jobs, njobs, (int)blockIdx.x));
     const int bid = (int)blockIdx.x - a.blk0;
     constexpr int TH = kWgTH, TW = 32, IR = TH + 2, IC = TW + 2, PI = 35;
-    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // gradient tile [TH][TW][CO], then the input window [CI][IR][PI] (>= 256 * 3 * CO floats)
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // gradient tile [TH][TW][CO], then the input window [CI][IR][PI]; at the end the reduction scratch
     float* const s_g = s_dyn;
     float* const s_x = s_dyn + TH * TW * CO;
     const int tid = threadIdx.x;
@@ -522,7 +521,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
                 }
             WindowStager<IR, IC, 256> st;
             st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
-            st.template stage<GEN>(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);
+            st.template stage<GEN, 16>(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);   // every channel in ONE round trip (with the gradient tile's loads)
 #pragma unroll
             for (int c = 0; c < CO; ++c)
 #pragma unroll
@@ -553,7 +552,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
     }
     // reduce over the row subsets (fixed order), then one thread per tap row adds the block's sums to its row of the table
     __syncthreads();
-    float* s_red = s_x;   // S * P * 3 * CO <= 256 * 24 floats
+    float* s_red = s_dyn;   // S * P * 3 * CO <= 256 * 3 * CO floats, over the (dead) gradient tile and input window
     if (active) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -974,9 +973,9 @@ struct Trainer {
         const int ntiles = a.tiles_x * a.tiles_y * B;
         a.nblk = ntiles < kPartRows ? ntiles : kPartRows;
         const int ci = in[0].nch + in[1].nch + in[2].nch;
-        size_t lds_x = (size_t)ci * (kWgTH + 2) * 35;                     // input window; doubles as the reduction scratch (256 * 3 * CO floats)
-        if (lds_x < (size_t)256 * 3 * co) lds_x = (size_t)256 * 3 * co;
-        const size_t lds = sizeof(float) * ((size_t)kWgTH * 32 * co + lds_x);
+        size_t lds_f = (size_t)kWgTH * 32 * co + (size_t)ci * (kWgTH + 2) * 35;   // gradient tile + input window; the reduction scratch
+        if (lds_f < (size_t)256 * 3 * co) lds_f = (size_t)256 * 3 * co;           // (256 * 3 * CO floats) takes their place at the end
+        const size_t lds = sizeof(float) * lds_f;
         if (co == 8) { jobs8.push_back(a); if (lds > lds8) lds8 = lds; }
         else if (co == 2) { jobs2.push_back(a); if (lds > lds2) lds2 = lds; }
         else return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no weight-gradient kernel for %d output channels", co);
