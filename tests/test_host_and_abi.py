@@ -32,6 +32,19 @@ def test_header_symbols_all_exported():
         assert b"HIP device" in lib.hn_last_error(None) or lib.hn_last_error(None)
 
 
+def test_python_enum_tables_match_the_header():
+    """The ctypes side passes plain integers: its tables must be the header's enumerators (name -> value), all of them."""
+    from helmnet_amd import _lib
+    hdr = open(os.path.join(REPO, "include", "helmnet_hip.h")).read()
+    enums = {name: int(val) for name, val in re.findall(r"\b(HN_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr)}
+    for table, prefix, rename in ((_lib.HN_OPTION, "HN_OPT_", {}), (_lib.HN_ACT, "HN_ACT_", {}),
+                                  (_lib.HN_PRECISION, "HN_PREC_", {"valu": "FP32_VALU"}), (_lib.HN_COUNTER, "HN_CNT_", {})):
+        in_header = {k: v for k, v in enums.items() if k.startswith(prefix)}
+        mine = {prefix + rename.get(k, k).upper(): v for k, v in table.items()}
+        assert mine == in_header, (prefix, set(mine.items()) ^ set(in_header.items()))
+    assert int(re.search(r"#define\s+HN_ABI_VERSION\s+(\d+)", hdr).group(1)) == _lib.ABI_VERSION
+
+
 def test_product_does_not_import_oracle():
     """The oracle is test infrastructure: nothing under helmnet_amd/ may reference it."""
     for root, _, files in os.walk(os.path.join(REPO, "helmnet_amd")):
