@@ -1328,10 +1328,16 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         HN_HIP(ctx, hipEventCreateWithFlags(&ctx->train_join, hipEventDisableTiming));
     }
     const hipStream_t ls[2] = {s, lanes == 2 ? ctx->train_stream : s};
+    // Under stream capture (a caller recording the step into a HIP graph) nothing may wait on the host: the job tables of a captured
+    // call are copied from the pinned buffer at every REPLAY, so the caller must not interleave other training calls of this context
+    // with replays (they would rewrite the tables); the event bookkeeping of the eager path is skipped.
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap);
+    const bool capturing = cap == hipStreamCaptureStatusActive;
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
         W.jobs_set = (W.jobs_set + 1) % hn_ctx::TrainWs::kJobSets;
-        if (W.jobs_in_flight[W.jobs_set]) {   // the tables of the call that last used this set have left the pinned buffer (normally long ago)
+        if (!capturing && W.jobs_in_flight[W.jobs_set]) {   // the tables of the call that last used this set have left the pinned buffer (normally long ago)
             HN_HIP(ctx, hipEventSynchronize(W.jobs_copied[W.jobs_set]));
             W.jobs_in_flight[W.jobs_set] = false;
         }
@@ -1405,8 +1411,10 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
                 return rc;
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
-        HN_HIP(ctx, hipEventRecord(W.jobs_copied[W.jobs_set], ls[l]));
-        W.jobs_in_flight[W.jobs_set] = true;
+        if (!capturing) {
+            HN_HIP(ctx, hipEventRecord(W.jobs_copied[W.jobs_set], ls[l]));
+            W.jobs_in_flight[W.jobs_set] = true;
+        }
         // gradients with respect to the inputs: each lane's samples, on its own stream
         if (grad_wf0) HN_HIP(ctx, hipMemcpyAsync(grad_wf0 + (size_t)lane_b0[l] * p2, W.g_wf[cur_wf[l]], sizeof(float) * (size_t)lane_nb[l] * p2, hipMemcpyDeviceToDevice, ls[l]));
         if (grad_res0) HN_HIP(ctx, hipMemcpyAsync(grad_res0 + (size_t)lane_b0[l] * p2, W.g_res, sizeof(float) * (size_t)lane_nb[l] * p2, hipMemcpyDeviceToDevice, ls[l]));

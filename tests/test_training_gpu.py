@@ -291,6 +291,39 @@ def test_two_lanes_give_the_gradient_of_one_lane(solver, weights):
     assert torch.equal(a1["residuals"], a2["residuals"]) and rel(a1["grad"], a2["grad"]) <= 2e-6
 
 
+def test_training_step_can_be_captured_in_a_hip_graph(solver, weights):
+    """hn_train_grad only enqueues work on the caller's stream (under capture it skips its host-side event bookkeeping), so a step can be
+    recorded with torch.cuda.graph and replayed: the replay's gradient is bit-identical to the eager call's.  (Replay is NOT faster --
+    the cost of a small dependent launch is on the GPU side: tools/graph_train_ab.py)"""
+    n, b = 64, 4
+    solver.set_domain_size(n, source_location=[50, 32])
+    eng = solver.engine()
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=8)).to(DEV)
+    out = solver.forward(sos, num_iterations=3, return_wavefields=True, return_states=True)
+    args = [out["wavefields"][-1].contiguous(), out["residuals"][-1].contiguous(), out["states"][-1].contiguous(),
+            ((1.0 / sos) ** 2).contiguous(), solver.source.detach().repeat(b, 1, 1, 1).contiguous()]
+    blob = torch.from_numpy(pack_weights(weights)).to(DEV)
+    g = torch.zeros_like(blob)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        eager = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+        torch.cuda.synchronize()
+        want, want_loss = g.clone(), eager["loss"].clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            captured = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+        for _ in range(2):
+            g.zero_()
+            captured["loss"].zero_()
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(g, want) and torch.equal(captured["loss"], want_loss)
+    # and the eager path still works afterwards
+    again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want) and torch.equal(again["loss"], want_loss)
+
+
 def test_adam_three_steps_match_the_reference_optimiser(solver, weights, g_train):
     n, b, k_sq, src, (wf0, res0, st0) = _fixture_inputs(g_train)
     solver.set_domain_size(n, source_location=[82, 48])
