@@ -67,6 +67,7 @@ struct Packer {
         DcW w;
         w.act = act;
         w.w1q = nullptr;   // set by hn_load_weights for the 8-channel DoubleConvs
+        w.u1 = w.u2 = nullptr;
         repack_oihw(src + pos, dst.data() + pos, cm, cin, 9);
         w.w1 = dev + pos; pos += (size_t)cm * cin * 9;
         std::memcpy(dst.data() + pos, src + pos, sizeof(float) * cm);
@@ -187,7 +188,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}};
+                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) c->opt_side_low_priority = std::atoi(v) != 0;
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -251,6 +252,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_TRAIN_LANES:
             if (value < 1 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_LANES must be 1 or 2 (got %d)", value);
             ctx->opt_train_lanes = value;
+            break;
+        case HN_OPT_DC_WINO:
+            if (value < 0 || value > 15 || (value & 4)) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_WINO must be a sum of 1 (inc), 2 (conv_signal), 8 (decoder) (got %d)", value);
+            ctx->opt_dc_wino = value;
             break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }
@@ -341,7 +346,8 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     HN_HIP(ctx, hipMemcpy(ctx->wdev, packed.data(), want * sizeof(float), hipMemcpyHostToDevice));
     {   // A-operand fragments for the matrix-core kernels, built from the original OIHW tensors
         std::vector<float> fr;
-        std::vector<size_t> off, offq;   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order
+        std::vector<size_t> off, offq, offu;   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order; offu: its
+                                               // two convolutions in the Winograd domain (hn_wino.hip)
         size_t pos = 0;
         auto dc = [&](int cin, int cm, int co) {  // returns offsets of (frag1, frag2) or (npos, npos)
             const float* w1 = blob + pos; pos += (size_t)cm * cin * 9 + cm + 1;
@@ -352,6 +358,11 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
                 return;
             }
             offq.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 72); pack_valu_q(w1, cin, fr.data() + offq.back());
+            {   // U = G g G^T; the input layer (cin == 6) carries the reference's 1e3 on its residual channels (hybridnet.py:566)
+                static const float inc_scale[kInCh] = {1.f, 1.f, 1000.f, 1000.f, 1.f, 1.f};
+                offu.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 128); pack_wino(w1, cin, cin == kInCh ? inc_scale : nullptr, fr.data() + offu.back());
+                offu.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * 128); pack_wino(w2, kFeat, nullptr, fr.data() + offu.back());
+            }
             // each fp32 fragment block is followed by its split-bf16 and fp16 twins (launch_dc8 relies on this order)
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3(w1, cin, fr.data() + off.back());
             { const size_t o = fr.size(); fr.resize(o + frag_3x3_split_floats(cin)); pack_frag_3x3_split(w1, cin, fr.data() + o); }
@@ -393,6 +404,9 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             fr.resize(fr.size() + (size_t)kFeat * 9 * 2);
             pack_outc3x3_valu(w2, wo, fr.data() + off_comp_v);
         }
+        fr.resize((fr.size() + 3) / 4 * 4);   // 16-byte aligned
+        const size_t off_zero = fr.size();
+        fr.resize(fr.size() + 64, 0.f);       // the zero page out-of-image staging loads read (hn_wino.hip)
         (void)hipFree(ctx->fragdev);
         ctx->fragdev = nullptr;
         HN_HIP(ctx, hipMalloc((void**)&ctx->fragdev, fr.size() * sizeof(float)));
@@ -410,7 +424,13 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             ctx->inc.w1q = ctx->fragdev + offq[iq++];
             for (int d = 0; d < depth; ++d) ctx->sig[d].w1q = ctx->fragdev + offq[iq++];
             for (int d = 0; d <= depth; ++d) ctx->dec[d].w1q = ctx->fragdev + offq[iq++];
+            size_t iu = 0;
+            auto setu = [&](DcW& w) { w.u1 = ctx->fragdev + offu[iu++]; w.u2 = ctx->fragdev + offu[iu++]; };
+            setu(ctx->inc);
+            for (int d = 0; d < depth; ++d) setu(ctx->sig[d]);
+            for (int d = 0; d <= depth; ++d) setu(ctx->dec[d]);
         }
+        ctx->zero_page = ctx->fragdev + off_zero;
         ctx->f_dec0c = ctx->fragdev + off_comp;
         ctx->dec0c_b = ctx->fragdev + off_comp_b;
         ctx->v_dec0c = ctx->fragdev + off_comp_v;

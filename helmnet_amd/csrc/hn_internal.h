@@ -40,6 +40,7 @@ struct DcW {
     const float* b2;
     int act;   // hn_act
     const float* w1q;   // conv1 again as [cin][2 channel halves][3][3][4] (8-channel DoubleConvs only; hn_dcv.hip)
+    const float *u1, *u2;   // both convolutions in the Winograd F(2x2, 3x3) domain: [cin][2 halves][8 freq][8 cout] (hn_wino.hip)
 };
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each; MI355X_MICROARCH.md, "Workgroup
@@ -138,6 +139,9 @@ struct hn_ctx {
     bool cols_t_attr_set = false, cols512_attr_set = false;
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     int opt_dc_valu = 1;       // fp32 DoubleConvs of the big levels on the packed vector FMA (hn_dcv.hip): 0 none, 1 inc + decoder, 2 all
+    int opt_dc_wino = 0;       // level-0 DoubleConvs as Winograd F(2x2, 3x3) on the vector FMA (hn_wino.hip): bit mask over the kinds
+                               // (1 inc, 2 conv_signal, 8 decoder), 0 none
+    const float* zero_page = nullptr;   // 256 zero bytes (out-of-image staging loads of hn_wino.hip)
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
     // domain
@@ -311,6 +315,12 @@ void pack_valu_q(const float* w_oihw, int cin, float* dst);            // conv1 
 void pack_outc3x3_valu(const float* w2, const float* wo, float* dst);   // conv2 composed with the out-conv -> [8 cm][3][3][2]
 bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
 void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
+                    int W, int batch, hipStream_t s);
+
+// ---- Winograd F(2x2, 3x3) DoubleConv of the big levels (hn_wino.hip) ----
+void pack_wino(const float* w_oihw, int cin, const float* scale, float* dst);   // [8][cin][3][3] -> [cin][2][8][8]
+bool dc_wino_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
+void launch_dc_wino(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
                     int W, int batch, hipStream_t s);
 
 // ---- deep levels in one per-sample kernel (hn_deep.hip) ----

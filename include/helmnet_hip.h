@@ -64,7 +64,7 @@ enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_P
 /* Tuning knobs (hn_set_option).  Bit-exact ones -- the same kernels and summation order, only launched differently: LANES,
  * SIDE_STREAM, GRAPH, SPECTRAL_COLS (same butterflies, other memory access).  The others select a different kernel for the same
  * fp32 arithmetic and agree to fp32 rounding, like two fp32 implementations of the reference do: DEEP (other summation order,
- * 2e-6 * max), SPECTRAL_PFA (FFT instead of the dense operator), SPECTRAL_RADIX16 (other butterfly order), DC_VALU. */
+ * 2e-6 * max), SPECTRAL_PFA (FFT instead of the dense operator), SPECTRAL_RADIX16 (other butterfly order), DC_VALU, DC_WINO. */
 enum hn_option {
     HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
     HN_OPT_SIDE_STREAM = 1,  /* conv_state kernels: 0 in line; on a library side stream released 1 after the last `down`,
@@ -80,10 +80,14 @@ enum hn_option {
                               * (default; conv_signal stays on the matrix core: the vector kernels lower the sustained clock), 2 all three */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
-    HN_OPT_TRAIN_LANES = 8   /* hn_train_grad: 1 (default) the whole batch as one chain of launches; 2: the two halves of the batch as
+    HN_OPT_TRAIN_LANES = 8,  /* hn_train_grad: 1 (default) the whole batch as one chain of launches; 2: the two halves of the batch as
                               * two chains on two streams (samples are independent).  Same gradient up to the order of the final
                               * sum over the halves.  Measured equal to 1: two overlapping chains of 16 samples take as long as
                               * one chain of 32                                                            */
+    HN_OPT_DC_WINO = 9       /* fp32 DoubleConvs of the largest level (W >= 256) as Winograd F(2x2, 3x3) on the packed vector FMA (2.25 x fewer
+                              * multiplies; weights G g G^T composed in float64 at hn_load_weights): sum of 1 (inc), 2 (conv_signal),
+                              * 8 (decoder); default 11 = all three, 0 = the direct kernels HN_OPT_DC_VALU selects.  Same fp32 sums in
+                              * another order: agrees with the direct kernels to fp32 rounding                              */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };

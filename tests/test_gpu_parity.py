@@ -450,6 +450,7 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
     for valu in (2, 1, 0):   # all three level-0 DoubleConvs on the vector pipe / inc + decoder (the default) / none
         s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
         s.set_domain_size(n, source_location=SRC[n])
+        s.engine().set_option("dc_wino", 0)   # (the Winograd kernels would take the level-0 DoubleConvs whatever dc_valu says)
         s.engine().set_option("dc_valu", valu)
         g = {k: v.to(DEV) for k, v in ti.items()}
         k_sq, _ = s.get_initials(g["sos"])
@@ -467,6 +468,37 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
         assert (a2 - w).abs().max().item() <= 1e-5 * scale
         assert (bb - w).abs().max().item() <= 1e-5 * scale
     assert not torch.equal(outs[1][0], outs[0][0]) and not torch.equal(outs[2][0], outs[1][0])   # three different kernel sets did run
+
+
+@pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])
+def test_winograd_doubleconvs_match_the_direct_ones_and_the_oracle(weights, n, b):
+    """hn_wino.hip (level-0 DoubleConvs as Winograd F(2x2, 3x3) on v_pk_fma_f32, the default at W >= 256) against the direct vector /
+    matrix-core kernels (HN_OPT_DC_WINO = 0) and against the oracle, for every subset of kinds the option can select: the same fp32
+    sums in another order, so every variant sits within 1e-5 * max of the oracle and within 4e-6 * max of the direct kernels.  320 has
+    a partial tile row / odd tile counts (no XCD remap); at 512 level 1 (W = 256) takes the kernels too."""
+    from helmnet_amd import IterativeSolver
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=4242).items()}
+    src = SRC.get(n, [n // 3, n // 2])
+    outs = {}
+    for mask in (0, 11, 1, 2, 8):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=src)
+        s.engine().set_option("dc_wino", mask)
+        g = {k: v.to(DEV) for k, v in ti.items()}
+        k_sq, _ = s.get_initials(g["sos"])
+        s.f.set_states(g["states"], flatten=True)
+        wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
+        outs[mask] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, src, 10.0), t)
+    want = (want[0], want[1], O.flatten_states(want[2]))
+    for mask in (11, 1, 2, 8):
+        for a, d, w in zip(outs[mask], outs[0], want):
+            scale = w.abs().max().item()
+            assert (a - d).abs().max().item() <= 4e-6 * scale, (mask, (a - d).abs().max().item() / scale)
+            assert (a - w).abs().max().item() <= 1e-5 * scale, (mask, (a - w).abs().max().item() / scale)
+        assert not torch.equal(outs[mask][0], outs[0][0])   # another kernel did run
 
 
 def test_graph_replay_is_bit_identical_to_kernel_by_kernel_launches(solver):
