@@ -236,6 +236,8 @@ __global__ __launch_bounds__(512, 4) void k_dc_wino(Src sa, Src sb, Src sc, Dst 
     };
 
     // ---- conv1 in the transformed domain ----
+    // The bias enters in the transformed domain: A^T (b e1 e1^T) A = b on all four outputs of a tile, so frequency (1, 1) starts at b:
+    // that is accumulator 5 of the F = 0 half; of the edge tiles' sums, the second one of wave 4 (V row 1, columns 0 and 1).
     f32x2 acc[8][4], acce[2][4];
 #pragma unroll
     for (int xi = 0; xi < 8; ++xi)
@@ -245,6 +247,15 @@ __global__ __launch_bounds__(512, 4) void k_dc_wino(Src sa, Src sb, Src sc, Dst 
     for (int k = 0; k < 2; ++k)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acce[k][c] = (f32x2){0.f, 0.f};
+    {
+        const CwPtr bp = cw(w.b1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x2 bv = bp[c];
+            acc[5][c] = f == 0 ? bv : (f32x2){0.f, 0.f};
+            acce[1][c] = wave == 4 ? bv : (f32x2){0.f, 0.f};
+        }
+    }
     const int trow = 2 * rp + (lane >> 5), tcol = lane & 31;          // main tile of this lane
     const int bs = (2 * trow) * kPI + 2 + 2 * tcol;
     const int et = lane < 41 ? lane : 40;                             // edge tile: tile row 8 (32 tiles), then tile column 32 (9 tiles)
@@ -287,14 +298,11 @@ __global__ __launch_bounds__(512, 4) void k_dc_wino(Src sa, Src sb, Src sc, Dst 
     } else {
         f32x2 oth[2][4];
         if (f) wino_out<1>(acc, own, oth); else wino_out<0>(acc, own, oth);
-        float* xch = lds + kXch1 + (size_t)(wave ^ 1) * 16 * 64 + lane;
+        f32x2* xch = reinterpret_cast<f32x2*>(lds + kXch1) + (size_t)(wave ^ 1) * 8 * 64 + lane;
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                xch[((x * 4 + c) * 2 + 0) * 64] = oth[x][c][0];
-                xch[((x * 4 + c) * 2 + 1) * 64] = oth[x][c][1];
-            }
+            for (int c = 0; c < 4; ++c) xch[(x * 4 + c) * 64] = oth[x][c];
         if (lane < 41) {
             const int xi0 = (2 * f + (wave >> 2)) * 4 + 2 * ((wave >> 1) & 1);
             float* xe = lds + kXEdge + (size_t)xi0 * 8 * 64 + lane;
@@ -316,20 +324,17 @@ __global__ __launch_bounds__(512, 4) void k_dc_wino(Src sa, Src sb, Src sc, Dst 
     };
     const int mr = 2 * trow + f;   // this wave completes row f of its tiles
     if (!(kWExp & 8)) {
-        const float* rcv = lds + kXch1 + (size_t)wave * 16 * 64 + lane;
+        const f32x2* rcv = reinterpret_cast<const f32x2*>(lds + kXch1) + (size_t)wave * 8 * 64 + lane;
         const int ym = y0 - 1 + mr;
         const bool yin = ym >= 0 && ym < H;
-        const CwPtr bp = cw(w.b1);
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
             const int xm = x0 - 1 + 2 * tcol + x;
             const float mk = (yin && xm >= 0 && xm < W) ? 1.f : 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x2 bv = bp[c];
-                const float a0 = own[x][c][0] + rcv[((x * 4 + c) * 2 + 0) * 64] + bv[0];
-                const float a1 = own[x][c][1] + rcv[((x * 4 + c) * 2 + 1) * 64] + bv[1];
-                own[x][c] = (f32x2){activate(a0, mk), activate(a1, mk)};
+                const f32x2 a = own[x][c] + rcv[(x * 4 + c) * 64];
+                own[x][c] = (f32x2){activate(a[0], mk), activate(a[1], mk)};
             }
         }
     }
@@ -346,10 +351,9 @@ __global__ __launch_bounds__(512, 4) void k_dc_wino(Src sa, Src sb, Src sc, Dst 
             ca[i][0] = m0 + m1 + m2;
             ca[i][1] = m1 - m2 - m3;
         }
-        const float bv = w.b1[eco];
 #pragma unroll
         for (int x = 0; x < 2; ++x) {
-            const float t0 = ca[0][x] + ca[1][x] + ca[2][x] + bv, t1 = ca[1][x] - ca[2][x] - ca[3][x] + bv;
+            const float t0 = ca[0][x] + ca[1][x] + ca[2][x], t1 = ca[1][x] - ca[2][x] - ca[3][x];
             const int xm = x0 - 1 + 2 * eec + x;
             const bool xin = xm >= 0 && xm < W;
             const int ya = y0 - 1 + 2 * eer;
@@ -424,37 +428,32 @@ __global__ __launch_bounds__(512, 4) void k_dc_wino(Src sa, Src sb, Src sc, Dst 
         }
     } else {
         // ---- conv2 (8 -> 8) in the transformed domain: output tile (trow, tcol) reads mid rows 2 trow .. + 3, columns 2 tcol .. + 3 ----
+        {
+            const CwPtr bp = cw(w.b2);
 #pragma unroll
-        for (int xi = 0; xi < 8; ++xi)
+            for (int xi = 0; xi < 8; ++xi)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[xi][c] = (f32x2){0.f, 0.f};
+                for (int c = 0; c < 4; ++c) acc[xi][c] = (xi == 5 && f == 0) ? bp[c] : (f32x2){0.f, 0.f};
+        }
         __syncthreads();
         const float* const mid = lds + kMid + (2 * trow) * kPM + 2 * tcol;
         f32x2 oth[2][4];
         if (f) conv2_wave<1>(acc, acce, mid, w.u2, own, oth); else conv2_wave<0>(acc, acce, mid, w.u2, own, oth);
-        float* xch = lds + kXch2 + (size_t)(wave ^ 1) * 16 * 64 + lane;
+        f32x2* xch = reinterpret_cast<f32x2*>(lds + kXch2) + (size_t)(wave ^ 1) * 8 * 64 + lane;
 #pragma unroll
         for (int x = 0; x < 2; ++x)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                xch[((x * 4 + c) * 2 + 0) * 64] = oth[x][c][0];
-                xch[((x * 4 + c) * 2 + 1) * 64] = oth[x][c][1];
-            }
+            for (int c = 0; c < 4; ++c) xch[(x * 4 + c) * 64] = oth[x][c];
         __syncthreads();
-        const float* rcv = lds + kXch2 + (size_t)wave * 16 * 64 + lane;
+        const f32x2* rcv = reinterpret_cast<const f32x2*>(lds + kXch2) + (size_t)wave * 8 * 64 + lane;
         const int oy = y0 + 2 * trow + f, ox = x0 + 2 * tcol;
         if (oy < H && ox < W) {
             float* p = out.p + (long)b * out.sb + (long)oy * W + ox;
-            const CwPtr bp = cw(w.b2);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x2 bv = bp[c];
+                const f32x2 v0 = own[0][c] + rcv[c * 64], v1 = own[1][c] + rcv[(4 + c) * 64];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float v0 = own[0][c][h] + rcv[((0 * 4 + c) * 2 + h) * 64] + bv[h];
-                    const float v1 = own[1][c][h] + rcv[((1 * 4 + c) * 2 + h) * 64] + bv[h];
-                    *reinterpret_cast<float2*>(p + (long)(2 * c + h) * out.sc) = make_float2(v0, v1);
-                }
+                for (int h = 0; h < 2; ++h) *reinterpret_cast<float2*>(p + (long)(2 * c + h) * out.sc) = make_float2(v0[h], v1[h]);
             }
         }
     }
