@@ -194,6 +194,7 @@ struct hn_ctx {
         size_t slope_stride = 0;
         float* w3 = nullptr;         // 3x3 weights packed [cin][9][cout]: forward arrangement, then backward-data
         float* k8 = nullptr;         // 8x8 weights as fp32 matrix-core fragments: [depth][4][4096]
+        float* f3 = nullptr;         // 3x3 weights of the 8-channel DoubleConvs as fp32 matrix-core fragments [cin][3][64] (forward pass)
         float* zero8 = nullptr;      // 8 zeros (bias of the backward-data convolutions)
         float* sumsq = nullptr;      // [n_unroll][batch] per-sample sum of squared residuals
         // job tables of the batched weight-gradient launches: one region per unrolled iteration, filled on the host (pinned), copied
@@ -209,6 +210,7 @@ struct hn_ctx {
         int last_batch = 0;          // samples of the last hn_train_grad call in this workspace (hn_train_peek)
         int sumsq_batch = 0;         // samples per row of sumsq (lane 0 holds the whole batch's rows)
     } tr, tr_b;                      // tr_b: the second half of the batch when hn_train_grad runs as two lanes
+    int opt_train_fused = 1;       // HN_OPT_TRAIN_FUSED: the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue
     int opt_train_lanes = 1;       // HN_OPT_TRAIN_LANES: 2 = the halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t train_stream = nullptr;            // lane 1 (created on first use)
     hipEvent_t train_fork = nullptr, train_join = nullptr;
@@ -307,6 +309,10 @@ void pack_frag_up_x16(const float* w_iohw, float* dst_split, float* dst_half);
 // kind: 0 inc (2+2+2 ch), 1 conv_signal (8+2), 2 bottleneck (8), 3 decoder (8+8; final_epi adds outc + wf update)
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
+// training forward: the fused matrix-core DoubleConv with the pre-activation mid tensor stored to `z` ([B, 8, H, W]); fragments as pack_frag_3x3
+bool dc8_tape_applies(int H, int W);
+int launch_dc8_tape(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const float* frag1, const float* b1, const float* slope, const float* frag2,
+                    const float* b2, int act, float* z, int H, int W, int batch, hipStream_t s);
 void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
 void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate = false);
 

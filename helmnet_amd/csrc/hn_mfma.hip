@@ -100,6 +100,10 @@ struct McEpi {
     float* wf;
     const float* a2c;  // conv2 composed with the 1x1 out-conv, row-triple fragments [8 cm][5][64] (k_dc_mfma_s<.., EPI = 1>)
     const float* b2c;  // its bias [2]
+    // training forward (hn_train.hip): the PRE-activation mid tensor of the tile's own 16 x 64 (8 x 32 ...) positions also goes to the
+    // tape, element (b, c, y, x) at z[b * z_sb + c * z_sc + y * W + x]; nullptr in the inference path
+    float* z;
+    long z_sb, z_sc;
 };
 
 template <int CA, int CB, int CC, int TW, int EPI, bool GEN = false>
@@ -517,6 +521,11 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
         const float sel = slope <= 1.f ? __builtin_inff() : -__builtin_inff();
         auto put = [&](const f32x4& a, int mrow, int pc, f32x2 mk, f32x2 sk) {
             float2* m = reinterpret_cast<float2*>(lds + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc);
+            if (epi.z != nullptr && mrow >= 1 && mrow <= C::TH) {   // training tape: the tile's own positions (mid columns 1 .. TW), pre-activation
+                float* zp = epi.z + (long)b * epi.z_sb + (long)(2 * q) * epi.z_sc + (long)(y0 - 1 + mrow) * W + (x0 - 1 + 2 * pc);
+                if (mk[0] != 0.f && pc >= 1) { zp[0] = a[0]; zp[epi.z_sc] = a[2]; }
+                if (mk[1] != 0.f && 2 * pc + 1 <= C::TW) { zp[1] = a[1]; zp[epi.z_sc + 1] = a[3]; }
+            }
             if (GEN) {   // smooth activations: f(x) first, then the padding mask (f(0) need not be 0)
                 m[0] = make_float2(mk[0] * act_general(a[0], w.act), mk[1] * act_general(a[1], w.act));
                 m[C::MPLANE / 2] = make_float2(mk[0] * act_general(a[2], w.act), mk[1] * act_general(a[3], w.act));
@@ -1279,6 +1288,11 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
                 const bool yin = y >= 0 && y < H;
                 const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
                 float v[4] = {acc1[gi][0] + bm0, acc1[gi][1] + bm0, acc1[gi][2] + bm1, acc1[gi][3] + bm1};
+                if (epi.z != nullptr && mrow >= 1 && mrow <= C::TH) {   // training tape: the tile's own positions, pre-activation
+                    float* zp = epi.z + (long)b * epi.z_sb + (long)(2 * q) * epi.z_sc + (long)y * W + x;
+                    if (in0 && pc >= 1) { zp[0] = v[0]; zp[epi.z_sc] = v[2]; }
+                    if (in1 && 2 * pc + 1 <= C::TW) { zp[1] = v[1]; zp[epi.z_sc + 1] = v[3]; }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = GEN ? act_general(v[r], w.act) : (v[r] > 0.f ? v[r] : slope * v[r]);
                 float* m0 = lds + C::MID_OFF + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
@@ -2113,6 +2127,23 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
             if (final_epi) launch_dc_mfma<kFeat, kFeat, 0, 1>(x16, a, b, c, out, mw, e, H, W, batch, s);
             else launch_dc_mfma<kFeat, kFeat, 0, 0>(x16, a, b, c, out, mw, e, H, W, batch, s);
             break;
+        default: return fail(ctx, HN_ERR_ARG, "internal: bad DoubleConv kind %d", kind);
+    }
+    return HN_OK;
+}
+
+// Training forward (hn_train.hip): a whole 8-channel DoubleConv on the fp32 matrix core from fragments packed for THIS call's weights,
+// the pre-activation mid tensor stored to the tape by the kernel that computes it.
+bool dc8_tape_applies(int H, int W) { return (W & 1) == 0 && 8.0 * (double)H * (double)W * 4.0 < 4.0e9; }
+int launch_dc8_tape(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const float* frag1, const float* b1, const float* slope, const float* frag2,
+                    const float* b2, int act, float* z, int H, int W, int batch, hipStream_t s) {
+    const McW mw{frag1, b1, slope, frag2, b2, nullptr, nullptr, nullptr, nullptr, act};
+    const McEpi e{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, z, (long)kFeat * H * W, (long)H * W};
+    switch (kind) {
+        case 0: launch_dc_mfma<2, 2, 2, 0>(0, a, b, c, out, mw, e, H, W, batch, s); break;
+        case 1: launch_dc_mfma<kFeat, kState, 0, 0>(0, a, b, c, out, mw, e, H, W, batch, s); break;
+        case 2: launch_dc_mfma<kFeat, 0, 0, 0>(0, a, b, c, out, mw, e, H, W, batch, s); break;
+        case 3: launch_dc_mfma<kFeat, kFeat, 0, 0>(0, a, b, c, out, mw, e, H, W, batch, s); break;
         default: return fail(ctx, HN_ERR_ARG, "internal: bad DoubleConv kind %d", kind);
     }
     return HN_OK;

@@ -806,6 +806,28 @@ __global__ __launch_bounds__(256) void k_pack3(const float* __restrict__ raw, fl
         dst[total + off + e] = raw[off + (o * I + i) * 9 + (8 - k)];
     }
 }
+// 3x3 weights of the 8-channel DoubleConvs as A-operand fragments of the fp32 matrix-core kernels (hn_mfma.hip, pack_frag_3x3):
+// raw [8][cin][3][3] -> [cin][3][64], lane l -> (co = (l & 15) >> 1, dxo = l & 1, t = l >> 4): raw[co][ci][dy][t - dxo] where that tap exists.
+struct F3Layout { size_t inc[2], sig[kMaxDepth][2], dec[kMaxDepth + 1][2], total; };
+F3Layout f3_layout(int depth) {
+    F3Layout F{};
+    size_t pos = 0;
+    auto take = [&](size_t (&o)[2], int cin) { o[0] = pos; pos += (size_t)cin * 192; o[1] = pos; pos += (size_t)kFeat * 192; };
+    take(F.inc, kInCh);
+    for (int d = 0; d < depth; ++d) take(F.sig[d], kFeat + kState);
+    for (int d = 0; d <= depth; ++d) take(F.dec[d], d < depth ? 2 * kFeat : kFeat);
+    F.total = pos;
+    return F;
+}
+struct PackF3Jobs { int n; int raw[2 * (2 * kMaxDepth + 2)], dst[2 * (2 * kMaxDepth + 2)]; short cin[2 * (2 * kMaxDepth + 2)]; };
+__global__ __launch_bounds__(256) void k_pack_frag3(const float* __restrict__ blob, float* __restrict__ f3, PackF3Jobs jobs) {
+    const int j = blockIdx.y, cin = jobs.cin[j];
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= cin * 192) return;
+    const int l = e & 63, dy = (e >> 6) % 3, ci = e / 192;
+    const int co = (l & 15) >> 1, dx = (l >> 4) - (l & 1);
+    f3[jobs.dst[j] + e] = (dx >= 0 && dx <= 2) ? blob[jobs.raw[j] + ((co * cin + ci) * 3 + dy) * 3 + dx] : 0.f;
+}
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                                               const unsigned char* __restrict__ trainable, size_t n, float step_size, float inv_sqrt_bc2, float b1,
                                               float b2, float eps, float wd, float clip) {
@@ -944,7 +966,18 @@ struct Trainer {
     }
     // DoubleConv forward with tape: z = conv1(in) (stored), out = conv2(act(z))
     bool small_level(int d) const { return side(d) <= kSmallS; }
-    int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d) {
+    F3Layout F3;
+    bool fused_fwd = true;   // HN_OPT_TRAIN_FUSED 0 (A/B): every convolution of the forward pass as its own direct launch (the r3 path)
+    int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d, const size_t (*f3)[2] = nullptr) {
+        // 8-channel DoubleConvs: the fused matrix-core kernels of the inference path, which also store the pre-activation mid tensor
+        // (one launch instead of two, at 0.4-0.6 of the fp32 peak instead of 0.16; VERDICT r3 #2a)
+        if (fused_fwd && f3 != nullptr && dc.cm == kFeat && dc.co == kFeat && dc8_tape_applies(side(d), side(d)) && out.scale == 1.f && !out.accum &&
+            in[0].act == 0 && in[1].act == 0 && in[2].act == 0) {
+            const int kind = dc.cin == kInCh ? 0 : dc.cin == kFeat + kState ? 1 : dc.cin == kFeat ? 2 : 3;
+            auto ms = [](const TSrc& t) { return Src{t.p, t.sb, t.sc, t.scale}; };
+            return launch_dc8_tape(ctx, kind, ms(in[0]), ms(in[1]), ms(in[2]), Dst{out.p, out.sb, out.sc}, ctx->tr.f3 + (*f3)[0], w + dc.b1, w + dc.slope,
+                                   ctx->tr.f3 + (*f3)[1], w + dc.b2, act, z, side(d), side(d), B, s);
+        }
         if (small_level(d) && dc.cm == kFeat && dc.co == kFeat) {   // both convolutions in one launch (k_dc_small)
             const TSrc mid[3] = {feat(z, d, dc.cm, 1), nosrc(), nosrc()};
             const DcSmallArgs q{fwd_args(in, dc.w1, dc.b1, dc.slope, featdst(z, d, dc.cm), d), fwd_args(mid, dc.w2, dc.b2, dc.slope, out, d)};
@@ -1076,11 +1109,11 @@ struct Trainer {
         const long p0 = plane(0);
         {
             const TSrc in[3] = {TSrc{wf, 2 * p0, p0, 2, 1.f, 0}, TSrc{res, 2 * p0, p0, 2, 1e3f, 0}, TSrc{ctx->tab.sigmas, 0, p0, 2, 1.f, 0}};
-            if ((rc = dc_fwd(L.inc, in, tape(t, W.o_zinc), featdst(tape(t, W.o_x[0]), 0), 0)) != HN_OK) return rc;
+            if ((rc = dc_fwd(L.inc, in, tape(t, W.o_zinc), featdst(tape(t, W.o_x[0]), 0), 0, &F3.inc)) != HN_OK) return rc;
         }
         for (int d = 0; d < depth; ++d) {
             const TSrc in_sig[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
-            if ((rc = dc_fwd(L.sig[d], in_sig, tape(t, W.o_zsig[d]), featdst(tape(t, W.o_out[d]), d), d)) != HN_OK) return rc;
+            if ((rc = dc_fwd(L.sig[d], in_sig, tape(t, W.o_zsig[d]), featdst(tape(t, W.o_out[d]), d), d, &F3.sig[d])) != HN_OK) return rc;
             launch_down(ctx, msrc(tape(t, W.o_out[d]), d), mdst(tape(t, W.o_x[d + 1]), d + 1), frag8(d, 0), w + L.down[d].b, side(d), side(d), B, s);
         }
         {   // new_state_d = conv_state_d(cat[out_d, state_d]) (architectures.py:248) for every level at once: nothing of this iteration
@@ -1099,12 +1132,12 @@ struct Trainer {
         }
         {
             const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
-            if ((rc = dc_fwd(L.dec[depth], in, tape(t, W.o_zdec[depth]), featdst(tape(t, W.o_y[depth]), depth), depth)) != HN_OK) return rc;
+            if ((rc = dc_fwd(L.dec[depth], in, tape(t, W.o_zdec[depth]), featdst(tape(t, W.o_y[depth]), depth), depth, &F3.dec[depth])) != HN_OK) return rc;
         }
         for (int d = depth - 1; d >= 0; --d) {
             launch_up(ctx, msrc(tape(t, W.o_y[d + 1]), d + 1), mdst(tape(t, W.o_u[d]), d), frag8(d, 2), w + L.up[d].b, side(d + 1), side(d + 1), B, s);
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
-            if ((rc = dc_fwd(L.dec[d], in, tape(t, W.o_zdec[d]), featdst(tape(t, W.o_y[d]), d), d)) != HN_OK) return rc;
+            if ((rc = dc_fwd(L.dec[d], in, tape(t, W.o_zdec[d]), featdst(tape(t, W.o_y[d]), d), d, &F3.dec[d])) != HN_OK) return rc;
         }
         const long total = (long)B * p0;
         hipLaunchKernelGGL(k_outc_fwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, tape(t, W.o_y[0]), w + L.outc_w, w + L.outc_b, wf, wf_next, p0, total);
@@ -1182,7 +1215,7 @@ struct Trainer {
 };
 
 void train_free_ws(hn_ctx::TrainWs& W) {
-    for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.zero8, (void*)W.sumsq, (void*)W.jobs_dev}) (void)hipFree(p);
+    for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.f3, (void*)W.zero8, (void*)W.sumsq, (void*)W.jobs_dev}) (void)hipFree(p);
     if (W.jobs_host != nullptr) (void)hipHostFree(W.jobs_host);
     for (hipEvent_t e : W.jobs_copied)
         if (e != nullptr) (void)hipEventDestroy(e);
@@ -1249,6 +1282,7 @@ int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int 
     HN_HIP(ctx, hipMalloc((void**)&W.slope_part, sizeof(double) * W.slope_stride * (3 * depth + 2)));
     HN_HIP(ctx, hipMalloc((void**)&W.w3, sizeof(float) * 2 * total));
     HN_HIP(ctx, hipMalloc((void**)&W.k8, sizeof(float) * (size_t)depth * 4 * 4096));
+    HN_HIP(ctx, hipMalloc((void**)&W.f3, sizeof(float) * f3_layout(depth).total));
     HN_HIP(ctx, hipMalloc((void**)&W.zero8, sizeof(float) * 8));
     HN_HIP(ctx, hipMemset(W.zero8, 0, sizeof(float) * 8));
     HN_HIP(ctx, hipMalloc((void**)&W.sumsq, sizeof(float) * (size_t)nu * nsq));
@@ -1349,6 +1383,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = ctx->opt_train_fused != 0; }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
     struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};
@@ -1372,6 +1407,18 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
             kj.off[4 * d + 3] = (int)L.up[d].w;   kj.up[4 * d + 3] = 0;   // up, backward-data: [in, out] read as [out, in] by the convolution kernel
         }
         hipLaunchKernelGGL(k_pack_frag8, dim3(16, 4 * depth), dim3(256), 0, s, weights, W.k8, kj);
+        {
+            const F3Layout F = f3_layout(depth);
+            PackF3Jobs fj{};
+            auto addf = [&](const RawDc& dc, const size_t (&o)[2]) {
+                fj.raw[fj.n] = (int)dc.w1; fj.dst[fj.n] = (int)o[0]; fj.cin[fj.n] = (short)dc.cin; ++fj.n;
+                fj.raw[fj.n] = (int)dc.w2; fj.dst[fj.n] = (int)o[1]; fj.cin[fj.n] = (short)dc.cm; ++fj.n;
+            };
+            addf(L.inc, F.inc);
+            for (int d = 0; d < depth; ++d) addf(L.sig[d], F.sig[d]);
+            for (int d = 0; d <= depth; ++d) addf(L.dec[d], F.dec[d]);
+            hipLaunchKernelGGL(k_pack_frag3, dim3(cdiv(16 * 192, 256), fj.n), dim3(256), 0, s, weights, W.f3, fj);
+        }
         HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));
     }
     if (lanes == 2) {   // the second lane starts behind the packed weights (and whatever the caller's stream held before)

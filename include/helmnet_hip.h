@@ -84,10 +84,13 @@ enum hn_option {
                               * two chains on two streams (samples are independent).  Same gradient up to the order of the final
                               * sum over the halves.  Measured equal to 1: two overlapping chains of 16 samples take as long as
                               * one chain of 32                                                            */
-    HN_OPT_DC_WINO = 9       /* fp32 DoubleConvs of the largest level (W >= 256) as Winograd F(2x2, 3x3) on the packed vector FMA (2.25 x fewer
+    HN_OPT_DC_WINO = 9,      /* fp32 DoubleConvs of the largest level (W >= 256) as Winograd F(2x2, 3x3) on the packed vector FMA (2.25 x fewer
                               * multiplies; weights G g G^T composed in float64 at hn_load_weights): sum of 1 (inc), 2 (conv_signal),
                               * 8 (decoder); default 11 = all three, 0 = the direct kernels HN_OPT_DC_VALU selects.  Same fp32 sums in
                               * another order: agrees with the direct kernels to fp32 rounding                              */
+    HN_OPT_TRAIN_FUSED = 10  /* hn_train_grad, forward pass: 1 (default) an 8-channel DoubleConv is ONE launch of the fused matrix-core
+                              * kernels of the inference path, which also store the pre-activation mid tensor to the tape; 0: every
+                              * convolution as its own direct launch (round 3).  Same tape within fp32 rounding                */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };

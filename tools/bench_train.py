@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cpu", action="store_true")
     ap.add_argument("--side-stream", action="store_true", help="run on a torch side stream instead of the default (null) stream")
     ap.add_argument("--lanes", type=int, default=None, help="HN_OPT_TRAIN_LANES (1 or 2; default: the library's)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="hn_set_option (e.g. train_fused=0)")
     a = ap.parse_args()
     from helmnet_amd import IterativeSolver
     from helmnet_amd.engine import pack_weights
@@ -34,6 +35,9 @@ def main():
     eng = s.engine()
     if a.lanes is not None:
         eng.set_option("train_lanes", a.lanes)
+    for kv in a.opt:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     sos = torch.from_numpy(ring_sos_batch(a.n, a.batch, seed=5)).to(dev)
     out = s.forward(sos, num_iterations=5, return_wavefields=True, return_states=True)
     wf, res, st = out["wavefields"][-1].contiguous(), out["residuals"][-1].contiguous(), out["states"][-1].contiguous()
