@@ -188,7 +188,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}};
+                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) c->opt_side_low_priority = std::atoi(v) != 0;
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -256,6 +256,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_TRAIN_FUSED:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_FUSED must be 0 or 1 (got %d)", value);
             ctx->opt_train_fused = value;
+            break;
+        case HN_OPT_TRAIN_OVERLAP:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_OVERLAP must be 0 or 1 (got %d)", value);
+            ctx->opt_train_overlap = value;
             break;
         case HN_OPT_DC_WINO:
             if (value < 0 || value > 15 || (value & 4)) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_WINO must be a sum of 1 (inc), 2 (conv_signal), 8 (decoder) (got %d)", value);

@@ -187,7 +187,13 @@ struct hn_ctx {
         float* gbuf = nullptr;       // gradient buffers, carved below
         float *g_x[hn::kMaxDepth + 1]{}, *g_out[hn::kMaxDepth]{}, *g_u[hn::kMaxDepth]{}, *g_y[hn::kMaxDepth + 1]{};
         float *gz[3 * hn::kMaxDepth + 2]{};   // gradient of every DoubleConv's mid tensor (it feeds conv1's weight gradient at the end of the iteration)
-        float *g_wf[2]{}, *g_res = nullptr, *g_st[2]{};
+        float *g_wf[2]{}, *g_res = nullptr, *g_st[3]{};   // g_st: read one, write the next, the third is still read by the previous iteration's weight gradients
+        // two sets of the per-iteration gradient buffers above (g_x .. gz point into the set of the iteration being processed): the weight-gradient
+        // launches of iteration t run on a stream of their own beside the backward chain of iteration t - 1, which writes the other set
+        struct GSet { float *g_x[hn::kMaxDepth + 1]{}, *g_y[hn::kMaxDepth + 1]{}, *g_out[hn::kMaxDepth]{}, *g_u[hn::kMaxDepth]{}, *gz[3 * hn::kMaxDepth + 2]{}; } gset[2];
+        hipStream_t wg_stream = nullptr;
+        hipEvent_t wg_ready[2]{}, wg_done[2]{};
+        bool wg_pending[2]{};
         float* part = nullptr;       // [640 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
         size_t part_floats = 0;
         double* slope_part = nullptr; // [3 depth + 2 DoubleConvs][slope_stride]: per-block sums of the PReLU-slope gradients (float64)
@@ -210,6 +216,7 @@ struct hn_ctx {
         int last_batch = 0;          // samples of the last hn_train_grad call in this workspace (hn_train_peek)
         int sumsq_batch = 0;         // samples per row of sumsq (lane 0 holds the whole batch's rows)
     } tr, tr_b;                      // tr_b: the second half of the batch when hn_train_grad runs as two lanes
+    int opt_train_overlap = 1;     // HN_OPT_TRAIN_OVERLAP: weight-gradient launches on a side stream beside the next iteration's backward chain
     int opt_train_fused = 1;       // HN_OPT_TRAIN_FUSED: the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue
     int opt_train_lanes = 1;       // HN_OPT_TRAIN_LANES: 2 = the halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t train_stream = nullptr;            // lane 1 (created on first use)

@@ -41,6 +41,7 @@ namespace hn {
 namespace {
 
 constexpr int cdiv(int a, int b) { return (a + b - 1) / b; }
+void select_gset(hn_ctx::TrainWs& W, int k);
 
 // ---- raw (PyTorch-layout) blob offsets, the order of hn_load_weights -------------------------------------------------
 struct RawDc { size_t w1, b1, slope, w2, b2; int cin, cm, co; };
@@ -967,6 +968,7 @@ struct Trainer {
     // DoubleConv forward with tape: z = conv1(in) (stored), out = conv2(act(z))
     bool small_level(int d) const { return side(d) <= kSmallS; }
     F3Layout F3;
+    bool overlap = true;     // HN_OPT_TRAIN_OVERLAP 0 (A/B): the weight-gradient launches in line on the chain's stream (the r3 path)
     bool fused_fwd = true;   // HN_OPT_TRAIN_FUSED 0 (A/B): every convolution of the forward pass as its own direct launch (the r3 path)
     int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d, const size_t (*f3)[2] = nullptr) {
         // 8-channel DoubleConvs: the fused matrix-core kernels of the inference path, which also store the pre-activation mid tensor
@@ -1022,7 +1024,7 @@ struct Trainer {
     }
     // the jobs filed during the backward pass of iteration t: table -> device (stream-ordered copy out of this iteration's own
     // region of the pinned buffer), then the three launches
-    int flush_wgrads(int t) {
+    int flush_wgrads(int t, hipStream_t s) {   // (`s` shadows the chain's stream: the launches go where the caller says)
         auto& W = T();
         const size_t b8 = jobs8.size() * sizeof(Wg3Args), b2 = jobs2.size() * sizeof(Wg3Args), bk = jobsk.size() * sizeof(Wg8Args);
         if (b8 + b2 + bk > W.jobs_region) return fail(ctx, HN_ERR_STATE, "internal: weight-gradient job table overflow (%zu > %zu bytes)", b8 + b2 + bk, W.jobs_region);
@@ -1152,6 +1154,11 @@ struct Trainer {
         auto& W = T();
         int rc;
         const long p0 = plane(0), tot2 = (long)B * 2 * p0;
+        const int par = t & 1;
+        if (overlap) {   // this iteration writes buffer set `par`: the weight gradients of iteration t + 2, which read it, must be done
+            if (W.wg_pending[par]) { HN_HIP(ctx, hipStreamWaitEvent(s, W.wg_done[par], 0)); W.wg_pending[par] = false; }
+            select_gset(W, par);
+        } else select_gset(W, 0);
         // this iteration's loss term, then the adjoint of the residual operator: G = g_wf + L^H(g_res) + ksq * g_res
         hipLaunchKernelGGL(k_loss_seed, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, s, W.g_res, res_out, loss_c, 1, tot2);
         if ((rc = spec_adjoint(ctx, W.g_res, W.g_wf[cur_wf ^ 1], ksq, W.g_wf[cur_wf], B, s)) != HN_OK) return rc;
@@ -1172,7 +1179,7 @@ struct Trainer {
                 const TSrc g_new = state_src(W.g_st[cur_st], d);
                 if ((rc = dc_wgrads(dc, slot_st(d), in, tape(t, W.o_zst[d]), g_new, d)) != HN_OK) return rc;
                 q2.job[d] = bwd2_args(dc, slot_st(d), tape(t, W.o_zst[d]), g_new, d);
-                const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 0), state_dst(W.g_st[cur_st ^ 1], d, 0), nodst()};
+                const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 0), state_dst(W.g_st[(cur_st + 1) % 3], d, 0), nodst()};
                 q1.job[d] = bwd1_args(dc, slot_st(d), gin, d);
             }
             if ((rc = launch_conv3_batch(ctx, kState, true, q2, B, s)) != HN_OK) return rc;
@@ -1198,7 +1205,7 @@ struct Trainer {
             wgrad8(W.g_x[d + 1], d + 1, tape(t, W.o_out[d]), L.down[d].w, 0);
             {   // conv_signal: out = DC(cat[x, state])
                 const TSrc in[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
-                const TDst gin[3] = {featdst(W.g_x[d], d), state_dst(W.g_st[cur_st ^ 1], d, 1), nodst()};
+                const TDst gin[3] = {featdst(W.g_x[d], d), state_dst(W.g_st[(cur_st + 1) % 3], d, 1), nodst()};
                 if ((rc = dc_bwd(L.sig[d], slot_sig(d), in, tape(t, W.o_zsig[d]), feat(W.g_out[d], d), gin, d)) != HN_OK) return rc;
             }
         }
@@ -1207,18 +1214,36 @@ struct Trainer {
             const TDst gin[3] = {TDst{G, 2 * p0, p0, 2, 1.f, 1}, TDst{W.g_res, 2 * p0, p0, 2, 1e3f, 0}, nodst()};
             if ((rc = dc_bwd(L.inc, slot_inc(), in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0)) != HN_OK) return rc;
         }
-        cur_st ^= 1;
-        if ((rc = flush_wgrads(t)) != HN_OK) return rc;
+        cur_st = (cur_st + 1) % 3;
+        if (overlap) {   // the filed weight-gradient jobs: three launches on the side stream, beside the backward chain of iteration t - 1
+            HN_HIP(ctx, hipEventRecord(W.wg_ready[par], s));
+            HN_HIP(ctx, hipStreamWaitEvent(W.wg_stream, W.wg_ready[par], 0));
+            if ((rc = flush_wgrads(t, W.wg_stream)) != HN_OK) return rc;
+            HN_HIP(ctx, hipEventRecord(W.wg_done[par], W.wg_stream));
+            W.wg_pending[par] = true;
+        } else if ((rc = flush_wgrads(t, s)) != HN_OK) return rc;
         HN_HIP(ctx, hipGetLastError());
         return HN_OK;
     }
 };
+
+void select_gset(hn_ctx::TrainWs& W, int k) {   // g_x .. gz name the buffers of the iteration being processed
+    const auto& G = W.gset[k];
+    for (int d = 0; d <= kMaxDepth; ++d) { W.g_x[d] = G.g_x[d]; W.g_y[d] = G.g_y[d]; }
+    for (int d = 0; d < kMaxDepth; ++d) { W.g_out[d] = G.g_out[d]; W.g_u[d] = G.g_u[d]; }
+    for (int i = 0; i < 3 * kMaxDepth + 2; ++i) W.gz[i] = G.gz[i];
+}
 
 void train_free_ws(hn_ctx::TrainWs& W) {
     for (void* p : {(void*)W.tape, (void*)W.gbuf, (void*)W.part, (void*)W.slope_part, (void*)W.w3, (void*)W.k8, (void*)W.f3, (void*)W.zero8, (void*)W.sumsq, (void*)W.jobs_dev}) (void)hipFree(p);
     if (W.jobs_host != nullptr) (void)hipHostFree(W.jobs_host);
     for (hipEvent_t e : W.jobs_copied)
         if (e != nullptr) (void)hipEventDestroy(e);
+    if (W.wg_stream != nullptr) (void)hipStreamDestroy(W.wg_stream);
+    for (int k = 0; k < 2; ++k) {
+        if (W.wg_ready[k] != nullptr) (void)hipEventDestroy(W.wg_ready[k]);
+        if (W.wg_done[k] != nullptr) (void)hipEventDestroy(W.wg_done[k]);
+    }
     W = hn_ctx::TrainWs{};
 }
 
@@ -1251,30 +1276,42 @@ int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int 
     HN_HIP(ctx, hipMalloc((void**)&W.tape, sizeof(float) * W.step_floats * nu));
     size_t g = 0;
     auto gtake = [&](size_t floats) { const size_t o = g; g += floats; return o; };
-    size_t o_gx[kMaxDepth + 1], o_gy[kMaxDepth + 1], o_go[kMaxDepth], o_gu[kMaxDepth];
-    for (int d = 0; d <= depth; ++d) {
-        o_gx[d] = gtake((size_t)nb * kFeat * plane(d));
-        o_gy[d] = gtake((size_t)nb * kFeat * plane(d));
-        if (d < depth) { o_go[d] = gtake((size_t)nb * kFeat * plane(d)); o_gu[d] = gtake((size_t)nb * kFeat * plane(d)); }
+    size_t o_gx[2][kMaxDepth + 1], o_gy[2][kMaxDepth + 1], o_go[2][kMaxDepth], o_gu[2][kMaxDepth];
+    size_t o_gz[2][3 * kMaxDepth + 2];   // slots as Trainer::slot_*: inc, sig[d], st[d], dec[d]
+    for (int k = 0; k < 2; ++k) {
+        for (int d = 0; d <= depth; ++d) {
+            o_gx[k][d] = gtake((size_t)nb * kFeat * plane(d));
+            o_gy[k][d] = gtake((size_t)nb * kFeat * plane(d));
+            if (d < depth) { o_go[k][d] = gtake((size_t)nb * kFeat * plane(d)); o_gu[k][d] = gtake((size_t)nb * kFeat * plane(d)); }
+        }
+        o_gz[k][0] = gtake((size_t)nb * kFeat * plane(0));
+        for (int d = 0; d < depth; ++d) {
+            o_gz[k][1 + d] = gtake((size_t)nb * kFeat * plane(d));
+            o_gz[k][1 + depth + d] = gtake((size_t)nb * kState * plane(d));
+        }
+        for (int d = 0; d <= depth; ++d) o_gz[k][1 + 2 * depth + d] = gtake((size_t)nb * kFeat * plane(d));
     }
-    size_t o_gz[3 * kMaxDepth + 2];   // slots as Trainer::slot_*: inc, sig[d], st[d], dec[d]
-    o_gz[0] = gtake((size_t)nb * kFeat * plane(0));
-    for (int d = 0; d < depth; ++d) {
-        o_gz[1 + d] = gtake((size_t)nb * kFeat * plane(d));
-        o_gz[1 + depth + d] = gtake((size_t)nb * kState * plane(d));
-    }
-    for (int d = 0; d <= depth; ++d) o_gz[1 + 2 * depth + d] = gtake((size_t)nb * kFeat * plane(d));
     const size_t o_wf0 = gtake((size_t)nb * 2 * plane(0)), o_wf1 = gtake((size_t)nb * 2 * plane(0)), o_res = gtake((size_t)nb * 2 * plane(0));
-    const size_t o_st0 = gtake((size_t)nb * kState * ctx->state_len), o_st1 = gtake((size_t)nb * kState * ctx->state_len);
+    size_t o_st[3];
+    for (size_t& o : o_st) o = gtake((size_t)nb * kState * ctx->state_len);
     HN_HIP(ctx, hipMalloc((void**)&W.gbuf, sizeof(float) * g));
-    for (int d = 0; d <= depth; ++d) {
-        W.g_x[d] = W.gbuf + o_gx[d];
-        W.g_y[d] = W.gbuf + o_gy[d];
-        if (d < depth) { W.g_out[d] = W.gbuf + o_go[d]; W.g_u[d] = W.gbuf + o_gu[d]; }
+    for (int k = 0; k < 2; ++k) {
+        auto& G = W.gset[k];
+        for (int d = 0; d <= depth; ++d) {
+            G.g_x[d] = W.gbuf + o_gx[k][d];
+            G.g_y[d] = W.gbuf + o_gy[k][d];
+            if (d < depth) { G.g_out[d] = W.gbuf + o_go[k][d]; G.g_u[d] = W.gbuf + o_gu[k][d]; }
+        }
+        for (int i = 0; i < 3 * depth + 2; ++i) G.gz[i] = W.gbuf + o_gz[k][i];
     }
-    for (int i = 0; i < 3 * depth + 2; ++i) W.gz[i] = W.gbuf + o_gz[i];
+    select_gset(W, 0);
     W.g_wf[0] = W.gbuf + o_wf0; W.g_wf[1] = W.gbuf + o_wf1; W.g_res = W.gbuf + o_res;
-    W.g_st[0] = W.gbuf + o_st0; W.g_st[1] = W.gbuf + o_st1;
+    for (int k = 0; k < 3; ++k) W.g_st[k] = W.gbuf + o_st[k];
+    HN_HIP(ctx, hipStreamCreateWithFlags(&W.wg_stream, hipStreamNonBlocking));
+    for (int k = 0; k < 2; ++k) {
+        HN_HIP(ctx, hipEventCreateWithFlags(&W.wg_ready[k], hipEventDisableTiming));
+        HN_HIP(ctx, hipEventCreateWithFlags(&W.wg_done[k], hipEventDisableTiming));
+    }
     const size_t total = raw_layout(depth).total;
     W.part_floats = (size_t)kPartRows * total;
     HN_HIP(ctx, hipMalloc((void**)&W.part, sizeof(float) * W.part_floats));
@@ -1383,7 +1420,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
-    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = ctx->opt_train_fused != 0; }
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = ctx->opt_train_fused != 0; t.overlap = ctx->opt_train_overlap != 0; }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
     struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};
@@ -1458,6 +1495,8 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
                 return rc;
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
+        for (int k = 0; k < 2; ++k)   // the side stream's weight-gradient launches join the lane's stream
+            if (W.wg_pending[k]) { HN_HIP(ctx, hipStreamWaitEvent(ls[l], W.wg_done[k], 0)); W.wg_pending[k] = false; }
         if (!capturing) {
             HN_HIP(ctx, hipEventRecord(W.jobs_copied[W.jobs_set], ls[l]));
             W.jobs_in_flight[W.jobs_set] = true;

@@ -7,9 +7,12 @@ Mirrors, without Lightning: ``helmnet/replaybuffer.py:1-47`` (``Experience`` / `
 time, gradient clipping and the Adam update -- runs in libhelmnet_hip.so (``hn_train_grad`` / ``hn_adam_step``); this
 module holds the flat parameter / gradient / moment tensors, the replay buffer and the host-side bookkeeping.
 
-Data-parallel training (the reference trains with Lightning DDP, train.py:103-112): one process per GPU, every rank
-draws its own replay-buffer batch, the flat gradient (one 193 KB bucket) is averaged with a single all-reduce over
-RCCL between ``hn_train_grad`` and ``hn_adam_step`` (``allreduce_gradients``), so the replicas stay bit-identical.
+Data-parallel training (the reference trains with Lightning DDP, train.py:103-112): one process per GPU.  The replicas start
+from rank 0's parameters and Adam moments (``broadcast_from_rank0`` in ``Trainer.__init__`` / ``load_state_dict``: what DDP does
+when it wraps the module), every rank draws its own replay-buffer batch, the flat gradient (one 193 KB bucket) is averaged
+with a single all-reduce over RCCL between ``hn_train_grad`` and ``hn_adam_step`` (``allreduce_gradients``), and the
+epoch-mean loss the learning-rate scheduler monitors is averaged over the ranks (``allreduce_mean_scalar``): same weights,
+same moments, same gradient, same learning rate on every rank, so the replicas stay bit-identical.
 """
 from __future__ import annotations
 
@@ -29,26 +32,84 @@ Experience = collections.namedtuple(
 
 
 class ReplayBuffer:
-    """replaybuffer.py:20-47: a fixed-capacity list of Experiences addressed by index; ``sample`` draws ``batch_size``
-    distinct slots with ``np.random.choice`` and stacks the fields."""
+    """The reference's replay buffer (replaybuffer.py:20-47: ``capacity`` slots addressed by index, ``sample`` draws distinct
+    slots with ``np.random.choice(capacity, batch_size, replace=False)``) kept as ONE pre-allocated ``[capacity, ...]`` tensor per
+    field on the device of the first experience written: ``sample`` is an ``index_select`` per field and a training step writes
+    its advanced / fresh experiences back with one ``index_copy_`` per field (``write``) instead of ``batch_size`` Python-side
+    clones and a ``torch.stack`` of 5 x ``batch_size`` tensors.  Under a seed the sampled indices are the reference's."""
+
+    FIELDS = ("wavefield", "hidden_state", "k_sq", "residual", "source")
 
     def __init__(self, capacity: int):
-        self.buffer = [None for _ in range(capacity)]
         self.capacity = capacity
+        self.fields: Optional[dict] = None                       # name -> [capacity, ...] tensor
+        self.iteration = np.zeros(capacity, dtype=np.int64)      # nominal solver iteration of every slot (host side: it only feeds Python logic)
+        self.filled = np.zeros(capacity, dtype=bool)
 
     def __len__(self):
         return self.capacity
 
-    def append(self, experience, index):
-        self.buffer[index] = experience
+    def _ensure(self, like: dict):
+        if self.fields is None:
+            self.fields = {k: torch.empty((self.capacity,) + tuple(v.shape[1:]), dtype=v.dtype, device=v.device) for k, v in like.items()}
 
-    def sample(self, batch_size: int):
+    def write(self, indices, wavefield, hidden_state, k_sq, residual, source, iterations):
+        """Batched ``append``: slot ``indices[j]`` <- the j-th row of every field (``indices``: 1-D integer tensor / array)."""
+        vals = dict(zip(self.FIELDS, (wavefield, hidden_state, k_sq, residual, source)))
+        self._ensure(vals)
+        idx_host = np.asarray(indices.cpu() if torch.is_tensor(indices) else indices, dtype=np.int64).reshape(-1)
+        if idx_host.size == 0:
+            return
+        for k, v in vals.items():
+            buf = self.fields[k]
+            buf.index_copy_(0, torch.as_tensor(idx_host, device=buf.device), v.to(device=buf.device, dtype=buf.dtype))
+        self.iteration[idx_host] = np.asarray(iterations, dtype=np.int64).reshape(-1)
+        self.filled[idx_host] = True
+
+    def append(self, experience, index):   # replaybuffer.py:29-30
+        self.write([index], *(f.unsqueeze(0) for f in experience[:5]), [experience[5]])
+
+    @property
+    def buffer(self):
+        """The reference's list view: an ``Experience`` of views per written slot, ``None`` for an empty one."""
+        return [Experience(*(self.fields[k][i] for k in self.FIELDS), int(self.iteration[i])) if self.filled[i] else None for i in range(self.capacity)]
+
+    def sample(self, batch_size: int):     # replaybuffer.py:32-47
         if batch_size > self.capacity:
             batch_size = self.capacity
         indices = np.random.choice(self.capacity, batch_size, replace=False)
-        wavefields, h_states, k_sqs, residual, source, iterations = zip(*[self.buffer[t] for t in indices])
-        return (torch.stack(wavefields, 0), torch.stack(h_states, 0), torch.stack(k_sqs, 0), torch.stack(residual, 0),
-                torch.stack(source, 0), iterations, indices)
+        if not self.filled[indices].all():
+            raise ValueError("sampled an empty replay-buffer slot: fill the buffer first (fill_replay_buffer)")
+        out = []
+        for k in self.FIELDS:
+            buf = self.fields[k]
+            out.append(buf.index_select(0, torch.as_tensor(indices, device=buf.device)))
+        return (*out, tuple(int(i) for i in self.iteration[indices]), indices)
+
+
+def _world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def broadcast_from_rank0(*tensors: torch.Tensor) -> None:
+    """What wrapping a module in DDP does once (train.py:103-112 under Lightning): every rank starts from rank 0's parameters (here also
+    its optimiser moments, for a resumed run).  A no-op without an initialised process group."""
+    if _world_size() > 1:
+        import torch.distributed as dist
+        for t in tensors:
+            dist.broadcast(t, src=0)
+
+
+def allreduce_mean_scalar(value: float, device="cpu") -> float:
+    """Mean of a per-rank scalar over the ranks (the epoch-mean training loss ReduceLROnPlateau monitors: Lightning logs it with the
+    mean over ranks, so every replica's scheduler sees the same number and the learning rates cannot drift apart)."""
+    if _world_size() > 1:
+        import torch.distributed as dist
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return float(t[0]) / dist.get_world_size()
+    return value
 
 
 def allreduce_gradients(grad: torch.Tensor) -> torch.Tensor:
@@ -111,6 +172,7 @@ class Trainer:
         self.exp_avg = torch.zeros_like(self.weights)
         self.exp_avg_sq = torch.zeros_like(self.weights)
         self.trainable = torch.from_numpy(trainable_mask(f.depth, f.activation_function, f.state_depth)).to(dev)
+        broadcast_from_rank0(self.weights, self.exp_avg, self.exp_avg_sq)   # DDP: every replica starts from rank 0's state
         self.step_count = 0
         self.current_epoch = 0
         self.global_step = 0
@@ -146,28 +208,35 @@ class Trainer:
         self.step_count, self.lr, self.current_epoch, self.global_step = int(sd["step"]), float(sd["lr"]), int(sd["epoch"]), int(sd["global_step"])
         self.scheduler.load_state_dict(sd["scheduler"])
         self._lr_holder.param_groups[0]["lr"] = self.lr
+        broadcast_from_rank0(self.weights, self.exp_avg, self.exp_avg_sq)
         self.sync_to_module()
 
     # ------------------------------------------------------------------ replay buffer -----------
-    def _fresh_experience(self, sos_map: torch.Tensor, iteration: int) -> Experience:
-        """Initial (zero wavefield) experience of one [1, 1, N, N] sound-speed map (hybridnet.py:203-216, 454-462)."""
+    def _fresh_fields(self, sos_maps: torch.Tensor):
+        """Initial (zero wavefield) experiences of a batch of [n, 1, N, N] sound-speed maps (hybridnet.py:203-216, 454-462) as the five
+        field tensors: ONE get_initials and ONE residual call for the whole batch."""
         s = self.solver
         s.reset_source()
-        k_sq, wf = s.get_initials(sos_map.float().to(s.device))
+        k_sq, wf = s.get_initials(sos_maps.float().to(s.device))
         s.f.clear_states(wf)
         h = s.f.get_states(flatten=True)
         # after set_source_maps(sources) the reference's self.source holds one map per sample and its get_residual broadcasts
         # (:556); the maps of a batch are equal unless the caller set different ones -- the first one is the source of a fresh slot
         src0 = s.source[:1].detach().float().contiguous()
         res = s.engine().residual(wf, k_sq.contiguous(), src0)
-        return Experience(wf[0], h[0], k_sq[0], res[0], src0[0], iteration)
+        return wf, h, k_sq, res, src0.expand(wf.shape[0], -1, -1, -1)
 
-    def fill_replay_buffer(self, sos_train):
+    def _fresh_experience(self, sos_map: torch.Tensor, iteration: int) -> Experience:
+        return Experience(*(f[0] for f in self._fresh_fields(sos_map)), iteration)
+
+    def fill_replay_buffer(self, sos_train, chunk: int = 64):
         """hybridnet.py:192-218: one fresh experience per slot, slot ``c`` starting at nominal iteration ``10 c``."""
         with torch.no_grad():
-            for counter in range(len(self.replaybuffer)):
-                sos_map = torch.as_tensor(sos_train[counter]).unsqueeze(0)
-                self.replaybuffer.append(self._fresh_experience(sos_map, counter * 10), counter)
+            cap = len(self.replaybuffer)
+            for c0 in range(0, cap, chunk):
+                idx = list(range(c0, min(c0 + chunk, cap)))
+                maps = torch.stack([torch.as_tensor(sos_train[c]) for c in idx])
+                self.replaybuffer.write(idx, *self._fresh_fields(maps), [10 * c for c in idx])
 
     # ------------------------------------------------------------------ one step ----------------
     def loss_and_grad(self, wavefields, h_states, k_sqs, residual, sources, num_iterations: Optional[int] = None, input_grads: bool = False):
@@ -199,18 +268,20 @@ class Trainer:
         T = out["residuals"].shape[0]
         iteration = np.random.choice(T)
         res_it, wf_it, st_it = out["residuals"][iteration], out["wavefields"][iteration], out["states"][iteration]
-        keep = (res_it.pow(2).mean((1, 2, 3)) < 1).cpu().numpy()      # one device-to-host read for the whole batch
-        counter = 0
-        for sample_idx in range(wavefields.shape[0]):
-            new_timesteps = timesteps[sample_idx] + iteration + 1
-            if keep[sample_idx] and new_timesteps < maxiter:
-                exp = Experience(wf_it[sample_idx].clone(), st_it[sample_idx].clone(), k_sqs[sample_idx], res_it[sample_idx].clone(),
-                                 sources[sample_idx], new_timesteps)
-            else:
-                with torch.no_grad():
-                    exp = self._fresh_experience(choice(sos_batch).unsqueeze(0), 0)
-                counter += 1
-            self.replaybuffer.append(exp, indices[sample_idx])
+        # which sampled slots keep their (advanced) experience: bounded residual and young enough (:436-452).  ONE device-to-host read
+        # per step: the count of rejected slots decides how many fresh maps Python's ``choice`` draws, as in the reference's loop.
+        new_timesteps = np.asarray(timesteps, dtype=np.int64) + iteration + 1
+        keep = (res_it.pow(2).mean((1, 2, 3)) < 1).cpu().numpy() & (new_timesteps < maxiter)
+        kept, fresh = np.nonzero(keep)[0], np.nonzero(~keep)[0]
+        with torch.no_grad():
+            if kept.size:
+                k = torch.as_tensor(kept, device=wf_it.device)
+                self.replaybuffer.write(indices[kept], wf_it.index_select(0, k), st_it.index_select(0, k), k_sqs.index_select(0, k),
+                                        res_it.index_select(0, k), sources.index_select(0, k), new_timesteps[kept])
+            if fresh.size:   # one random map of this batch per rejected slot (drawn in slot order, as the reference's loop does), solved from scratch
+                maps = torch.stack([choice(sos_batch) for _ in fresh])
+                self.replaybuffer.write(indices[fresh], *self._fresh_fields(maps), np.zeros(fresh.size, dtype=np.int64))
+        counter = int(fresh.size)
         self.new_sos = counter
         self.global_step += 1
         self.epoch_losses.append(loss.detach())
@@ -219,6 +290,7 @@ class Trainer:
     def training_epoch_end(self) -> float:
         """hybridnet.py:379-383 + the scheduler step Lightning performs on ``train_loss_mean`` once per epoch (:276-281)."""
         mean = float(torch.stack(self.epoch_losses).mean()) if self.epoch_losses else float("nan")
+        mean = allreduce_mean_scalar(mean, self.weights.device)   # every replica's scheduler monitors the same number
         self.epoch_losses = []
         self.scheduler.step(mean)
         self.lr = float(self._lr_holder.param_groups[0]["lr"])
@@ -230,7 +302,7 @@ class Trainer:
         """A plain training loop over ``sos_train`` ([M, 1, N, N] tensor or dataset of [1, N, N] maps), batches of hparams.batch_size,
         ``drop_last=True`` as train_dataloader (:221-226).  Returns the epoch-mean losses."""
         hp = self.solver.hparams
-        if self.replaybuffer.buffer[0] is None:
+        if not self.replaybuffer.filled.all():
             self.fill_replay_buffer(sos_train)
         n = len(sos_train)
         history = []

@@ -88,9 +88,12 @@ enum hn_option {
                               * multiplies; weights G g G^T composed in float64 at hn_load_weights): sum of 1 (inc), 2 (conv_signal),
                               * 8 (decoder); default 11 = all three, 0 = the direct kernels HN_OPT_DC_VALU selects.  Same fp32 sums in
                               * another order: agrees with the direct kernels to fp32 rounding                              */
-    HN_OPT_TRAIN_FUSED = 10  /* hn_train_grad, forward pass: 1 (default) an 8-channel DoubleConv is ONE launch of the fused matrix-core
+    HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad, forward pass: 1 (default) an 8-channel DoubleConv is ONE launch of the fused matrix-core
                               * kernels of the inference path, which also store the pre-activation mid tensor to the tape; 0: every
                               * convolution as its own direct launch (round 3).  Same tape within fp32 rounding                */
+    HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: 1 (default) the three weight-gradient launches of unrolled iteration t run on
+                              * a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers); 0: in line
+                              * on the caller's stream.  Bit-identical gradients (the launches keep their order)                  */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };

@@ -104,10 +104,14 @@ def test_weight_blob_round_trip_and_trainable_mask(weights):
 
 
 def test_replay_buffer_follows_the_reference_semantics():
-    """replaybuffer.py:20-47: fixed capacity, append by index, sample without replacement, stacked fields, capacity clamp."""
+    """replaybuffer.py:20-47: fixed capacity, append by index, sample without replacement, stacked fields, capacity clamp -- on the
+    pre-allocated [capacity, ...] field tensors, with the batched write the training step uses; the indices drawn under a seed are the
+    ones ``np.random.choice(capacity, batch, replace=False)`` gives the reference."""
     from helmnet_amd.training import Experience, ReplayBuffer
     rb = ReplayBuffer(6)
     assert len(rb) == 6 and rb.buffer == [None] * 6
+    with pytest.raises(ValueError):
+        np.random.seed(0); rb.sample(2)          # nothing written yet
     for i in range(6):
         rb.append(Experience(torch.full((2, 4, 4), float(i)), torch.full((2, 21), float(i)), torch.ones(1, 4, 4), torch.zeros(2, 4, 4),
                              torch.ones(2, 4, 4), 10 * i), i)
@@ -115,9 +119,17 @@ def test_replay_buffer_follows_the_reference_semantics():
     wf, h, k, r, s, its, idx = rb.sample(4)
     assert wf.shape == (4, 2, 4, 4) and h.shape == (4, 2, 21) and k.shape == (4, 1, 4, 4) and s.shape == (4, 2, 4, 4)
     assert len(set(idx.tolist())) == 4 and [int(wf[j, 0, 0, 0]) for j in range(4)] == idx.tolist() and list(its) == [10 * j for j in idx]
+    np.random.seed(1)
+    assert idx.tolist() == np.random.choice(6, 4, replace=False).tolist()      # the reference's draw
     assert rb.sample(99)[0].shape[0] == 6
-    rb.append(Experience(*([torch.zeros(1)] * 5), 7), 2)
-    assert rb.buffer[2].iteration == 7
+    rb.append(Experience(torch.zeros(2, 4, 4), torch.zeros(2, 21), torch.zeros(1, 4, 4), torch.zeros(2, 4, 4), torch.zeros(2, 4, 4), 7), 2)
+    assert rb.buffer[2].iteration == 7 and float(rb.buffer[2].wavefield.abs().max()) == 0.0
+    # batched write (what training_step does with its advanced / fresh experiences): rows land in their slots, the others are untouched
+    rb.write(np.array([5, 0]), torch.full((2, 2, 4, 4), 9.0), torch.full((2, 2, 21), 9.0), torch.ones(2, 1, 4, 4), torch.zeros(2, 2, 4, 4),
+             torch.ones(2, 2, 4, 4), [31, 32])
+    assert [b.iteration for b in rb.buffer] == [32, 10, 7, 30, 40, 31]
+    assert float(rb.buffer[5].wavefield[0, 0, 0]) == 9.0 and float(rb.buffer[1].wavefield[0, 0, 0]) == 1.0
+    rb.write(np.array([], dtype=np.int64), *(torch.zeros(0, 2, 4, 4), torch.zeros(0, 2, 21), torch.zeros(0, 1, 4, 4), torch.zeros(0, 2, 4, 4), torch.zeros(0, 2, 4, 4)), [])
 
 
 def _free_port():
@@ -137,6 +149,54 @@ def _ddp_worker(rank, world, port, q):
         q.put((rank, g.tolist()))
     finally:
         dist.destroy_process_group()
+
+
+def _ddp_sync_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from helmnet_amd.training import allreduce_gradients, allreduce_mean_scalar, broadcast_from_rank0
+        torch.manual_seed(100 + rank)                      # every rank initialises differently, as freshly constructed modules do
+        w, m, v = torch.randn(50), torch.rand(50), torch.rand(50)
+        broadcast_from_rank0(w, m, v)
+        holder = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1e-3)
+        sched = torch.optim.lr_scheduler.ReduceLROnPlateau(holder, mode="min", factor=0.5, patience=1, min_lr=1e-6)
+        lrs = []
+        for epoch in range(6):
+            for step in range(2):                          # two data-parallel steps: rank-local gradients, averaged, plain SGD on the blob
+                g = torch.randn(50) * (rank + 1)
+                allreduce_gradients(g)
+                w -= holder.param_groups[0]["lr"] * g
+            # rank-local epoch losses that would trip the plateau detector in DIFFERENT epochs on the two ranks
+            local = [1.0, 0.9, 0.95, 0.97, 0.5, 0.6][epoch] if rank == 0 else [1.0, 1.1, 1.2, 0.2, 0.3, 0.4][epoch]
+            sched.step(allreduce_mean_scalar(local))
+            lrs.append(holder.param_groups[0]["lr"])
+        q.put((rank, w.tolist(), m.tolist(), lrs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_replicas_stay_identical_gloo():
+    """the replicas start from rank 0's weights / moments and step their learning-rate schedulers on the SAME (rank-mean) epoch
+    loss -- with rank-local losses the two schedulers below would halve the rate in different epochs (world size 2, gloo on the CPU)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_ddp_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    got = {r[0]: r[1:] for r in (q.get(timeout=120) for _ in ps)}
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[0][0] == got[1][0] and got[0][1] == got[1][1]      # weights after 12 steps, broadcast moments: bit-identical
+    assert got[0][2] == got[1][2] and got[0][2][-1] < 1e-3        # same learning-rate history, and the plateau logic did act
+    from helmnet_amd.training import allreduce_mean_scalar, broadcast_from_rank0
+    t = torch.ones(2)
+    broadcast_from_rank0(t)                                       # no process group: identity
+    assert allreduce_mean_scalar(0.25) == 0.25 and torch.equal(t, torch.ones(2))
 
 
 def test_gradient_allreduce_averages_over_ranks_gloo():
