@@ -158,3 +158,25 @@ def test_phantoms():
     assert r[0, 0, 100, 30] == 2.0 and r[0, 0, 169, 239] == 1.0 and r[0, 0, 0, 0] == 1.0
     s = smooth_random_sos(64, 2)
     assert s.shape == (2, 1, 64, 64) and 1.0 <= s.min() and s.max() <= 2.0
+
+
+def test_gmres_hessenberg_least_squares_on_the_host_matches_lstsq():
+    """helmnet_amd/gmres.py solves the (m + 1) x m Hessenberg least-squares problem once per restart cycle with Givens rotations (the
+    reference leaves this to MATLAB's gmres, matlab/spectral_gmres_solver.m:107): the truncated solutions and the residual norm after every
+    inner iteration equal numpy's dense least-squares answers."""
+    import numpy as np
+    from helmnet_amd.gmres import _back_substitute, _hessenberg_least_squares
+    rng = np.random.default_rng(0)
+    B, m = 3, 9
+    H = np.zeros((B, m + 1, m), complex)
+    for j in range(m):
+        H[:, : j + 2, j] = rng.standard_normal((B, j + 2)) + 1j * rng.standard_normal((B, j + 2))
+    beta = np.abs(rng.standard_normal(B)) + 1.0
+    R, g, res = _hessenberg_least_squares(H, beta)
+    for k in (1, 4, 9):
+        y = _back_substitute(R, g, k)
+        for b in range(B):
+            e = np.zeros(k + 1, complex)
+            e[0] = beta[b]
+            yl = np.linalg.lstsq(H[b, : k + 1, :k], e, rcond=None)[0]
+            assert np.allclose(y[b], yl) and np.isclose(res[b, k - 1], np.linalg.norm(e - H[b, : k + 1, :k] @ yl))

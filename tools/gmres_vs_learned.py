@@ -8,7 +8,7 @@ RMSE (hybridnet.py:295-297, worst sample) GMRES reached, and to its own floor; t
 reference's own metric (support_functions.py:23-48: source-normalised, PML cropped; no conjugation -- both come
 from the same operator).
 
-    python tools/gmres_vs_learned.py [--n 256] [--batch 8] > profiles/r3_gmres_vs_learned.json
+    python tools/gmres_vs_learned.py [--n 256] [--batch 4] > profiles/r4_gmres_vs_learned.json
 """
 import argparse
 import json
@@ -57,6 +57,13 @@ def main():
     rm_g = float(hist[-1].max())
     out["gmres"] = {"iterations": its, "seconds": round(t_g, 3), "worst_rmse_reached": rm_g, "iterations_per_s": round(its / t_g, 1),
                     "wall_budget_s": a.budget}
+    # the pure Arnoldi rate: full restart cycles that cannot converge (tol = 0), no early exit
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    gg = gmres(s, sos, restart=a.restart, max_outer=25, tol=0.0, x0=x)
+    torch.cuda.synchronize()
+    t_a = time.perf_counter() - t0
+    out["gmres"]["arnoldi_iterations_per_s"] = round(gg["operator_applications"] / t_a, 1)
     # the learned solver to the SAME residual level (and to its own floor)
     for tol in (max(rm_g, 1e-6), 2e-4):
         torch.cuda.synchronize()
@@ -73,8 +80,9 @@ def main():
             "gmres_iterations_over_learned_iterations": round(its / r["iterations"], 2) if tol >= rm_g else None,
             "difference_to_gmres_wavefield_linf_source_normalised": float(diff.flatten(1).max(dim=1).values.max()),
             "difference_to_gmres_wavefield_rmse_source_normalised": float(diff.pow(2).mean([1, 2]).sqrt().max())})
-    out["note"] = ("GMRES here keeps its Krylov bookkeeping in PyTorch tensor ops (modified Gram-Schmidt, a small least-squares solve per inner "
-                   "iteration): its seconds include that host-driven plumbing, its operator applications are the hardware-independent count")
+    out["note"] = ("r4: the Krylov bookkeeping runs on the device (batched matrix-vector products over one basis tensor, classical Gram-Schmidt "
+                   "with re-orthogonalisation, no host read-back inside a restart cycle; the Hessenberg least-squares problem is solved once per "
+                   "cycle).  r3 (per-vector modified Gram-Schmidt + lstsq + a host sync per inner iteration) ran at 13 it/s")
     print(json.dumps(out, indent=1))
 
 
