@@ -163,10 +163,10 @@ def make_problem(solver, n, B, loc, seed, dev, readme_first):
     return eng, sos_np, (wf, res, st, k_sq.contiguous(), solver.source.detach().contiguous())
 
 
-def secondary(solver, dev, n, B, precision, steps, warmup):
+def secondary(solver, dev, n, B, precision, steps, warmup, loc=None, seed=5, readme_first=False, label=None):
     """A short measured run of another configuration (rank 0, N = 1 only): it/s plus the dominant-kernel time."""
     solver.set_unet_precision(precision)
-    eng, _, (wf, res, st, k_sq, src) = make_problem(solver, n, B, [n - 62, n // 2], 5, dev, False)
+    eng, _, (wf, res, st, k_sq, src) = make_problem(solver, n, B, [n - 62, n // 2] if loc is None else loc, seed, dev, readme_first)
     rmse = torch.zeros(max(steps, warmup), B, device=dev)
     eng.step(wf, res, st, k_sq, src, warmup, rmse_hist=rmse[:warmup])
     torch.cuda.synchronize()
@@ -175,7 +175,7 @@ def secondary(solver, dev, n, B, precision, steps, warmup):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     flops = 2.0 * sum(kernel_macs(n).values()) * B
-    return {"workload": f"{n}x{n} ring-phantom SoS maps, batch={B}, point source, UNet precision {precision}",
+    return {"workload": label or f"{n}x{n} ring-phantom SoS maps, batch={B}, point source, UNet precision {precision}",
             "dtype": DTYPE[precision], "value": round(steps / dt, 2), "unit": "iterations/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 4), "sample_iterations_per_s": round(B * steps / dt, 1),
             "unet_tflops_fp32_equivalent": round(flops * steps / dt / 1e12, 2),
@@ -213,6 +213,73 @@ def secondary_train_step(solver, dev, n=96, B=32, unroll=10, steps=8, warmup=3):
             "approx_tflops_forward_plus_backward": round(3 * fwd_flop / dt / 1e12, 2), "loss": float(o["loss"][0])}
 
 
+def train_main(args, rank, world, dev, dist):
+    """``bench.py --train``: the data-parallel TRAINING step (hybridnet.py:385-413 under Lightning DDP, train.py:103-112) --
+    per rank a replay-buffer batch of its own (32 maps at 96^2, 5 solver iterations in), hn_train_grad (10 unrolled iterations, forward +
+    backward), ONE all-reduce of the flat 193 KB gradient over RCCL, hn_adam_step.  Weak scaling: 32 maps per GPU.  The replicas start from
+    rank 0's weights (broadcast) and stay bit-identical."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.engine import pack_weights
+    from helmnet_amd.training import allreduce_gradients, broadcast_from_rank0
+    n, B, K, W, unroll = (96 if args.size == 256 else args.size), args.batch, args.steps, args.warmup, 10
+    solver = IterativeSolver.from_exported_weights()
+    solver.to(dev)
+    eng, _, (wf, res, st, k_sq, src) = make_problem(solver, n, B, [n - 14, n // 2], 100 + rank, dev, False)
+    for kv in args.opt:
+        name, value = kv.split("=")
+        eng.set_option(name, int(value))
+    eng.step(wf, res, st, k_sq, src, 5)
+    src_b = src.repeat(B, 1, 1, 1).contiguous() if src.shape[0] == 1 else src
+    w = torch.from_numpy(pack_weights(dict(solver.f.state_dict()))).to(dev)
+    m, v, g = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
+    broadcast_from_rank0(w, m, v)
+
+    def step(i):
+        o = eng.train_grad(w, wf, res, st, k_sq, src_b, unroll, 1e4, grad=g)
+        allreduce_gradients(g)
+        eng.adam_step(w, g, m, v, i + 1, 1e-5, (0.9, 0.95), 1e-8, 1e-6, 1.0)
+        return o
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(W, 2)):
+        o = step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        o = step(W + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    same = True
+    if dist is not None:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+        w0 = w.clone()
+        dist.broadcast(w0, src=0)
+        flag = torch.tensor([1.0 if torch.equal(w0, w) else 0.0], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        same = bool(flag.item() == 1.0)
+    if rank == 0:
+        fwd_flop = 2.0 * sum(kernel_macs(n).values()) * B * unroll
+        print(json.dumps({
+            "metric": f"training sample-iterations/sec (whole node), {n}^2 domain, batch={B} per GPU x {unroll} unrolled iterations",
+            "value": round(world * B * unroll * K / dt, 1), "unit": "sample-iterations/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"training step (SURVEY 8 f4): {n}x{n} ring phantoms, batch={B} per GPU, {unroll} unrolled iterations, forward + "
+                                   "backward + gradient all-reduce (one 193 KB bucket, RCCL) + Adam", "options": args.opt,
+                       "parallelism": f"dp{world} (each rank its own replay batch; one gradient all-reduce per step)"},
+            "approx_tflops_forward_plus_backward": round(world * 3 * fwd_flop * K / dt / 1e12, 2), "loss_rank0": float(o["loss"][0]),
+            "replicas_bit_identical_after_run": same}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 STEP_COMPULSORY_BYTES_256 = 3751936.0   # SURVEY.md 8(d): read 4[(2+2+1) N^2 + 2 sum N_d^2] + write 4[(2+2) N^2 + 2 sum N_d^2] at N = 256
 
 
@@ -237,6 +304,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the short 512^2 / bf16x3 side measurements")
     ap.add_argument("--breakdown", action="store_true", help="also print the per-kernel time table (stderr)")
+    ap.add_argument("--train", action="store_true",
+                    help="time the data-parallel TRAINING step instead (96^2, batch 32 per GPU, 10 unrolled iterations, gradient all-reduce over RCCL); "
+                         "a separate JSON line, not the headline metric")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -254,6 +324,9 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.train:
+        return train_main(args, rank, world, dev, dist)
 
     from helmnet_amd import IterativeSolver
     from helmnet_amd.distributed import allreduce_residual_norms
@@ -410,7 +483,7 @@ def main():
         # every level-0 kernel of the main chain: shortest event-bracketed launch of the warm-up pass against the fp32 peak
         line["level0_kernels_note"] = ("shortest launch per kernel in the warm-up pass in which EVERY kernel is bracketed by an event pair: each figure carries "
                                        "~5-8 us of event overhead (decode0: compare roofline.avg_launch_us, sampled in the timed region); rocprofv3 durations "
-                                       "are in profiles/r3_kernel_stats.csv")
+                                       "are in profiles/r4_kernel_stats.csv")
         line["level0_kernels"] = [{"kernel": k, "us": round(pmin[k] * 1e3, 2), "tflops": round(2.0 * macs[k] * B / per_step / (pmin[k] * 1e-3) / 1e12, 1),
                                    "frac": round(2.0 * macs[k] * B / per_step / (pmin[k] * 1e-3) / 1e12 / PEAK_TFLOPS[prec], 4)}
                                   for k in ("inc", "conv_signal0", "down0", "up0", "decode0") if k in pmin and k in macs and pmin[k] > 0]
@@ -441,7 +514,10 @@ def main():
                   f"conv_state* run on the side stream, overlapped)", file=sys.stderr)
         if world == 1 and not args.no_secondary and (n, B, prec) == (256, 32, "fp32"):
             # driver-visible side measurements: same process, a few seconds each
-            line["secondary"] = [secondary(solver, dev, 512, 16, "fp32", 40, 10),
+            line["secondary"] = [secondary(solver, dev, 256, 32, "fp32", 300, 20, loc=loc, seed=rank, readme_first=True,
+                                           label="the HEADLINE workload again, 300 timed steps after 20 (VERDICT r3 #10: the driver's --steps 20 "
+                                                 "region is 10 ms; this is the same loop over 150 ms in the same process)"),
+                                 secondary(solver, dev, 512, 16, "fp32", 40, 10),
                                  secondary(solver, dev, 256, 32, "bf16x3", 60, 10),
                                  secondary(solver, dev, 512, 16, "fp16", 40, 10),
                                  secondary_train_step(solver, dev)]
