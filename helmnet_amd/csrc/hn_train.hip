@@ -177,6 +177,37 @@ struct WindowStager {
 // Wave-uniform reads through the constant address space become scalar loads (SGPR operands of the FMAs).
 typedef const float __attribute__((address_space(4))) * CfPtr;
 __device__ __forceinline__ CfPtr cf(const float* p) { return (CfPtr)(uintptr_t)p; }
+// ... and channel PAIRS of the packed 3x3 weights as SGPR pairs of v_pk_fma_f32 (the packed arrays start at even offsets: pk_off)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef const f32x2 __attribute__((address_space(4))) * Cf2Ptr;
+__device__ __forceinline__ Cf2Ptr cf2(const float* p) { return (Cf2Ptr)(uintptr_t)p; }
+__host__ __device__ constexpr long pk_off(long raw_off) { return (raw_off + 1) & ~1L; }   // the float after a 3x3 weight tensor is a bias: never packed
+
+// The 9-tap x CO-channel FMA block of the direct 3x3 kernels for one input channel.  HN_TRAIN_PK 1: packed over channel pairs (v_pk_fma_f32 with an
+// SGPR-pair weight operand, half the issue slots); 0: scalar v_fma_f32.  [measured, r4, same box] packed is SLOWER in these latency-bound kernels
+// (step 9.82 vs 9.60 ms with fused forward, 11.51 vs 11.15 without: the pair operands cost SGPR alignment / spills): scalar is the default.
+#ifndef HN_TRAIN_PK
+#define HN_TRAIN_PK 0
+#endif
+template <int CO>
+__device__ __forceinline__ void fma_taps(float (&acc)[CO], const float* wpk_ci, const float (&v)[9]) {
+#if HN_TRAIN_PK
+    const Cf2Ptr wq = cf2(wpk_ci);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int c = 0; c < CO / 2; ++c) {
+            const f32x2 r = __builtin_elementwise_fma(wq[k * (CO / 2) + c], (f32x2){v[k], v[k]}, (f32x2){acc[2 * c], acc[2 * c + 1]});
+            acc[2 * c] = r[0]; acc[2 * c + 1] = r[1];
+        }
+#else
+    const CfPtr wq = cf(wpk_ci);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = fmaf(wq[k * CO + c], v[k], acc[c]);
+#endif
+}
 
 // Entry `j` of a job table, read word by word through the constant address space: the index is the same for the whole block, so
 // the struct arrives in SGPRs and everything derived from it (loop bounds, base pointers) stays wave-uniform.
@@ -278,20 +309,15 @@ __device__ __forceinline__ void conv3_tile(const Conv3Args& a, int x0, int y0, i
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
-    const CfPtr wc = cf(a.wpk);
 #pragma unroll CO <= 8 ? 2 : 1
     for (int ci = 0; ci < CI; ++ci) {
         const float* t = &s_in[(ci * IR + ry) * PI + cx];
-        const CfPtr wq = wc + ci * 9 * CO;
         float v[9];
 #pragma unroll
         for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = t[dy * PI + dx];
-#pragma unroll
-        for (int k = 0; k < 9; ++k)
-#pragma unroll
-            for (int c = 0; c < CO; ++c) acc[c] = fmaf(wq[k * CO + c], v[k], acc[c]);
+        fma_taps<CO>(acc, a.wpk + ci * 9 * CO, v);
     }
     double sp = 0.0;   // the slope gradient is ONE number summed over every pixel of the layer with both signs: kept in float64
     if (live) {
@@ -370,7 +396,7 @@ __device__ __forceinline__ void small_conv(const Conv3Args& a, int CI, const flo
     const float df0 = a.dst[0].scale, df1 = a.dst[1].scale, df2 = a.dst[2].scale;
     const int da0 = a.dst[0].accum, da1 = a.dst[1].accum, da2 = a.dst[2].accum;
     const int dn0 = a.dst[0].nch, dn01 = dn0 + a.dst[1].nch;
-    const CfPtr wc = cf(a.wpk), bp = cf(a.bias);
+    const CfPtr bp = cf(a.bias);
     for (int p = tid; p < S * S; p += kSmallNT) {
         const int y = p / S, x = p - y * S;
         const long pix = (long)y * S + x;
@@ -394,16 +420,12 @@ __device__ __forceinline__ void small_conv(const Conv3Args& a, int CI, const flo
 #pragma unroll CO <= 8 ? 2 : 1
         for (int ci = 0; ci < CI; ++ci) {
             const float* t = &s_in[(ci * R + y) * P + x];
-            const CfPtr wq = wc + ci * 9 * CO;
             float v[9];
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = t[dy * P + dx];
-#pragma unroll
-            for (int k = 0; k < 9; ++k)
-#pragma unroll
-                for (int c = 0; c < CO; ++c) acc[c] = fmaf(wq[k * CO + c], v[k], acc[c]);
+            fma_taps<CO>(acc, a.wpk + ci * 9 * CO, v);
         }
 #pragma unroll
         for (int c = 0; c < CO; ++c) {
@@ -459,6 +481,130 @@ __global__ __launch_bounds__(kSmallNT) void k_dc_small(DcSmallArgs q) {
     }
     double unused = 0.0;
     small_conv<C2, false, GEN>(q.a2, C1, s_mid, nullptr, false, b, S, slope, unused);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Backward-data of a DoubleConv at a BIG level as ONE launch per 16 x 32 tile (r4; at the small levels k_dc_small does the same per sample):
+//   g_z  = conv(g_out; W2^T) * act'(z)   on the tile + a halo of 1 (recomputed by the neighbouring tiles: 612 instead of 512 positions),
+//          its own 16 x 32 positions stored (the weight gradient of conv1 reads g_z), the PReLU-slope sum taken over those only;
+//   g_in = conv(g_z; W1^T)                from the LDS copy -> the channel groups of the DoubleConv's input concatenation.
+// Two launches (k_conv3<8, EPI> + k_conv3<C2>) with a g_z round trip through HBM become one; same arithmetic per output, same
+// per-block slope partial sums (the tiling is k_conv3's), so the gradients do not change by a bit.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kDtPI = kC3TW + 5, kDtPM = kC3TW + 3;   // row pitches of the staged g_out window (20 x 36) and of the g_z planes (18 x 34)
+
+template <int C2, bool GEN>
+__global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
+    constexpr int TH = kC3TH, TW = kC3TW, IR = TH + 4, IC = TW + 4, MR = TH + 2, MC = TW + 2, C1 = kFeat;
+    __shared__ __attribute__((aligned(16))) float s_in[C1 * IR * kDtPI];
+    __shared__ __attribute__((aligned(16))) float s_mid[C1 * MR * kDtPM];
+    __shared__ double s_red[8];
+    const Conv3Args& a1 = q.a1;
+    const Conv3Args& a2 = q.a2;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+    const int H = a1.H, W = a1.W;
+    const float slope = a1.slope != nullptr ? a1.slope[0] : 0.f;
+    {
+        WindowStager<IR, IC, 512> st;
+        st.setup(tid, y0 - 2, x0 - 2, H, W, kDtPI);
+        st.template stage<GEN>(a1.src, C1, b, s_in, IR * kDtPI, a1.act_kind, slope);
+    }
+    __syncthreads();
+    double sp = 0.0;
+    {
+        float* const gz = a1.dst[0].p;
+        const long gz_sb = a1.dst[0].sb, gz_sc = a1.dst[0].sc;
+        for (int p = tid; p < MR * MC; p += 512) {
+            const int my = p / MC, mx = p - my * MC;
+            const int y = y0 - 1 + my, x = x0 - 1 + mx;
+            const bool in = y >= 0 && y < H && x >= 0 && x < W;
+            const bool own = in && my >= 1 && my <= TH && mx >= 1 && mx <= TW;
+            const long pix = in ? (long)y * W + x : 0;
+            float zz[C1];
+#pragma unroll
+            for (int c = 0; c < C1; ++c) zz[c] = a1.z[(long)b * a1.z_sb + (long)c * a1.z_sc + pix];
+            float acc[C1];
+#pragma unroll
+            for (int c = 0; c < C1; ++c) acc[c] = 0.f;
+#pragma unroll 2
+            for (int ci = 0; ci < C1; ++ci) {
+                const float* t = &s_in[(ci * IR + my) * kDtPI + mx];
+                float v[9];
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = t[dy * kDtPI + dx];
+                fma_taps<C1>(acc, a1.wpk + ci * 9 * C1, v);
+            }
+#pragma unroll
+            for (int c = 0; c < C1; ++c) {
+                float v = acc[c];
+                if (own && zz[c] <= 0.f) sp += (double)v * (double)zz[c];
+                v *= act_grad<GEN>(zz[c], a1.act_kind, slope);
+                if (own && gz != nullptr) gz[(long)b * gz_sb + (long)c * gz_sc + pix] = v;
+                s_mid[(c * MR + my) * kDtPM + mx] = in ? v : 0.f;
+            }
+        }
+    }
+    if (a1.slope_part != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
+        if ((tid & 63) == 0) s_red[tid >> 6] = sp;
+    }
+    __syncthreads();
+    if (a1.slope_part != nullptr && tid == 0) {
+        double tot = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < 8; ++wv) tot += s_red[wv];
+        a1.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] += tot;
+    }
+    // ---- g_in = conv(g_z; W1^T): one pixel per thread, C2 channels, to the groups of the input concatenation ----
+    const int ry = tid >> 5, cx = tid & 31;
+    const int y = y0 + ry, x = x0 + cx;
+    const bool live = y < H && x < W;
+    const long pix = live ? (long)y * W + x : 0;
+    const float *dp0 = a2.dst[0].p, *dp1 = a2.dst[1].p, *dp2 = a2.dst[2].p;
+    const long dsb0 = a2.dst[0].sb, dsb1 = a2.dst[1].sb, dsb2 = a2.dst[2].sb, dsc0 = a2.dst[0].sc, dsc1 = a2.dst[1].sc, dsc2 = a2.dst[2].sc;
+    const float df0 = a2.dst[0].scale, df1 = a2.dst[1].scale, df2 = a2.dst[2].scale;
+    const int da0 = a2.dst[0].accum, da1 = a2.dst[1].accum, da2 = a2.dst[2].accum;
+    const int dn0 = a2.dst[0].nch, dn01 = dn0 + a2.dst[1].nch;
+    float old[C2];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) {   // the old values of accumulated destinations, requested ahead of the FMA loop
+        const bool g1 = c >= dn0, g2 = c >= dn01;
+        const float* dp = g2 ? dp2 : g1 ? dp1 : dp0;
+        old[c] = 0.f;
+        if (dp != nullptr && (g2 ? da2 : g1 ? da1 : da0)) {
+            const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
+            old[c] = dp[(long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix];
+        }
+    }
+    float o[C2];
+#pragma unroll
+    for (int c = 0; c < C2; ++c) o[c] = 0.f;
+#pragma unroll C2 <= 8 ? 2 : 1
+    for (int ci = 0; ci < C1; ++ci) {
+        const float* t = &s_mid[(ci * MR + ry) * kDtPM + cx];
+        float v[9];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) v[dy * 3 + dx] = t[dy * kDtPM + dx];
+        fma_taps<C2>(o, a2.wpk + ci * 9 * C2, v);
+    }
+    if (live) {
+#pragma unroll
+        for (int c = 0; c < C2; ++c) {
+            const float v = o[c];
+            const bool g1 = c >= dn0, g2 = c >= dn01;
+            float* dp = const_cast<float*>(g2 ? dp2 : g1 ? dp1 : dp0);
+            if (dp != nullptr) {
+                const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
+                dp[(long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix] = fmaf(v, g2 ? df2 : g1 ? df1 : df0, 0.f) + old[c];
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -800,11 +946,11 @@ __global__ __launch_bounds__(256) void k_pack3(const float* __restrict__ raw, fl
     if (e >= O * I * 9) return;
     {   // forward: index (ci * 9 + k) * O + co
         const int co = e % O, r = e / O, k = r % 9, ci = r / 9;
-        dst[off + e] = raw[off + (co * I + ci) * 9 + k];
+        dst[pk_off(off) + e] = raw[off + (co * I + ci) * 9 + k];
     }
     {   // backward-data: input channel = forward output o, output channel = forward input i: index (o * 9 + k) * I + i
         const int i = e % I, r = e / I, k = r % 9, o = r / 9;
-        dst[total + off + e] = raw[off + (o * I + i) * 9 + (8 - k)];
+        dst[total + pk_off(off) + e] = raw[off + (o * I + i) * 9 + (8 - k)];
     }
 }
 // 3x3 weights of the 8-channel DoubleConvs as A-operand fragments of the fp32 matrix-core kernels (hn_mfma.hip, pack_frag_3x3):
@@ -922,6 +1068,21 @@ int launch_dc_small(hn_ctx* ctx, int c1, int c2, bool epi, const DcSmallArgs& q,
     return HN_OK;
 }
 
+int launch_dc_bwd_tile(hn_ctx* ctx, int c2, const DcSmallArgs& q, int batch, hipStream_t s) {
+    const dim3 grid(cdiv(q.a1.W, kC3TW), cdiv(q.a1.H, kC3TH), batch);
+    const bool gen = q.a1.act_kind > HN_ACT_LEAKYRELU;
+#define HN_DBT(C) do { if (gen) hipLaunchKernelGGL((k_dc_bwd_tile<C, true>), grid, dim3(512), 0, s, q); else hipLaunchKernelGGL((k_dc_bwd_tile<C, false>), grid, dim3(512), 0, s, q); } while (0)
+    switch (c2) {
+        case 6: HN_DBT(6); break;
+        case 8: HN_DBT(8); break;
+        case 10: HN_DBT(10); break;
+        case 16: HN_DBT(16); break;
+        default: return fail(ctx, HN_ERR_UNSUPPORTED, "internal: no tiled DoubleConv backward kernel for %d input channels", c2);
+    }
+#undef HN_DBT
+    return HN_OK;
+}
+
 constexpr int kPartRows = 640;   // rows of the partials table = the most blocks ONE job of a weight-gradient launch uses (96^2 x 32: 1152 tiles of 8 x 32, ~2 each;
                                  // 256 rows measured the same at batch 32 and 3 % slower at batch 128)
 
@@ -948,8 +1109,8 @@ struct Trainer {
     TDst state_dst(float* flat, int d, int accum = 0) const { return TDst{flat + ctx->state_off[d], 2 * Lst, Lst, kState, 1.f, accum}; }
     Src msrc(const float* p, int d) const { return Src{p, kFeat * plane(d), plane(d), 1.f}; }
     Dst mdst(float* p, int d) const { return Dst{p, kFeat * plane(d), plane(d)}; }
-    const float* wfwd(size_t off) const { return ctx->tr.w3 + off; }            // (packed weights: one copy, in the first lane's workspace)                // k_pack3: forward arrangement at the raw offset
-    const float* wbwd(size_t off) const { return ctx->tr.w3 + L.total + off; }      // backward-data arrangement behind it
+    const float* wfwd(size_t off) const { return ctx->tr.w3 + pk_off((long)off); }            // (packed weights: one copy, in the first lane's workspace)                // k_pack3: forward arrangement at the raw offset
+    const float* wbwd(size_t off) const { return ctx->tr.w3 + pk_off((long)L.total) + 2 + pk_off((long)off); }      // backward-data arrangement behind it
     float* table(size_t col) const { return T().part + col; }                   // &table[0][col]; rows are L.total floats apart
     const float* frag8(int d, int which) const { return ctx->tr.k8 + ((size_t)d * 4 + which) * 4096; }   // 0 down fwd, 1 down bwd-data, 2 up fwd, 3 up bwd-data
 
@@ -969,6 +1130,7 @@ struct Trainer {
     bool small_level(int d) const { return side(d) <= kSmallS; }
     F3Layout F3;
     bool overlap = true;     // HN_OPT_TRAIN_OVERLAP 0 (A/B): the weight-gradient launches in line on the chain's stream (the r3 path)
+    bool fused_bwd = true;   // HN_OPT_TRAIN_FUSED bit 1 (A/B): the big levels' backward DoubleConvs as two k_conv3 launches (the r3 path)
     bool fused_fwd = true;   // HN_OPT_TRAIN_FUSED 0 (A/B): every convolution of the forward pass as its own direct launch (the r3 path)
     int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d, const size_t (*f3)[2] = nullptr) {
         // 8-channel DoubleConvs: the fused matrix-core kernels of the inference path, which also store the pre-activation mid tensor
@@ -1082,6 +1244,10 @@ struct Trainer {
         if (small_level(d) && dc.cm == kFeat && (dc.cin == kFeat || dc.cin == kFeat + kState || dc.cin == 2 * kFeat)) {
             const DcSmallArgs q{bwd2_args(dc, slot, z, g_out, d), bwd1_args(dc, slot, gin, d)};
             return launch_dc_small(ctx, dc.cm, dc.cin, true, q, B, s);
+        }
+        if (fused_bwd && dc.cm == kFeat && dc.co == kFeat && g_out.act == 0) {   // big levels: both backward-data convolutions in one tiled launch
+            const DcSmallArgs q{bwd2_args(dc, slot, z, g_out, d), bwd1_args(dc, slot, gin, d)};
+            return launch_dc_bwd_tile(ctx, dc.cin, q, B, s);
         }
         if ((rc = launch_conv3(ctx, dc.cm, true, bwd2_args(dc, slot, z, g_out, d), B, s)) != HN_OK) return rc;
         return launch_conv3(ctx, dc.cin, false, bwd1_args(dc, slot, gin, d), B, s);
@@ -1317,7 +1483,7 @@ int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int 
     HN_HIP(ctx, hipMalloc((void**)&W.part, sizeof(float) * W.part_floats));
     W.slope_stride = (size_t)nb * cdiv(n, kC3TW) * cdiv(n, kC3TH);
     HN_HIP(ctx, hipMalloc((void**)&W.slope_part, sizeof(double) * W.slope_stride * (3 * depth + 2)));
-    HN_HIP(ctx, hipMalloc((void**)&W.w3, sizeof(float) * 2 * total));
+    HN_HIP(ctx, hipMalloc((void**)&W.w3, sizeof(float) * 2 * (total + 4)));   // both arrangements, each tensor at an even offset (pk_off)
     HN_HIP(ctx, hipMalloc((void**)&W.k8, sizeof(float) * (size_t)depth * 4 * 4096));
     HN_HIP(ctx, hipMalloc((void**)&W.f3, sizeof(float) * f3_layout(depth).total));
     HN_HIP(ctx, hipMalloc((void**)&W.zero8, sizeof(float) * 8));
@@ -1431,7 +1597,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
-    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = ctx->opt_train_fused != 0; t.overlap = ctx->opt_train_overlap != 0; }
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.overlap = ctx->opt_train_overlap != 0; }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
     struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};
@@ -1446,7 +1612,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         add(L.inc);
         for (int d = 0; d < depth; ++d) { add(L.sig[d]); add(L.st[d]); }
         for (int d = 0; d <= depth; ++d) add(L.dec[d]);
-        hipLaunchKernelGGL(k_pack3, dim3(cdiv(16 * 9 * 8, 256), jobs.n), dim3(256), 0, s, weights, W.w3, (long)L.total, jobs);
+        hipLaunchKernelGGL(k_pack3, dim3(cdiv(16 * 9 * 8, 256), jobs.n), dim3(256), 0, s, weights, W.w3, pk_off((long)L.total) + 2, jobs);
         PackK8Jobs kj{};
         for (int d = 0; d < depth; ++d) {
             kj.off[4 * d + 0] = (int)L.down[d].w; kj.up[4 * d + 0] = 0;   // down, forward

@@ -88,9 +88,10 @@ enum hn_option {
                               * multiplies; weights G g G^T composed in float64 at hn_load_weights): sum of 1 (inc), 2 (conv_signal),
                               * 8 (decoder); default 11 = all three, 0 = the direct kernels HN_OPT_DC_VALU selects.  Same fp32 sums in
                               * another order: agrees with the direct kernels to fp32 rounding                              */
-    HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad, forward pass: 1 (default) an 8-channel DoubleConv is ONE launch of the fused matrix-core
-                              * kernels of the inference path, which also store the pre-activation mid tensor to the tape; 0: every
-                              * convolution as its own direct launch (round 3).  Same tape within fp32 rounding                */
+    HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
+                              * the inference path, which also store the pre-activation mid tensor to the tape; same tape within fp32
+                              * rounding) and 2 (backward pass: both backward-data convolutions of a big level's DoubleConv as one tiled
+                              * launch; bit-identical gradients); default 3, 0: every convolution as its own direct launch (round 3) */
     HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: 1: the three weight-gradient launches of unrolled iteration t run on a library
                               * stream beside the backward chain of iteration t - 1 (two sets of gradient buffers); 0 (default): in line on
                               * the caller's stream.  Bit-identical gradients (the launches keep their order).  Measured equal: the chain's
