@@ -18,22 +18,23 @@ def main():
     ap.add_argument("--n", type=int, default=96)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--buffer", type=int, default=256)
+    ap.add_argument("--batch", type=int, default=32)
     a = ap.parse_args()
     from helmnet_amd import IterativeSolver
     from helmnet_amd.phantoms import ring_sos_batch
     torch.manual_seed(0); np.random.seed(0); random.seed(0)
     s = IterativeSolver.from_exported_weights()
     s.to("cuda:0")
-    s.hparams.batch_size, s.hparams.buffer_size = 32, a.buffer
+    s.hparams.batch_size, s.hparams.buffer_size = a.batch, max(a.buffer, 2 * a.batch)
     s.set_domain_size(a.n, source_location=[a.n - 14, a.n // 2])
-    sos_train = torch.from_numpy(ring_sos_batch(a.n, max(a.buffer, 512), seed=100))
+    sos_train = torch.from_numpy(ring_sos_batch(a.n, max(a.buffer, 2 * a.batch, 512), seed=100))
     tr = s.trainer()
     tr.current_epoch = 10     # maxiter = 201: most slots are advanced, a few are re-drawn (steady state of a run)
     t0 = time.perf_counter()
     tr.fill_replay_buffer(sos_train)
     torch.cuda.synchronize()
     fill = time.perf_counter() - t0
-    batches = [sos_train[np.random.choice(len(sos_train), 32, replace=False)].to("cuda:0") for _ in range(a.steps + 5)]
+    batches = [sos_train[np.random.choice(len(sos_train), a.batch, replace=False)].to("cuda:0") for _ in range(a.steps + 5)]
     for i in range(5):
         tr.training_step(batches[i], i)
     torch.cuda.synchronize()
@@ -44,7 +45,7 @@ def main():
     torch.cuda.synchronize()
     total = (time.perf_counter() - t0) / a.steps
     # the two library calls alone on one sampled batch
-    wavefields, h_states, k_sqs, residual, sources, _, _ = tr.replaybuffer.sample(32)
+    wavefields, h_states, k_sqs, residual, sources, _, _ = tr.replaybuffer.sample(a.batch)
     for _ in range(3):
         tr.loss_and_grad(wavefields, h_states, k_sqs, residual, sources); tr.optimizer_step()
     torch.cuda.synchronize()
@@ -53,7 +54,7 @@ def main():
         tr.loss_and_grad(wavefields, h_states, k_sqs, residual, sources); tr.optimizer_step()
     torch.cuda.synchronize()
     lib = (time.perf_counter() - t0) / a.steps
-    print(json.dumps({"n": a.n, "batch": 32, "buffer": a.buffer, "training_step_ms": round(total * 1e3, 3), "library_calls_ms": round(lib * 1e3, 3),
+    print(json.dumps({"n": a.n, "batch": a.batch, "buffer": a.buffer, "training_step_ms": round(total * 1e3, 3), "library_calls_ms": round(lib * 1e3, 3),
                       "host_logic_ms": round((total - lib) * 1e3, 3), "fresh_maps_per_step": new / a.steps, "fill_replay_buffer_s": round(fill, 3)}))
 
 
