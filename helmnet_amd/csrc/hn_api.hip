@@ -262,7 +262,8 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             ctx->opt_train_overlap = value;
             break;
         case HN_OPT_DC_WINO:
-            if (value < 0 || value > 15 || (value & 4)) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_WINO must be a sum of 1 (inc), 2 (conv_signal), 8 (decoder) (got %d)", value);
+            if (value < 0 || value > 63 || (value & 4))
+                return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_WINO must be a sum of 1 (inc), 2 (conv_signal), 8 (decoder), 16 / 32 (conv_signal / decoder one level down) (got %d)", value);
             ctx->opt_dc_wino = value;
             break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);

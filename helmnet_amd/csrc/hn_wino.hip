@@ -489,13 +489,17 @@ void pack_wino(const float* w, int cin, const float* scale, float* dst) {
 bool dc_wino_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W) {
     (void)act;
     if (ctx->precision != HN_PREC_FP32 || !ctx->opt_dc_wino || ctx->zero_page == nullptr) return false;
-    if (kind == 2 || !((ctx->opt_dc_wino >> kind) & 1)) return false;   // (kind 2, the bottleneck, lives at the deepest level)
+    if (kind == 2) return false;   // (the bottleneck lives at the deepest level)
+    // option bits: 1 inc, 2 conv_signal, 8 decoder at the largest level; 16 conv_signal, 32 decoder one level down (W = n / 2)
+    const bool level1 = ctx->tab.n > 0 && 2 * W == ctx->tab.n;
+    const int bit = level1 ? (kind == 1 ? 16 : kind == 3 ? 32 : 0) : (1 << kind);
+    if (!(ctx->opt_dc_wino & bit) || (!level1 && W < 256) || W < 128) return false;
     // the input layer's U carries the reference's 1e3 on the residual channels (hybridnet.py:566); any other scaling takes the direct kernels
     const bool scales_ok = kind == 0 ? (a.scale == 1.f && b.scale == 1000.f && c.scale == 1.f) : (a.scale == 1.f && b.scale == 1.f && c.scale == 1.f);
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;
     const bool aligned = (reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(b.p) | (kind == 0 ? reinterpret_cast<uintptr_t>(c.p) : 0)) % 16 == 0 &&
                          (a.sb % 4 | a.sc % 4 | b.sb % 4 | b.sc % 4 | (kind == 0 ? (c.sb % 4 | c.sc % 4) : 0)) == 0;
-    return W >= 256 && (W & 3) == 0 && off32 && scales_ok && aligned;
+    return (W & 3) == 0 && off32 && scales_ok && aligned;
 }
 
 void launch_dc_wino(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H, int W,

@@ -86,8 +86,9 @@ enum hn_option {
                               * one chain of 32                                                            */
     HN_OPT_DC_WINO = 9,      /* fp32 DoubleConvs of the largest level (W >= 256) as Winograd F(2x2, 3x3) on the packed vector FMA (2.25 x fewer
                               * multiplies; weights G g G^T composed in float64 at hn_load_weights): sum of 1 (inc), 2 (conv_signal),
-                              * 8 (decoder); default 11 = all three, 0 = the direct kernels HN_OPT_DC_VALU selects.  Same fp32 sums in
-                              * another order: agrees with the direct kernels to fp32 rounding                              */
+                              * 8 (decoder), 16 / 32 (conv_signal / decoder one level down, W >= 128); default 0 = the direct kernels
+                              * HN_OPT_DC_VALU selects ([measured] the Winograd kernels are at parity with them, not ahead: DESIGN.md 4.2d).
+                              * Same fp32 sums in another order: agrees with the direct kernels to fp32 rounding                */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
                               * the inference path, which also store the pre-activation mid tensor to the tape; same tape within fp32
                               * rounding) and 2 (backward pass: both backward-data convolutions of a big level's DoubleConv as one tiled
