@@ -219,8 +219,9 @@ struct hn_ctx {
     int opt_train_overlap = 0;     // HN_OPT_TRAIN_OVERLAP: weight-gradient launches on a side stream beside the next iteration's backward chain.  Off:
                                    // [measured, r4] 9.58 vs 9.61 ms at batch 32, 20.8 vs 21.3 at 128 -- the overlap is real (2.3 ms of kernel time per step run
                                    // concurrently) but the chain's kernels slow down by as much (k_conv3<8> 16.5 -> 20.3 us, the batched conv_state 13 -> 60 us)
-    int opt_train_fused = 3;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
-                                   // bit 1 the backward-data pass of a big level's DoubleConv as one tiled launch (k_dc_bwd_tile)
+    int opt_train_fused = 7;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
+                                   // bit 1 the backward-data pass of a big level's DoubleConv as one tiled launch (k_dc_bwd_tile), bit 2 the hidden-state
+                                   // DoubleConvs of all levels as one launch per direction (k_dc_state_batch)
     int opt_train_lanes = 1;       // HN_OPT_TRAIN_LANES: 2 = the halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t train_stream = nullptr;            // lane 1 (created on first use)
     hipEvent_t train_fork = nullptr, train_join = nullptr;

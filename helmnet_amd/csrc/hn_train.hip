@@ -493,28 +493,32 @@ __global__ __launch_bounds__(kSmallNT) void k_dc_small(DcSmallArgs q) {
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int kDtPI = kC3TW + 5, kDtPM = kC3TW + 3;   // row pitches of the staged g_out window (20 x 36) and of the g_z planes (18 x 34)
 
-template <int C2, bool GEN>
-__global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
-    constexpr int TH = kC3TH, TW = kC3TW, IR = TH + 4, IC = TW + 4, MR = TH + 2, MC = TW + 2, C1 = kFeat;
-    __shared__ __attribute__((aligned(16))) float s_in[C1 * IR * kDtPI];
+// One 16 x 32 tile of a two-convolution chain.  BWD: the backward-data pass described above (first convolution's output * act'(z), no biases).
+// !BWD (the hidden-state DoubleConvs' forward pass): mid = conv(in) + b1 stored pre-activation (the tape's z), act(mid) in LDS, out = conv(act(mid)) + b2.
+// CIMAX = most input channels staged (8: g_out; 10: cat[out_d, state_d]); C1 = channels of the tensor between the two convolutions, C2 = of the result.
+template <int CIMAX, int C1, int C2, bool BWD, bool GEN>
+__device__ __forceinline__ void dc_tile(const DcSmallArgs& q, int x0, int y0, int b, int block_in_layer) {
+    constexpr int TH = kC3TH, TW = kC3TW, IR = TH + 4, IC = TW + 4, MR = TH + 2, MC = TW + 2;
+    __shared__ __attribute__((aligned(16))) float s_in[CIMAX * IR * kDtPI];
     __shared__ __attribute__((aligned(16))) float s_mid[C1 * MR * kDtPM];
     __shared__ double s_red[8];
     const Conv3Args& a1 = q.a1;
     const Conv3Args& a2 = q.a2;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
     const int H = a1.H, W = a1.W;
+    const int CI = a1.src[0].nch + a1.src[1].nch + a1.src[2].nch;
     const float slope = a1.slope != nullptr ? a1.slope[0] : 0.f;
     {
         WindowStager<IR, IC, 512> st;
         st.setup(tid, y0 - 2, x0 - 2, H, W, kDtPI);
-        st.template stage<GEN>(a1.src, C1, b, s_in, IR * kDtPI, a1.act_kind, slope);
+        st.template stage<GEN>(a1.src, CI, b, s_in, IR * kDtPI, a1.act_kind, slope);
     }
     __syncthreads();
     double sp = 0.0;
     {
         float* const gz = a1.dst[0].p;
         const long gz_sb = a1.dst[0].sb, gz_sc = a1.dst[0].sc;
+        const CfPtr bp = cf(a1.bias);
         for (int p = tid; p < MR * MC; p += 512) {
             const int my = p / MC, mx = p - my * MC;
             const int y = y0 - 1 + my, x = x0 - 1 + mx;
@@ -523,12 +527,12 @@ __global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
             const long pix = in ? (long)y * W + x : 0;
             float zz[C1];
 #pragma unroll
-            for (int c = 0; c < C1; ++c) zz[c] = a1.z[(long)b * a1.z_sb + (long)c * a1.z_sc + pix];
+            for (int c = 0; c < C1; ++c) zz[c] = BWD ? a1.z[(long)b * a1.z_sb + (long)c * a1.z_sc + pix] : (a1.bias != nullptr ? bp[c] : 0.f);   // (!BWD: the bias)
             float acc[C1];
 #pragma unroll
             for (int c = 0; c < C1; ++c) acc[c] = 0.f;
 #pragma unroll 2
-            for (int ci = 0; ci < C1; ++ci) {
+            for (int ci = 0; ci < CI; ++ci) {
                 const float* t = &s_in[(ci * IR + my) * kDtPI + mx];
                 float v[9];
 #pragma unroll
@@ -540,26 +544,28 @@ __global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
 #pragma unroll
             for (int c = 0; c < C1; ++c) {
                 float v = acc[c];
-                if (own && zz[c] <= 0.f) sp += (double)v * (double)zz[c];
-                v *= act_grad<GEN>(zz[c], a1.act_kind, slope);
+                if (BWD) {
+                    if (own && zz[c] <= 0.f) sp += (double)v * (double)zz[c];
+                    v *= act_grad<GEN>(zz[c], a1.act_kind, slope);
+                } else v += zz[c];
                 if (own && gz != nullptr) gz[(long)b * gz_sb + (long)c * gz_sc + pix] = v;
-                s_mid[(c * MR + my) * kDtPM + mx] = in ? v : 0.f;
+                s_mid[(c * MR + my) * kDtPM + mx] = in ? (BWD ? v : act_fwd<GEN>(v, a1.act_kind, slope)) : 0.f;
             }
         }
     }
-    if (a1.slope_part != nullptr) {
+    if (BWD && a1.slope_part != nullptr) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
         if ((tid & 63) == 0) s_red[tid >> 6] = sp;
     }
     __syncthreads();
-    if (a1.slope_part != nullptr && tid == 0) {
+    if (BWD && a1.slope_part != nullptr && tid == 0) {
         double tot = 0.0;
 #pragma unroll
         for (int wv = 0; wv < 8; ++wv) tot += s_red[wv];
-        a1.slope_part[blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)] += tot;
+        a1.slope_part[block_in_layer] += tot;
     }
-    // ---- g_in = conv(g_z; W1^T): one pixel per thread, C2 channels, to the groups of the input concatenation ----
+    // ---- second convolution from the LDS planes: one pixel per thread, C2 channels, to the destination's channel groups ----
     const int ry = tid >> 5, cx = tid & 31;
     const int y = y0 + ry, x = x0 + cx;
     const bool live = y < H && x < W;
@@ -569,20 +575,22 @@ __global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
     const float df0 = a2.dst[0].scale, df1 = a2.dst[1].scale, df2 = a2.dst[2].scale;
     const int da0 = a2.dst[0].accum, da1 = a2.dst[1].accum, da2 = a2.dst[2].accum;
     const int dn0 = a2.dst[0].nch, dn01 = dn0 + a2.dst[1].nch;
-    float old[C2];
+    float old[C2], o[C2], bias2[C2];
+    {
+        const CfPtr bp2 = cf(a2.bias);
 #pragma unroll
-    for (int c = 0; c < C2; ++c) {   // the old values of accumulated destinations, requested ahead of the FMA loop
-        const bool g1 = c >= dn0, g2 = c >= dn01;
-        const float* dp = g2 ? dp2 : g1 ? dp1 : dp0;
-        old[c] = 0.f;
-        if (dp != nullptr && (g2 ? da2 : g1 ? da1 : da0)) {
-            const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
-            old[c] = dp[(long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix];
+        for (int c = 0; c < C2; ++c) {   // the old values of accumulated destinations and the biases, requested ahead of the FMA loop
+            const bool g1 = c >= dn0, g2 = c >= dn01;
+            const float* dp = g2 ? dp2 : g1 ? dp1 : dp0;
+            old[c] = 0.f;
+            if (dp != nullptr && (g2 ? da2 : g1 ? da1 : da0)) {
+                const int cd = g2 ? c - dn01 : g1 ? c - dn0 : c;
+                old[c] = dp[(long)b * (g2 ? dsb2 : g1 ? dsb1 : dsb0) + (long)cd * (g2 ? dsc2 : g1 ? dsc1 : dsc0) + pix];
+            }
+            o[c] = 0.f;
+            bias2[c] = (!BWD && a2.bias != nullptr) ? bp2[c] : 0.f;   // added last, as k_conv3 does: the fused path is bit-identical to the two launches
         }
     }
-    float o[C2];
-#pragma unroll
-    for (int c = 0; c < C2; ++c) o[c] = 0.f;
 #pragma unroll C2 <= 8 ? 2 : 1
     for (int ci = 0; ci < C1; ++ci) {
         const float* t = &s_mid[(ci * MR + ry) * kDtPM + cx];
@@ -596,7 +604,7 @@ __global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
     if (live) {
 #pragma unroll
         for (int c = 0; c < C2; ++c) {
-            const float v = o[c];
+            const float v = o[c] + bias2[c];
             const bool g1 = c >= dn0, g2 = c >= dn01;
             float* dp = const_cast<float*>(g2 ? dp2 : g1 ? dp1 : dp0);
             if (dp != nullptr) {
@@ -605,6 +613,31 @@ __global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
             }
         }
     }
+}
+
+template <int C2, bool GEN>
+__global__ __launch_bounds__(512) void k_dc_bwd_tile(DcSmallArgs q) {
+    dc_tile<kFeat, kFeat, C2, true, GEN>(q, blockIdx.x * kC3TW, blockIdx.y * kC3TH, blockIdx.z, blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z));
+}
+
+// The hidden-state DoubleConvs (10 -> 2 -> 2) of EVERY level in one launch per direction (they are off the chain within an iteration, so the levels'
+// instances are independent): forward z = conv(cat[out_d, state_d]) + b (tape), new state = conv(act(z)) + b; backward g_z = conv(g_new; W2^T) act'(z),
+// (g_out_d, g_state_d) = conv(g_z; W1^T).  r3 ran each direction as two batched launches with the 2-channel tensor going through HBM in between.
+struct DcBatch {
+    DcSmallArgs job[kMaxDepth];
+    int blk0[kMaxDepth + 1];
+    int tiles_x[kMaxDepth], tiles_y[kMaxDepth];
+    int njobs;
+};
+static_assert(sizeof(DcBatch) <= 4096, "kernel-argument block");
+template <bool BWD, bool GEN>
+__global__ __launch_bounds__(512) void k_dc_state_batch(DcBatch q) {
+    int j = 0;
+    while (j + 1 < q.njobs && (int)blockIdx.x >= q.blk0[j + 1]) ++j;
+    const int bid = (int)blockIdx.x - q.blk0[j];
+    const int tx = bid % q.tiles_x[j], r = bid / q.tiles_x[j], ty = r % q.tiles_y[j], b = r / q.tiles_y[j];
+    if (BWD) dc_tile<kState, kState, kFeat + kState, true, GEN>(q.job[j], tx * kC3TW, ty * kC3TH, b, bid);
+    else dc_tile<kFeat + kState, kState, kState, false, GEN>(q.job[j], tx * kC3TW, ty * kC3TH, b, bid);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1068,6 +1101,25 @@ int launch_dc_small(hn_ctx* ctx, int c1, int c2, bool epi, const DcSmallArgs& q,
     return HN_OK;
 }
 
+int launch_dc_state_batch(hn_ctx* ctx, bool bwd, DcBatch& q, int batch, hipStream_t s) {
+    int total = 0;
+    for (int j = 0; j < q.njobs; ++j) {
+        q.tiles_x[j] = cdiv(q.job[j].a1.W, kC3TW);
+        q.tiles_y[j] = cdiv(q.job[j].a1.H, kC3TH);
+        q.blk0[j] = total;
+        total += q.tiles_x[j] * q.tiles_y[j] * batch;
+    }
+    q.blk0[q.njobs] = total;
+    if (total == 0) return HN_OK;
+    const bool gen = q.job[0].a1.act_kind > HN_ACT_LEAKYRELU;
+    if (bwd && gen) hipLaunchKernelGGL((k_dc_state_batch<true, true>), dim3(total), dim3(512), 0, s, q);
+    else if (bwd) hipLaunchKernelGGL((k_dc_state_batch<true, false>), dim3(total), dim3(512), 0, s, q);
+    else if (gen) hipLaunchKernelGGL((k_dc_state_batch<false, true>), dim3(total), dim3(512), 0, s, q);
+    else hipLaunchKernelGGL((k_dc_state_batch<false, false>), dim3(total), dim3(512), 0, s, q);
+    (void)ctx;
+    return HN_OK;
+}
+
 int launch_dc_bwd_tile(hn_ctx* ctx, int c2, const DcSmallArgs& q, int batch, hipStream_t s) {
     const dim3 grid(cdiv(q.a1.W, kC3TW), cdiv(q.a1.H, kC3TH), batch);
     const bool gen = q.a1.act_kind > HN_ACT_LEAKYRELU;
@@ -1130,6 +1182,7 @@ struct Trainer {
     bool small_level(int d) const { return side(d) <= kSmallS; }
     F3Layout F3;
     bool overlap = true;     // HN_OPT_TRAIN_OVERLAP 0 (A/B): the weight-gradient launches in line on the chain's stream (the r3 path)
+    bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
     bool fused_bwd = true;   // HN_OPT_TRAIN_FUSED bit 1 (A/B): the big levels' backward DoubleConvs as two k_conv3 launches (the r3 path)
     bool fused_fwd = true;   // HN_OPT_TRAIN_FUSED 0 (A/B): every convolution of the forward pass as its own direct launch (the r3 path)
     int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d, const size_t (*f3)[2] = nullptr) {
@@ -1287,16 +1340,22 @@ struct Trainer {
         {   // new_state_d = conv_state_d(cat[out_d, state_d]) (architectures.py:248) for every level at once: nothing of this iteration
             // reads the new states, so the levels' DoubleConvs are two launches (first convolutions, second convolutions) instead of 2 depth
             Conv3Batch q1{}, q2{};
-            q1.njobs = q2.njobs = depth;
+            DcBatch qf{};
+            q1.njobs = q2.njobs = qf.njobs = depth;
             for (int d = 0; d < depth; ++d) {
                 const RawDc& dc = L.st[d];
                 const TSrc in_st[3] = {feat(tape(t, W.o_out[d]), d), state_src(st_in, d), nosrc()};
                 q1.job[d] = fwd_args(in_st, dc.w1, dc.b1, dc.slope, featdst(tape(t, W.o_zst[d]), d, dc.cm), d);
                 const TSrc mid[3] = {feat(tape(t, W.o_zst[d]), d, dc.cm, 1), nosrc(), nosrc()};
                 q2.job[d] = fwd_args(mid, dc.w2, dc.b2, dc.slope, state_dst(st_next, d), d);
+                qf.job[d] = DcSmallArgs{q1.job[d], q2.job[d]};
             }
-            if ((rc = launch_conv3_batch(ctx, kState, false, q1, B, s)) != HN_OK) return rc;
-            if ((rc = launch_conv3_batch(ctx, kState, false, q2, B, s)) != HN_OK) return rc;
+            if (fused_state) {   // both convolutions of every level's hidden-state DoubleConv in ONE launch (k_dc_state_batch)
+                if ((rc = launch_dc_state_batch(ctx, false, qf, B, s)) != HN_OK) return rc;
+            } else {
+                if ((rc = launch_conv3_batch(ctx, kState, false, q1, B, s)) != HN_OK) return rc;
+                if ((rc = launch_conv3_batch(ctx, kState, false, q2, B, s)) != HN_OK) return rc;
+            }
         }
         {
             const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
@@ -1348,8 +1407,15 @@ struct Trainer {
                 const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 0), state_dst(W.g_st[(cur_st + 1) % 3], d, 0), nodst()};
                 q1.job[d] = bwd1_args(dc, slot_st(d), gin, d);
             }
-            if ((rc = launch_conv3_batch(ctx, kState, true, q2, B, s)) != HN_OK) return rc;
-            if ((rc = launch_conv3_batch(ctx, kFeat + kState, false, q1, B, s)) != HN_OK) return rc;
+            if (fused_state) {
+                DcBatch qb{};
+                qb.njobs = depth;
+                for (int d = 0; d < depth; ++d) qb.job[d] = DcSmallArgs{q2.job[d], q1.job[d]};
+                if ((rc = launch_dc_state_batch(ctx, true, qb, B, s)) != HN_OK) return rc;
+            } else {
+                if ((rc = launch_conv3_batch(ctx, kState, true, q2, B, s)) != HN_OK) return rc;
+                if ((rc = launch_conv3_batch(ctx, kFeat + kState, false, q1, B, s)) != HN_OK) return rc;
+            }
         }
         for (int d = 0; d < depth; ++d) {   // decoder, top down
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
@@ -1597,7 +1663,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
-    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.overlap = ctx->opt_train_overlap != 0; }
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.overlap = ctx->opt_train_overlap != 0; }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
     struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};

@@ -91,8 +91,9 @@ enum hn_option {
                               * Same fp32 sums in another order: agrees with the direct kernels to fp32 rounding                */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
                               * the inference path, which also store the pre-activation mid tensor to the tape; same tape within fp32
-                              * rounding) and 2 (backward pass: both backward-data convolutions of a big level's DoubleConv as one tiled
-                              * launch; bit-identical gradients); default 3, 0: every convolution as its own direct launch (round 3) */
+                              * rounding), 2 (backward pass: both backward-data convolutions of a big level's DoubleConv as one tiled
+                              * launch; bit-identical gradients) and 4 (the hidden-state DoubleConvs of all levels as one launch per
+                              * direction instead of two; bit-identical); default 7, 0: every convolution as its own launch (round 3)  */
     HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: 1: the three weight-gradient launches of unrolled iteration t run on a library
                               * stream beside the backward chain of iteration t - 1 (two sets of gradient buffers); 0 (default): in line on
                               * the caller's stream.  Bit-identical gradients (the launches keep their order).  Measured equal: the chain's

@@ -363,6 +363,35 @@ def test_batched_gradient_equals_the_mean_of_per_sample_gradients_beyond_640_til
     assert err <= 2e-5, err
 
 
+def test_fused_training_launches_keep_the_gradient_bits(solver, weights, g_train):
+    """HN_OPT_TRAIN_FUSED: bit 1 (a big level's backward DoubleConv as one tiled launch) and bit 2 (the hidden-state DoubleConvs as one
+    launch per direction) do the same arithmetic per output in the same order as the launches they replace: loss, gradient and input
+    gradients are BIT-identical.  Bit 0 (forward DoubleConvs on the fused matrix-core kernels) is another summation order: fp32 rounding.
+    HN_OPT_TRAIN_OVERLAP (weight gradients on a side stream) keeps the launches' order: bit-identical too."""
+    n, b, k_sq, src, (wf0, res0, st0) = _fixture_inputs(g_train)
+    solver.set_domain_size(n, source_location=[82, 48])
+    eng = solver.engine()
+    blob = torch.from_numpy(pack_weights(weights)).to(DEV)
+    args = [x.to(DEV).contiguous() for x in (wf0, res0, st0, k_sq, src)]
+    outs = {}
+    try:
+        for fused, overlap in ((7, 0), (3, 0), (1, 0), (0, 0), (7, 1)):
+            eng.set_option("train_fused", fused)
+            eng.set_option("train_overlap", overlap)
+            o = eng.train_grad(blob, *args, 4, 1e4, input_grads=True)
+            outs[(fused, overlap)] = tuple(o[k].clone() for k in ("loss", "grad", "grad_wf", "grad_res", "grad_states"))
+    finally:
+        eng.set_option("train_fused", 7)
+        eng.set_option("train_overlap", 0)
+    for other in ((3, 0), (1, 0), (7, 1)):
+        for a, c in zip(outs[(7, 0)], outs[other]):
+            assert torch.equal(a, c), other
+    # the fused forward: fp32 rounding at most.  (At this size it is in fact bit-identical as well: the f32 matrix instruction is an exact fmaf
+    # chain and k_dc_mfma_p walks (channel, row, tap) in k_conv3's order with the bias added last; the strip kernel of W >= 128 starts from the bias.)
+    for a, c in zip(outs[(1, 0)], outs[(0, 0)]):
+        assert float((a - c).abs().max()) <= 2e-5 * float(c.abs().max())
+
+
 def test_gradients_are_bit_reproducible_and_batch_independent(solver, weights, g_train):
     n, b, k_sq, src, (wf0, res0, st0) = _fixture_inputs(g_train)
     solver.set_domain_size(n, source_location=[82, 48])
