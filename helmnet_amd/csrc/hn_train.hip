@@ -1182,6 +1182,7 @@ struct Trainer {
     bool small_level(int d) const { return side(d) <= kSmallS; }
     F3Layout F3;
     bool overlap = true;     // HN_OPT_TRAIN_OVERLAP 0 (A/B): the weight-gradient launches in line on the chain's stream (the r3 path)
+    bool tile_small = false; // HN_OPT_TRAIN_FUSED bit 3 (A/B): the small levels' backward DoubleConvs on the tiled kernel too instead of the per-sample k_dc_small
     bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
     bool fused_bwd = true;   // HN_OPT_TRAIN_FUSED bit 1 (A/B): the big levels' backward DoubleConvs as two k_conv3 launches (the r3 path)
     bool fused_fwd = true;   // HN_OPT_TRAIN_FUSED 0 (A/B): every convolution of the forward pass as its own direct launch (the r3 path)
@@ -1294,7 +1295,7 @@ struct Trainer {
     int dc_bwd(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
         int rc;
         if ((rc = dc_wgrads(dc, slot, in, z, g_out, d)) != HN_OK) return rc;
-        if (small_level(d) && dc.cm == kFeat && (dc.cin == kFeat || dc.cin == kFeat + kState || dc.cin == 2 * kFeat)) {
+        if (!tile_small && small_level(d) && dc.cm == kFeat && (dc.cin == kFeat || dc.cin == kFeat + kState || dc.cin == 2 * kFeat)) {
             const DcSmallArgs q{bwd2_args(dc, slot, z, g_out, d), bwd1_args(dc, slot, gin, d)};
             return launch_dc_small(ctx, dc.cm, dc.cin, true, q, B, s);
         }
@@ -1650,7 +1651,10 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     const bool capturing = cap == hipStreamCaptureStatusActive;
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
-        W.jobs_set = (W.jobs_set + 1) % hn_ctx::TrainWs::kJobSets;
+        // set 0 of the pinned job tables belongs to CAPTURED calls (their graph copies the tables out of it at every replay, so eager calls
+        // must never rewrite it); eager calls rotate over sets 1 .. kJobSets - 1
+        if (capturing) W.jobs_set = 0;
+        else W.jobs_set = W.jobs_set % (hn_ctx::TrainWs::kJobSets - 1) + 1;
         if (!capturing && W.jobs_in_flight[W.jobs_set]) {   // the tables of the call that last used this set have left the pinned buffer (normally long ago)
             HN_HIP(ctx, hipEventSynchronize(W.jobs_copied[W.jobs_set]));
             W.jobs_in_flight[W.jobs_set] = false;
@@ -1663,7 +1667,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
-    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.overlap = ctx->opt_train_overlap != 0; }
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.tile_small = (ctx->opt_train_fused & 8) != 0; t.overlap = ctx->opt_train_overlap != 0; }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
     struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};
@@ -1714,13 +1718,23 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     auto in_wf = [&](int t, int l) { return (t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf) + (size_t)lane_b0[l] * p2; };
     auto in_res = [&](int t, int l) { return (t == 0 ? res : res_hist + (size_t)(t - 1) * fwf) + (size_t)lane_b0[l] * p2; };
     auto in_st = [&](int t, int l) { return (t == 0 ? states : st_hist + (size_t)(t - 1) * fst) + (size_t)lane_b0[l] * pst; };
-    for (int t = 0; t < n_unroll; ++t)
-        for (int l = 0; l < lanes; ++l) {   // the lanes' launches are enqueued alternately, so both streams always hold work
-            const size_t o2 = (size_t)t * fwf + (size_t)lane_b0[l] * p2, ost = (size_t)t * fst + (size_t)lane_b0[l] * pst;
-            if ((rc = tr[l].forward_step(t, in_wf(t, l), in_res(t, l), in_st(t, l), wf_hist + o2, res_hist + o2, st_hist + ost,
-                                         k_sq + (size_t)lane_b0[l] * n * n, src + (src_batch == 1 ? 0 : (size_t)lane_b0[l] * p2), src_batch == 1 ? 1 : lane_nb[l])) != HN_OK)
-                return rc;
+    // An error inside the sweeps must not leave the library's streams forked from the caller's: they are joined before returning.
+    auto join_streams = [&]() {
+        for (int l = 0; l < lanes; ++l)
+            for (int k = 0; k < 2; ++k)
+                if (ws[l]->wg_pending[k]) { (void)hipStreamWaitEvent(ls[l], ws[l]->wg_done[k], 0); ws[l]->wg_pending[k] = false; }
+        if (lanes == 2) {
+            (void)hipEventRecord(ctx->train_join, ctx->train_stream);
+            (void)hipStreamWaitEvent(s, ctx->train_join, 0);
         }
+    };
+    for (int t = 0; t < n_unroll && rc == HN_OK; ++t)
+        for (int l = 0; l < lanes && rc == HN_OK; ++l) {   // the lanes' launches are enqueued alternately, so both streams always hold work
+            const size_t o2 = (size_t)t * fwf + (size_t)lane_b0[l] * p2, ost = (size_t)t * fst + (size_t)lane_b0[l] * pst;
+            rc = tr[l].forward_step(t, in_wf(t, l), in_res(t, l), in_st(t, l), wf_hist + o2, res_hist + o2, st_hist + ost,
+                                    k_sq + (size_t)lane_b0[l] * n * n, src + (src_batch == 1 ? 0 : (size_t)lane_b0[l] * p2), src_batch == 1 ? 1 : lane_nb[l]);
+        }
+    if (rc != HN_OK) { join_streams(); return rc; }
     // backward sweep
     int cur_wf[2] = {0, 0}, cur_st[2] = {0, 0};
     for (int l = 0; l < lanes; ++l) {
@@ -1731,11 +1745,11 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     }
     const double count = (double)n_unroll * batch * 2.0 * n * n;
     const float loss_c = (float)(2.0 * (double)loss_scale / count);
-    for (int t = n_unroll - 1; t >= 0; --t)
-        for (int l = 0; l < lanes; ++l)
-            if ((rc = tr[l].backward_step(t, in_wf(t, l), in_res(t, l), in_st(t, l), res_hist + (size_t)t * fwf + (size_t)lane_b0[l] * p2,
-                                          k_sq + (size_t)lane_b0[l] * n * n, loss_c, cur_wf[l], cur_st[l])) != HN_OK)
-                return rc;
+    for (int t = n_unroll - 1; t >= 0 && rc == HN_OK; --t)
+        for (int l = 0; l < lanes && rc == HN_OK; ++l)
+            rc = tr[l].backward_step(t, in_wf(t, l), in_res(t, l), in_st(t, l), res_hist + (size_t)t * fwf + (size_t)lane_b0[l] * p2,
+                                     k_sq + (size_t)lane_b0[l] * n * n, loss_c, cur_wf[l], cur_st[l]);
+    if (rc != HN_OK) { join_streams(); return rc; }
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
         for (int k = 0; k < 2; ++k)   // the side stream's weight-gradient launches join the lane's stream

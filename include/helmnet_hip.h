@@ -231,8 +231,8 @@ int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll);
  * d loss / d (wf, res, states) (optional, NULL to skip).
  * Stream capture (a caller recording the step into a HIP graph): supported with the workspace in place -- call hn_train_reserve (or run
  * one eager hn_train_grad of the same shape) first; a captured call whose workspace would have to grow returns HN_ERR_STATE instead of
- * breaking the capture.  The launch tables of a captured call are copied from a pinned buffer at every replay: do not run other training
- * calls of this context between replays of the graph. */
+ * breaking the capture.  The launch tables of a captured call live in a pinned buffer of their own that eager calls never rewrite; capturing a
+ * SECOND graph on the same context rewrites it (one captured training step per context at a time). */
 int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const float* res, const float* states, const float* k_sq,
                   const float* src, int src_batch, int batch, int n_unroll, float loss_scale, float* wf_hist, float* res_hist,
                   float* st_hist, float* loss, float* grad, float* grad_wf0, float* grad_res0, float* grad_st0, void* stream);
