@@ -383,8 +383,11 @@ def test_fused_training_launches_keep_the_gradient_bits(solver, weights, g_train
     finally:
         eng.set_option("train_fused", 7)
         eng.set_option("train_overlap", 0)
+    # (the LOSS is read off per-sample sums of squares that the spectral row kernel accumulates with float atomics: its last bit depends on
+    # the order in which the workgroups of a sample arrive, so it is compared to rounding; nothing downstream reads it)
     for other in ((3, 0), (1, 0), (7, 1)):
-        for a, c in zip(outs[(7, 0)], outs[other]):
+        assert abs(float(outs[(7, 0)][0]) - float(outs[other][0])) <= 1e-6 * abs(float(outs[other][0]))
+        for a, c in zip(outs[(7, 0)][1:], outs[other][1:]):
             assert torch.equal(a, c), other
     # the fused forward: fp32 rounding at most.  (At this size it is in fact bit-identical as well: the f32 matrix instruction is an exact fmaf
     # chain and k_dc_mfma_p walks (channel, row, tap) in k_conv3's order with the bias added last; the strip kernel of W >= 128 starts from the bias.)
