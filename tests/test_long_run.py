@@ -81,8 +81,12 @@ def _check(tag, g, trace, fields, n_gold, early=300, floor=slice(-50, None)):
     report = {}
     for cp, wf in fields.items():
         err = np.abs(wf[:n_gold, :, ::st, ::st] - g[f"{tag}_wf_it{cp}"]).reshape(n_gold, -1).max(1)
-        bar = np.maximum(1e-4, 2 * g[f"{tag}_f32dev_probe_it{cp}"].max())
+        dev = g[f"{tag}_f32dev_probe_it{cp}"]      # what the REFERENCE's own fp32 run deviates from its float64 run, per sample
+        # every sample within twice the reference's worst sample AND (r4) within four times what the reference's fp32 run deviates
+        # on THAT sample (observed: 0.1 - 1.1 x, one sample of cfg2 at iteration 300 3.4 x: two fp32 evaluations of a chaotic iteration)
+        bar = np.minimum(np.maximum(1e-4, 2 * dev.max()), np.maximum(1e-4, 4 * dev))
         report[cp] = (err, bar)
+        print(f"[{tag}] iteration {cp}: Linf vs the float64 trajectory per sample {err}, the reference's own fp32 deviation {g[f'{tag}_f32dev_probe_it{cp}']}")
         assert (err <= bar).all(), (tag, cp, err, bar)
     return report
 
