@@ -676,11 +676,17 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
     const bool active = split < S, isb = pair == P - 1;
     const int ci = pair / 3, ky = pair - ci * 3;
     const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
-    float acc[3][CO];
+    // accumulators as channel PAIRS (HN_WG_PK, default): the gradient values of a pixel are adjacent in LDS, so a pair is one 8-byte read and a
+    // v_pk_fma_f32 with two VGPR operands does two of the 3 x CO multiply-adds of a pixel (no SGPR-pair operand as in the 3x3 data kernels,
+    // where the packed form measured slower)
+#ifndef HN_WG_PK
+#define HN_WG_PK 1
+#endif
+    f32x2 acc2[3][CO / 2];
 #pragma unroll
     for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int c = 0; c < CO; ++c) acc[k][c] = 0.f;
+        for (int c = 0; c < CO / 2; ++c) acc2[k][c] = (f32x2){0.f, 0.f};
     const int ntiles = a.tiles_x * a.tiles_y * a.batch;
     for (int tile = bid; tile < ntiles; tile += a.nblk) {
         const int tx = tile % a.tiles_x, r0 = tile / a.tiles_x, ty = r0 % a.tiles_y, b = r0 / a.tiles_y;
@@ -718,11 +724,20 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
                 for (int c = 0; c < TW / 2; ++c) {
                     const float xc = isb ? 0.f : xr[c + 2];
 #pragma unroll
-                    for (int o = 0; o < CO; ++o) {
-                        const float gv = gr[c * CO + o];
-                        acc[0][o] = fmaf(gv, xa, acc[0][o]);
-                        acc[1][o] = fmaf(gv, xb, acc[1][o]);
-                        acc[2][o] = fmaf(gv, xc, acc[2][o]);
+                    for (int o = 0; o < CO / 2; ++o) {
+                        const f32x2 gv = *reinterpret_cast<const f32x2*>(&gr[c * CO + 2 * o]);
+#if HN_WG_PK
+                        acc2[0][o] = __builtin_elementwise_fma(gv, (f32x2){xa, xa}, acc2[0][o]);
+                        acc2[1][o] = __builtin_elementwise_fma(gv, (f32x2){xb, xb}, acc2[1][o]);
+                        acc2[2][o] = __builtin_elementwise_fma(gv, (f32x2){xc, xc}, acc2[2][o]);
+#else
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            acc2[0][o][h] = fmaf(gv[h], xa, acc2[0][o][h]);
+                            acc2[1][o][h] = fmaf(gv[h], xb, acc2[1][o][h]);
+                            acc2[2][o][h] = fmaf(gv[h], xc, acc2[2][o][h]);
+                        }
+#endif
                     }
                     xa = isb ? 1.f : xb;
                     xb = xc;
@@ -737,7 +752,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int o = 0; o < CO; ++o) s_red[((split * P + pair) * 3 + k) * CO + o] = acc[k][o];
+            for (int o = 0; o < CO; ++o) s_red[((split * P + pair) * 3 + k) * CO + o] = acc2[k][o >> 1][o & 1];
     }
     __syncthreads();
     // every thread sums the row subsets (fixed order) of a few cells of the block's table row and adds them to it: consecutive

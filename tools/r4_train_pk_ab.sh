@@ -9,8 +9,8 @@ sys.argv = ["bench_train.py"] + sys.argv[2:]
 runpy.run_path("$R/tools/bench_train.py", run_name="__main__")
 PY
 for rep in 1 2; do
- for L in $R/helmnet_amd/libhelmnet_hip.so $R/tools/lib_trpk.so; do
-  for o in train_fused=3 train_fused=0; do
+ for L in $R/helmnet_amd/libhelmnet_hip.so $R/tools/lib_${VARIANT:-trpk}.so; do
+  for o in train_fused=7; do
    echo -n "$(basename $L) $o: "; python3 /tmp/bt.py $L --opt $o 2>/dev/null | tail -1 | python3 -c "import sys,json; print(round(json.loads(sys.stdin.read())['ms_per_step'],3))"
   done
  done
