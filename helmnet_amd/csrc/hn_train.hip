@@ -708,10 +708,19 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const Wg3Args* __restrict__
             WindowStager<IR, IC, 256> st;
             st.setup(tid, y0 - 1, x0 - 1, a.H, a.W, PI);
             st.template stage<GEN, 16>(a.src, CI, b, s_x, IR * PI, a.act_kind, slope);   // every channel in ONE round trip (with the gradient tile's loads)
+            // a pixel's CO gradient values are adjacent in LDS: stored as 16- / 8-byte vectors ([measured, r4 PMC] as CO scalar stores at a
+            // stride of CO dwords they were 8-way bank conflicts: 3.8 conflict cycles per LDS instruction over the whole kernel)
 #pragma unroll
-            for (int c = 0; c < CO; ++c)
+            for (int i = 0; i < NG; ++i) {
+                if constexpr (CO % 4 == 0) {
 #pragma unroll
-                for (int i = 0; i < NG; ++i) s_g[(tid + i * 256) * CO + c] = gv[c][i];
+                    for (int c = 0; c < CO; c += 4)
+                        *reinterpret_cast<float4*>(&s_g[(tid + i * 256) * CO + c]) = make_float4(gv[c][i], gv[c + 1][i], gv[c + 2][i], gv[c + 3][i]);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CO; c += 2) *reinterpret_cast<float2*>(&s_g[(tid + i * 256) * CO + c]) = make_float2(gv[c][i], gv[c + 1][i]);
+                }
+            }
         }
         __syncthreads();
         if (active) {
