@@ -23,7 +23,7 @@ HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2, "celu": 3, "tanh": 4, "gelu": 5
 HN_PRECISION = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16x2": 3, "valu": 4}
 HN_OPTION = {"lanes": 0, "side_stream": 1, "graph": 2, "deep": 3, "spectral_pfa": 4, "spectral_radix16": 5, "dc_valu": 6, "spectral_cols": 7, "train_lanes": 8, "dc_wino": 9, "train_fused": 10, "train_overlap": 11}
 HN_COUNTER = {"graph_replays": 0, "eager_iterations": 1, "graphs_captured": 2}
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); every symbol include/helmnet_hip.h declares
 SYMBOLS = {
@@ -56,7 +56,10 @@ SYMBOLS = {
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "hn_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                              c_float, c_float, c_int64, c_void_p]),
+    "hn_rows_gather": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "hn_rows_scatter": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "hn_train_peek": (c_int64, [c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "hn_train_set_forward_event": (c_int, [c_void_p, c_void_p, c_void_p, c_int64]),
     "hn_profile_enable": (c_int, [c_void_p, ctypes.c_uint64]),
     "hn_profile_min": (c_int, [c_void_p, POINTER(ctypes.c_double), c_int]),
     "hn_profile_stride": (c_int, [c_void_p, c_int]),

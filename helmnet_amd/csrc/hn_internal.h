@@ -222,6 +222,9 @@ struct hn_ctx {
     int opt_train_fused = 7;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
                                    // bit 1 the backward-data pass of a big level's DoubleConv as one tiled launch (k_dc_bwd_tile), bit 2 the hidden-state
                                    // DoubleConvs of all levels as one launch per direction (k_dc_state_batch)
+    hipEvent_t train_fwd_event = nullptr;   // caller-owned: recorded behind the forward sweep of hn_train_grad (hn_train_set_forward_event)
+    float* train_fwd_sumsq = nullptr;       // caller-owned pinned host floats: the [n_unroll, batch] sums of res^2 land here before that event
+    int64_t train_fwd_sumsq_cap = 0;
     int opt_train_lanes = 1;       // HN_OPT_TRAIN_LANES: 2 = the halves of the batch as two chains on two streams (measured: no gain)
     hipStream_t train_stream = nullptr;            // lane 1 (created on first use)
     hipEvent_t train_fork = nullptr, train_join = nullptr;

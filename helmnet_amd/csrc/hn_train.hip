@@ -1638,6 +1638,9 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     int rc = train_ready(ctx, batch, n_unroll);
     if (rc != HN_OK) return rc;
     if (src_batch != 1 && src_batch != batch) return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
+    if (ctx->train_fwd_sumsq != nullptr && (int64_t)n_unroll * batch > ctx->train_fwd_sumsq_cap)
+        return fail(ctx, HN_ERR_ARG, "hn_train_grad: the host table of hn_train_set_forward_event holds %lld floats, this call writes %lld", (long long)ctx->train_fwd_sumsq_cap,
+                    (long long)n_unroll * batch);
     DeviceGuard guard(ctx);
     hipStream_t s = (hipStream_t)stream;
     const int n = ctx->tab.n, depth = ctx->depth;
@@ -1759,6 +1762,15 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
                                     k_sq + (size_t)lane_b0[l] * n * n, src + (src_batch == 1 ? 0 : (size_t)lane_b0[l] * p2), src_batch == 1 ? 1 : lane_nb[l]);
         }
     if (rc != HN_OK) { join_streams(); return rc; }
+    if (ctx->train_fwd_event != nullptr && !capturing) {   // the histories are complete: the caller's host logic may read them while the backward pass runs (not recorded into a captured graph)
+        if (lanes == 2) {                    // (the second lane's forward sweep joins first)
+            HN_HIP(ctx, hipEventRecord(ctx->train_join, ctx->train_stream));
+            HN_HIP(ctx, hipStreamWaitEvent(s, ctx->train_join, 0));
+        }
+        if (ctx->train_fwd_sumsq != nullptr)   // sum over (2, N, N) of res^2 per (iteration, sample): what the reference's refill rule thresholds (hybridnet.py:437-438)
+            HN_HIP(ctx, hipMemcpyAsync(ctx->train_fwd_sumsq, ctx->tr.sumsq, sizeof(float) * (size_t)n_unroll * batch, hipMemcpyDeviceToHost, s));
+        HN_HIP(ctx, hipEventRecord(ctx->train_fwd_event, s));
+    }
     // backward sweep
     int cur_wf[2] = {0, 0}, cur_st[2] = {0, 0};
     for (int l = 0; l < lanes; ++l) {
@@ -1808,6 +1820,16 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
                            lanes == 2 ? ws[1]->slope_part : nullptr, (int)ws[1]->slope_stride, sj[1], grad);
     }
     HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int hn_train_set_forward_event(hn_ctx* ctx, void* event, float* sumsq_host, int64_t sumsq_capacity) {
+    if (!ctx) return HN_ERR_ARG;
+    if (sumsq_host != nullptr && (event == nullptr || sumsq_capacity < 1))
+        return fail(ctx, HN_ERR_ARG, "hn_train_set_forward_event: the host table needs the event that says when it is complete, and a capacity");
+    ctx->train_fwd_event = (hipEvent_t)event;
+    ctx->train_fwd_sumsq = sumsq_host;
+    ctx->train_fwd_sumsq_cap = sumsq_host != nullptr ? sumsq_capacity : 0;
     return HN_OK;
 }
 

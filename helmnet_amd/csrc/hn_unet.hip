@@ -354,7 +354,7 @@ __global__ __launch_bounds__(UpCfg::NT) void k_up8x8(Src in, Dst out, K8W w, int
     const TileId tl = xcd_tile();
     const int tid = threadIdx.x, b = tl.z;
     const int X0 = tl.x * C::TW, Y0 = tl.y * C::TH;
-    const int Hout = 2 * Hin, Wout = 2 * Win;
+    const int Wout = 2 * Win;
     for (int e = tid; e < C::PLANE; e += C::NT) {
         const int ir = e / C::PI, ic = e - ir * C::PI;
         const int y = Y0 - 2 + ir, x = X0 - 2 + ic;

@@ -388,6 +388,59 @@ class Engine:
                                    float(betas[0]), float(betas[1]), float(eps), float(weight_decay), float(clip_value), int(step), self._stream())
         _lib.check(rc, self.ctx, "hn_adam_step")
 
+    # ---- rows of a replay buffer (hn_rows_gather / hn_rows_scatter) ----------------------------------------------------
+    def _rows_args(self, buffers, slots):
+        n = len(buffers)
+        cap = buffers[0].shape[0]
+        for b in buffers:
+            if b.dtype != torch.float32 or b.device != self.device or not b.is_contiguous() or b.shape[0] != cap:
+                raise ValueError("replay-buffer fields must be contiguous fp32 [capacity, ...] tensors on the engine's device")
+        slots = np.ascontiguousarray(np.asarray(slots).reshape(-1), dtype=np.int32)
+        rows = (ctypes.c_int64 * n)(*[b[0].numel() for b in buffers])
+        return n, cap, slots, rows, (ctypes.c_void_p * n)(*[b.data_ptr() for b in buffers])
+
+    def rows_gather(self, buffers, slots):
+        """ReplayBuffer.sample's stack (replaybuffer.py:37-47): [len(slots), ...] copies of rows ``slots`` (host integers) of every buffer, one launch."""
+        n, cap, slots, rows, bufs = self._rows_args(buffers, slots)
+        out = [torch.empty((slots.size,) + tuple(b.shape[1:]), dtype=torch.float32, device=self.device) for b in buffers]
+        outs = (ctypes.c_void_p * n)(*[o.data_ptr() for o in out])
+        rc = self.lib.hn_rows_gather(self.ctx, n, bufs, rows, cap, slots.ctypes.data_as(ctypes.c_void_p), int(slots.size), outs, self._stream())
+        _lib.check(rc, self.ctx, "hn_rows_gather")
+        return out
+
+    def rows_scatter(self, buffers, slots, new_rows):
+        """ReplayBuffer.append for a batch of slots (replaybuffer.py:29-30): ``buffers[f][slots[j]] = new_rows[f][j]``; ``None`` writes zeros, a tensor
+        with ONE row is written to every slot.  One launch."""
+        n, cap, slots, rows, bufs = self._rows_args(buffers, slots)
+        keep, ptrs, strides = [], [], []
+        for b, v in zip(buffers, new_rows):
+            if v is None:
+                ptrs.append(None); strides.append(0)
+                continue
+            if v.dtype != torch.float32 or v.device != self.device or tuple(v.shape[1:]) != tuple(b.shape[1:]) or v.shape[0] not in (1, slots.size):
+                raise ValueError(f"new rows of shape {tuple(v.shape)} do not fit {slots.size} slots of {tuple(b.shape[1:])}")
+            v = v.contiguous()
+            keep.append(v)
+            ptrs.append(v.data_ptr()); strides.append(0 if (v.shape[0] == 1 and slots.size > 1) else b[0].numel())
+        rc = self.lib.hn_rows_scatter(self.ctx, n, bufs, rows, cap, slots.ctypes.data_as(ctypes.c_void_p), int(slots.size),
+                                      (ctypes.c_void_p * n)(*ptrs), (ctypes.c_int64 * n)(*strides), self._stream())
+        _lib.check(rc, self.ctx, "hn_rows_scatter")
+
+    def set_train_forward_event(self, event: Optional[torch.cuda.Event], sumsq_host: Optional[torch.Tensor] = None) -> None:
+        """hn_train_set_forward_event: ``event`` is recorded behind the forward sweep of every later ``train_grad`` (None clears it); ``sumsq_host``
+        (a pinned fp32 host tensor) receives the [n_unroll, batch] table of per-sample sums of res^2 before the event fires."""
+        handle, table, cap = None, None, 0
+        if event is not None:
+            if not event.cuda_event:      # (torch creates the HIP event lazily: recording it once makes the handle exist)
+                event.record(torch.cuda.current_stream(self.device))
+            handle = ctypes.c_void_p(event.cuda_event)
+        if sumsq_host is not None:
+            if sumsq_host.dtype != torch.float32 or sumsq_host.device.type != "cpu" or not sumsq_host.is_pinned() or not sumsq_host.is_contiguous():
+                raise ValueError("sumsq_host must be a contiguous pinned fp32 host tensor")
+            table, cap = ctypes.c_void_p(sumsq_host.data_ptr()), sumsq_host.numel()
+        _lib.check(self.lib.hn_train_set_forward_event(self.ctx, handle, table, cap), self.ctx, "hn_train_set_forward_event")
+        self._fwd_event, self._fwd_sumsq = event, sumsq_host           # keep them alive while the library holds the handles
+
     PEEK = {"x": 0, "sig_mid": 1, "out": 2, "st_mid": 3, "u": 4, "dec_mid": 5, "y": 6, "inc_mid": 7, "g_x": 16, "g_out": 18, "g_u": 20, "g_y": 22}
 
     def train_peek(self, kind: str, level: int, batch: int) -> torch.Tensor:

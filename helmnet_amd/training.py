@@ -18,7 +18,7 @@ from __future__ import annotations
 
 import collections
 from random import choice
-from typing import List, Optional
+from typing import List, Optional, Sequence
 
 import numpy as np
 import torch
@@ -31,6 +31,13 @@ Experience = collections.namedtuple(
 )
 
 
+def _index_on(device, idx_host) -> torch.Tensor:
+    """A host index array as an int64 tensor on ``device`` -- through pinned memory and a non-blocking copy on a GPU: a copy from pageable
+    memory would make the host wait for everything already enqueued on the stream (the backward pass of the step in flight)."""
+    t = torch.from_numpy(np.ascontiguousarray(idx_host, dtype=np.int64))
+    return t.pin_memory().to(device, non_blocking=True) if torch.device(device).type == "cuda" else t.to(device)
+
+
 class ReplayBuffer:
     """The reference's replay buffer (replaybuffer.py:20-47: ``capacity`` slots addressed by index, ``sample`` draws distinct
     slots with ``np.random.choice(capacity, batch_size, replace=False)``) kept as ONE pre-allocated ``[capacity, ...]`` tensor per
@@ -40,11 +47,14 @@ class ReplayBuffer:
 
     FIELDS = ("wavefield", "hidden_state", "k_sq", "residual", "source")
 
-    def __init__(self, capacity: int):
+    def __init__(self, capacity: int, engine=None):
         self.capacity = capacity
+        self.engine = engine      # helmnet_amd.engine.Engine: rows move with hn_rows_gather / hn_rows_scatter (one launch per call, the slot list in the
+                                  # kernel arguments); None (host tensors, tests): the same with torch's index_select / index_copy_
         self.fields: Optional[dict] = None                       # name -> [capacity, ...] tensor
         self.iteration = np.zeros(capacity, dtype=np.int64)      # nominal solver iteration of every slot (host side: it only feeds Python logic)
         self.filled = np.zeros(capacity, dtype=bool)
+        self.last_sample_index: Optional[torch.Tensor] = None
 
     def __len__(self):
         return self.capacity
@@ -60,11 +70,43 @@ class ReplayBuffer:
         idx_host = np.asarray(indices.cpu() if torch.is_tensor(indices) else indices, dtype=np.int64).reshape(-1)
         if idx_host.size == 0:
             return
-        for k, v in vals.items():
-            buf = self.fields[k]
-            buf.index_copy_(0, torch.as_tensor(idx_host, device=buf.device), v.to(device=buf.device, dtype=buf.dtype))
+        if self._native():
+            self.engine.rows_scatter([self.fields[k] for k in self.FIELDS], idx_host, [self._row(k, v) for k, v in vals.items()])
+        else:
+            idx = _index_on(next(iter(self.fields.values())).device, idx_host)
+            for k, v in vals.items():
+                buf = self.fields[k]
+                buf.index_copy_(0, idx, v.to(device=buf.device, dtype=buf.dtype))
         self.iteration[idx_host] = np.asarray(iterations, dtype=np.int64).reshape(-1)
         self.filled[idx_host] = True
+
+    def _native(self) -> bool:
+        return self.engine is not None and self.fields is not None and all(f.device == self.engine.device and f.dtype == torch.float32 for f in self.fields.values())
+
+    def _row(self, k, v):
+        buf = self.fields[k]
+        return v.to(device=buf.device, dtype=buf.dtype)
+
+    def update(self, indices, iterations, index_device: Optional[torch.Tensor] = None, zero: Sequence[str] = (), **fields):
+        """Rewrite SOME fields of already written slots: slot ``indices[j]`` <- row j of every tensor in ``fields`` (one ``index_copy_`` each), zeros for the
+        fields named in ``zero`` (one ``index_fill_`` each), a tensor with ONE row goes to every slot; the other fields keep what they hold.  ``index_device``: ``indices`` on the device, if the caller has it."""
+        idx_host = np.asarray(indices, dtype=np.int64).reshape(-1)
+        if idx_host.size == 0:
+            return
+        if not self.filled[idx_host].all():
+            raise ValueError("update of an empty replay-buffer slot")
+        if self._native():
+            names = list(fields) + list(zero)
+            self.engine.rows_scatter([self.fields[k] for k in names], idx_host, [self._row(k, v) for k, v in fields.items()] + [None] * len(zero))
+        else:
+            idx = index_device if index_device is not None else _index_on(next(iter(self.fields.values())).device, idx_host)
+            for k, v in fields.items():
+                buf = self.fields[k]
+                v = v.expand(idx_host.size, *v.shape[1:]) if v.shape[0] == 1 else v        # one row for every slot
+                buf.index_copy_(0, idx, v.to(device=buf.device, dtype=buf.dtype))
+            for k in zero:
+                self.fields[k].index_fill_(0, idx, 0)
+        self.iteration[idx_host] = np.asarray(iterations, dtype=np.int64).reshape(-1)
 
     def append(self, experience, index):   # replaybuffer.py:29-30
         self.write([index], *(f.unsqueeze(0) for f in experience[:5]), [experience[5]])
@@ -80,10 +122,12 @@ class ReplayBuffer:
         indices = np.random.choice(self.capacity, batch_size, replace=False)
         if not self.filled[indices].all():
             raise ValueError("sampled an empty replay-buffer slot: fill the buffer first (fill_replay_buffer)")
-        out = []
-        for k in self.FIELDS:
-            buf = self.fields[k]
-            out.append(buf.index_select(0, torch.as_tensor(indices, device=buf.device)))
+        if self._native():
+            out = self.engine.rows_gather([self.fields[k] for k in self.FIELDS], indices)
+        else:
+            idx = _index_on(next(iter(self.fields.values())).device, indices)
+            self.last_sample_index = idx            # (on the device already: ``update`` of the same slots needs no second copy)
+            out = [self.fields[k].index_select(0, idx) for k in self.FIELDS]
         return (*out, tuple(int(i) for i in self.iteration[indices]), indices)
 
 
@@ -182,9 +226,15 @@ class Trainer:
         self._lr_holder = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=self.lr)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self._lr_holder, mode="min", factor=0.5, patience=10,
                                                                      min_lr=float(hp.minimum_learning_rate))
-        self.replaybuffer = ReplayBuffer(hp.buffer_size)
+        self.replaybuffer = ReplayBuffer(hp.buffer_size, engine=self.engine)
         self.epoch_losses: List[torch.Tensor] = []
         self.new_sos = 0
+        # The refill decision of training_step needs ONE number per sample on the host (is the advanced residual still bounded?).  It depends on the
+        # forward sweep only, and the forward sweep already sums res^2 per (iteration, sample) for the loss: the library copies that table to pinned
+        # memory and records `_fwd_event` behind the forward sweep, so the host waits for that instead of draining the backward pass too.
+        self._fwd_event = torch.cuda.Event()
+        self._sumsq_host = None
+        self._reserve_sumsq(int(hp.batch_size) * int(hp.unrolling_steps))
 
     # ------------------------------------------------------------------ weights -----------------
     def sync_to_module(self):
@@ -212,19 +262,23 @@ class Trainer:
         self.sync_to_module()
 
     # ------------------------------------------------------------------ replay buffer -----------
-    def _fresh_fields(self, sos_maps: torch.Tensor):
+    def _fresh_fields(self, sos_maps: torch.Tensor, zeros: bool = True):
         """Initial (zero wavefield) experiences of a batch of [n, 1, N, N] sound-speed maps (hybridnet.py:203-216, 454-462) as the five
-        field tensors: ONE get_initials and ONE residual call for the whole batch."""
+        field tensors: ONE get_initials and ONE residual call for the whole batch.  ``zeros=False``: only (k_sq, residual, source) -- the
+        caller zero-fills the wavefield and hidden-state rows in place."""
         s = self.solver
         s.reset_source()
         k_sq, wf = s.get_initials(sos_maps.float().to(s.device))
-        s.f.clear_states(wf)
-        h = s.f.get_states(flatten=True)
         # after set_source_maps(sources) the reference's self.source holds one map per sample and its get_residual broadcasts
         # (:556); the maps of a batch are equal unless the caller set different ones -- the first one is the source of a fresh slot
         src0 = s.source[:1].detach().float().contiguous()
         res = s.engine().residual(wf, k_sq.contiguous(), src0)
-        return wf, h, k_sq, res, src0.expand(wf.shape[0], -1, -1, -1)
+        if not zeros:
+            return k_sq, res, src0          # (one source row for every slot)
+        src = src0.expand(wf.shape[0], -1, -1, -1)
+        s.f.clear_states(wf)
+        h = s.f.get_states(flatten=True)
+        return wf, h, k_sq, res, src
 
     def _fresh_experience(self, sos_map: torch.Tensor, iteration: int) -> Experience:
         return Experience(*(f[0] for f in self._fresh_fields(sos_map)), iteration)
@@ -239,11 +293,18 @@ class Trainer:
                 self.replaybuffer.write(idx, *self._fresh_fields(maps), [10 * c for c in idx])
 
     # ------------------------------------------------------------------ one step ----------------
+    def _reserve_sumsq(self, floats: int):
+        if self._sumsq_host is None or self._sumsq_host.numel() < floats:
+            self._sumsq_host = torch.zeros(max(int(floats), 1 << 16), dtype=torch.float32).pin_memory()
+        if getattr(self.engine, "_fwd_sumsq", None) is not self._sumsq_host:      # (another Trainer on the same solver may have registered its own)
+            self.engine.set_train_forward_event(self._fwd_event, self._sumsq_host)
+
     def loss_and_grad(self, wavefields, h_states, k_sqs, residual, sources, num_iterations: Optional[int] = None, input_grads: bool = False):
         """The differentiable core of training_step (hybridnet.py:399-409) + backward: returns the engine's dict with the loss
         (1e4 * mean(res^2) over all unrolled residuals), the flat gradient (already reduced over ranks) and the n_steps lists."""
         T = int(self.solver.hparams.unrolling_steps if num_iterations is None else num_iterations)
         self.solver.set_source_maps(sources)   # :400
+        self._reserve_sumsq(T * wavefields.shape[0])
         out = self.engine.train_grad(self.weights, wavefields.float().contiguous(), residual.float().contiguous(), h_states.float().contiguous(),
                                      k_sqs.float().contiguous(), sources.float().contiguous(), T, 1e4, input_grads, grad=self.grad)
         self.grad_reduce(self.grad)
@@ -263,24 +324,28 @@ class Trainer:
         maxiter = min([self.current_epoch * 20 + 1, hp.max_iterations])
         wavefields, h_states, k_sqs, residual, sources, timesteps, indices = self.replaybuffer.sample(hp.batch_size)
         out = self.loss_and_grad(wavefields, h_states, k_sqs, residual, sources)
-        self.optimizer_step()
         loss = out["loss"][0]
         T = out["residuals"].shape[0]
         iteration = np.random.choice(T)
         res_it, wf_it, st_it = out["residuals"][iteration], out["wavefields"][iteration], out["states"][iteration]
-        # which sampled slots keep their (advanced) experience: bounded residual and young enough (:436-452).  ONE device-to-host read
-        # per step: the count of rejected slots decides how many fresh maps Python's ``choice`` draws, as in the reference's loop.
+        self.optimizer_step()
+        # which sampled slots keep their (advanced) experience: bounded residual and young enough (:436-452).  The count of rejected slots decides how
+        # many fresh maps Python's ``choice`` draws, as in the reference's loop, so the host needs the answer -- it waits for the FORWARD sweep only
+        nb = wavefields.shape[0]
+        self._fwd_event.synchronize()
+        meansq = self._sumsq_host[: T * nb].view(T, nb)[iteration].numpy() / np.float32(res_it[0].numel())       # res.pow(2).mean() per sample, fp32
         new_timesteps = np.asarray(timesteps, dtype=np.int64) + iteration + 1
-        keep = (res_it.pow(2).mean((1, 2, 3)) < 1).cpu().numpy() & (new_timesteps < maxiter)
-        kept, fresh = np.nonzero(keep)[0], np.nonzero(~keep)[0]
+        keep = (meansq < 1) & (new_timesteps < maxiter)
+        fresh = np.nonzero(~keep)[0]
         with torch.no_grad():
-            if kept.size:
-                k = torch.as_tensor(kept, device=wf_it.device)
-                self.replaybuffer.write(indices[kept], wf_it.index_select(0, k), st_it.index_select(0, k), k_sqs.index_select(0, k),
-                                        res_it.index_select(0, k), sources.index_select(0, k), new_timesteps[kept])
+            # every sampled slot takes its advanced wavefield / hidden state / residual (k_sq and the source of a slot do not change: :441-449) with the index
+            # tensor ``sample`` left on the device -- three launches, no gather, no copy; the rejected slots are then overwritten by fresh experiences
+            self.replaybuffer.update(indices, np.where(keep, new_timesteps, 0), index_device=self.replaybuffer.last_sample_index,
+                                     wavefield=wf_it, hidden_state=st_it, residual=res_it)
             if fresh.size:   # one random map of this batch per rejected slot (drawn in slot order, as the reference's loop does), solved from scratch
                 maps = torch.stack([choice(sos_batch) for _ in fresh])
-                self.replaybuffer.write(indices[fresh], *self._fresh_fields(maps), np.zeros(fresh.size, dtype=np.int64))
+                k_sq, res, src = self._fresh_fields(maps, zeros=False)
+                self.replaybuffer.update(indices[fresh], np.zeros(fresh.size, dtype=np.int64), zero=("wavefield", "hidden_state"), k_sq=k_sq, residual=res, source=src)
         counter = int(fresh.size)
         self.new_sos = counter
         self.global_step += 1

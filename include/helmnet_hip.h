@@ -102,7 +102,7 @@ enum hn_option {
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };
 
-#define HN_ABI_VERSION 4
+#define HN_ABI_VERSION 5
 int hn_abi_version(void);
 
 /* Create / destroy a context on HIP device `device_id`. */
@@ -236,6 +236,31 @@ int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll);
 int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const float* res, const float* states, const float* k_sq,
                   const float* src, int src_batch, int batch, int n_unroll, float loss_scale, float* wf_hist, float* res_hist,
                   float* st_hist, float* loss, float* grad, float* grad_wf0, float* grad_res0, float* grad_st0, void* stream);
+
+/* ABI v5.  `event` (a hipEvent_t, or NULL to clear): every later hn_train_grad on this context records it on the caller's stream BEHIND THE FORWARD SWEEP, i.e. when
+ * wf_hist / res_hist / st_hist are complete and before the backward pass starts.  The reference's training_step decides from the residual of one
+ * unrolled iteration which replay-buffer slots to refill (`res.pow(2).mean() < 1`, hybridnet.py:431-463) -- a host decision; with this event the host
+ * takes it while the backward pass runs instead of draining the queue after it (helmnet_amd.training.Trainer).
+ * `sumsq_host` (optional; pinned host memory of `sumsq_capacity` floats): the forward sweep's own table of sum over (2, N, N) of res^2, one float per
+ * (iteration t, sample b) at [t * batch + b], is copied there before the event is recorded -- the refill rule needs nothing else, so no kernel of the
+ * caller has to run between the two sweeps.  The sums are accumulated with float atomics (their last bits are not reproducible, like `loss`).
+ * hn_train_grad returns HN_ERR_ARG if n_unroll * batch exceeds the capacity.  The caller owns event and table; not recorded / copied by a call that is
+ * being captured into a HIP graph. */
+int hn_train_set_forward_event(hn_ctx* ctx, void* event, float* sumsq_host, int64_t sumsq_capacity);
+
+/* ABI v5.  Rows of the caller's replay buffer (replaybuffer.py:20-47; hybridnet.py:388-397 sample, :436-463 refill).  The reference keeps a Python list of
+ * `capacity` Experience tuples; on the device that is one [capacity, row_floats[f]] fp32 array per field f (wavefield, hidden state, k_sq, residual,
+ * source: n_fields <= 8), owned by the caller.  `slots`: `count` HOST integers in [0, capacity) -- they travel in the kernel arguments, so neither
+ * call copies anything to the device or waits for it.
+ *   hn_rows_gather : out[f][j, :] = buffers[f][slots[j], :]            (ReplayBuffer.sample's `stack`, all fields in one launch)
+ *   hn_rows_scatter: buffers[f][slots[j], :] = rows[f][j, :]           (ReplayBuffer.append for a batch of slots); rows[f] == NULL writes zeros (the
+ *                    wavefield and hidden state of a fresh experience, :456-458); rows_stride[f] = floats between consecutive new rows, 0 = the same row for
+ *                    every slot (the one source map, :462); rows_stride == NULL means row_floats.  Slots must be distinct (as `sample` draws them).
+ * HN_ERR_ARG for a slot outside the buffer, a NULL array, more than 8 fields. */
+int hn_rows_gather(hn_ctx* ctx, int n_fields, const float* const* buffers, const int64_t* row_floats, int64_t capacity, const int32_t* slots,
+                   int count, float* const* out, void* stream);
+int hn_rows_scatter(hn_ctx* ctx, int n_fields, float* const* buffers, const int64_t* row_floats, int64_t capacity, const int32_t* slots, int count,
+                    const float* const* rows, const int64_t* rows_stride, void* stream);
 
 /* One optimiser step on caller-owned device arrays of n floats: gradient value clipping to [-clip_value, clip_value]
  * (clip_value <= 0: none; torch.nn.utils.clip_grad_value_, hybridnet.py:172-176), then torch.optim.Adam as configured by the

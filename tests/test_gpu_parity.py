@@ -44,7 +44,7 @@ def _err(name, got, g, n):
 def test_library_is_the_hip_build():
     from helmnet_amd import _lib
     lib = _lib.load()
-    assert lib.hn_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.hn_abi_version() == _lib.ABI_VERSION == 5
     assert torch.cuda.is_available()
 
 

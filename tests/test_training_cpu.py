@@ -130,6 +130,25 @@ def test_replay_buffer_follows_the_reference_semantics():
     assert [b.iteration for b in rb.buffer] == [32, 10, 7, 30, 40, 31]
     assert float(rb.buffer[5].wavefield[0, 0, 0]) == 9.0 and float(rb.buffer[1].wavefield[0, 0, 0]) == 1.0
     rb.write(np.array([], dtype=np.int64), *(torch.zeros(0, 2, 4, 4), torch.zeros(0, 2, 21), torch.zeros(0, 1, 4, 4), torch.zeros(0, 2, 4, 4), torch.zeros(0, 2, 4, 4)), [])
+    # partial update (the training step's write-back): the advanced fields of all sampled slots with the index tensor ``sample`` left behind,
+    # then the rejected ones re-initialised (zero wavefield / state, new k_sq / residual / source); untouched fields and slots keep their contents
+    np.random.seed(3)
+    wf, h, k, r, s, its, idx = rb.sample(3)
+    assert rb.last_sample_index.tolist() == idx.tolist()
+    k_before = [rb.buffer[i].k_sq.clone() for i in range(6)]
+    rb.update(idx, [101, 102, 103], index_device=rb.last_sample_index, wavefield=wf + 50, hidden_state=h + 50, residual=r + 50)
+    for j, i in enumerate(idx):
+        e = rb.buffer[i]
+        assert e.iteration == 101 + j and torch.equal(e.wavefield, wf[j] + 50) and torch.equal(e.residual, r[j] + 50) and torch.equal(e.k_sq, k_before[i])
+    others = [i for i in range(6) if i not in idx.tolist()]
+    rb.update(idx[1:2], [0], zero=("wavefield", "hidden_state"), k_sq=torch.full((1, 1, 4, 4), 4.0), residual=torch.full((1, 2, 4, 4), -1.0), source=torch.ones(1, 2, 4, 4))
+    e = rb.buffer[idx[1]]
+    assert e.iteration == 0 and float(e.wavefield.abs().max()) == 0 and float(e.hidden_state.abs().max()) == 0 and float(e.k_sq.min()) == 4.0 and float(e.residual.max()) == -1.0
+    assert all(torch.equal(rb.buffer[i].k_sq, k_before[i]) for i in others)
+    rb2 = ReplayBuffer(2)
+    rb2.append(Experience(torch.zeros(2, 4, 4), torch.zeros(2, 21), torch.zeros(1, 4, 4), torch.zeros(2, 4, 4), torch.zeros(2, 4, 4), 0), 0)
+    with pytest.raises(ValueError):
+        rb2.update([1], [5], wavefield=torch.zeros(1, 2, 4, 4))      # slot 1 was never written
 
 
 def _free_port():

@@ -448,6 +448,60 @@ def test_two_lanes_give_the_gradient_of_one_lane(solver, weights):
     assert torch.equal(a1["residuals"], a2["residuals"]) and rel(a1["grad"], a2["grad"]) <= 2e-6
 
 
+def test_forward_event_fires_behind_the_forward_sweep(solver, weights):
+    """hn_train_set_forward_event (ABI v5): the caller's event is recorded once the histories are complete, BEFORE the backward sweep, and the
+    forward sweep's table of per-(iteration, sample) sums of res^2 is in the caller's pinned memory by then -- what Trainer.training_step decides its
+    refill from.  A side stream waiting on the event reads the final residual history while the backward pass still runs."""
+    n, b, T = 96, 8, 6
+    solver.set_domain_size(n, source_location=[70, 48])
+    eng = solver.engine()
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=5)).to(DEV)
+    out = solver.forward(sos, num_iterations=3, return_wavefields=True, return_states=True)
+    args = [out["wavefields"][-1].contiguous(), out["residuals"][-1].contiguous(), out["states"][-1].contiguous(),
+            ((1.0 / sos) ** 2).contiguous(), solver.source.detach().repeat(b, 1, 1, 1).contiguous()]
+    blob = torch.from_numpy(pack_weights(weights)).to(DEV)
+    ref = eng.train_grad(blob, *args, T, 1e4)
+    torch.cuda.synchronize()
+    want = ref["residuals"].double().pow(2).sum((2, 3, 4)).cpu()          # [T, b]
+    fwd, start, end, done = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+    side = torch.cuda.Stream(device=DEV)
+    host = torch.empty(ref["residuals"].shape, dtype=torch.float32).pin_memory()
+    table = torch.zeros(T * b, dtype=torch.float32).pin_memory()
+    eng.set_train_forward_event(fwd, table)
+    try:
+        for lanes in (1, 2):
+            eng.set_option("train_lanes", lanes)
+            eng.train_grad(blob, *args, T, 1e4)     # (the first call of a lane count allocates its workspace)
+            torch.cuda.synchronize()
+            host.zero_(); table.zero_()
+            start.record()
+            got = eng.train_grad(blob, *args, T, 1e4)
+            with torch.cuda.stream(side):
+                side.wait_event(fwd)
+                host.copy_(got["residuals"], non_blocking=True)
+                done.record(side)
+            end.record()
+            fwd.synchronize()
+            sums = table.clone()             # taken while the backward sweep may still be running
+            done.synchronize()
+            snapshot = host.clone()
+            torch.cuda.synchronize()
+            assert torch.equal(snapshot, ref["residuals"].cpu()), lanes
+            assert float(((sums.view(T, b).double() - want).abs() / want).max()) <= 1e-5, lanes
+            assert torch.equal(got["grad"], ref["grad"]) or lanes == 2
+            t_fwd, t_all = start.elapsed_time(fwd), start.elapsed_time(end)
+            print(f"lanes {lanes}: forward event at {t_fwd:.2f} ms of {t_all:.2f} ms")
+            assert t_fwd < 0.6 * t_all, (t_fwd, t_all)
+        eng.set_option("train_lanes", 1)
+        with pytest.raises(ValueError, match="host table"):          # a call that would overrun the caller's table is refused
+            eng.train_grad(blob, *args, T + 1, 1e4)
+    finally:
+        eng.set_option("train_lanes", 1)
+        eng.set_train_forward_event(None)
+    again = eng.train_grad(blob, *args, T + 1, 1e4)      # cleared: nothing recorded or copied
+    assert torch.isfinite(again["grad"]).all()
+
+
 def test_training_step_can_be_captured_in_a_hip_graph(solver, weights):
     """hn_train_grad only enqueues work on the caller's stream (under capture it skips its host-side event bookkeeping), so a step can be
     recorded with torch.cuda.graph and replayed: the replay's gradient is bit-identical to the eager call's.  (Replay is NOT faster --
@@ -591,6 +645,98 @@ def test_trainer_runs_training_steps_and_learns(solver):
     b = tr2.loss_and_grad(*probe[:5])
     tr2.optimizer_step()
     assert torch.equal(a["grad"], b["grad"]) and torch.equal(tr.weights, tr2.weights)
+
+
+def test_replay_rows_gather_and_scatter_match_index_select_and_index_copy(solver):
+    """hn_rows_gather / hn_rows_scatter (ABI v5; replaybuffer.py:29-47 on device arrays): byte moves, so equality is exact.  Rows that are not a
+    multiple of four floats (scalar path), more slots than one launch carries (768), zero rows, one row for every slot, slot errors."""
+    eng = solver.engine()
+    g = torch.Generator().manual_seed(0)
+    for cap, count, shapes in ((40, 32, [(2, 96, 96), (2, 12240), (1, 96, 96)]), (23, 7, [(2, 9, 9), (1530,), (3,)]), (1000, 900, [(2, 8, 8), (5,)])):
+        bufs = [torch.randn((cap,) + sh, generator=g).to(DEV) for sh in shapes]
+        slots = np.random.default_rng(count).permutation(cap)[:count]
+        idx = torch.from_numpy(slots).to(DEV)
+        got = eng.rows_gather(bufs, slots)
+        for b, o in zip(bufs, got):
+            assert o.shape == (count,) + tuple(b.shape[1:]) and torch.equal(o, b.index_select(0, idx))
+        new = [torch.randn((count,) + sh, generator=g).to(DEV) for sh in shapes]
+        want = [b.clone().index_copy_(0, idx, v) for b, v in zip(bufs, new)]
+        eng.rows_scatter(bufs, slots, new)
+        assert all(torch.equal(b, w) for b, w in zip(bufs, want))
+        # zeros for the first field, ONE row for every slot of the second, untouched rows stay
+        one = torch.randn((1,) + shapes[1], generator=g).to(DEV)
+        want0 = bufs[0].clone().index_fill_(0, idx[: count // 2], 0)
+        want1 = bufs[1].clone().index_copy_(0, idx[: count // 2], one.expand(count // 2, *shapes[1]))
+        eng.rows_scatter(bufs[:2], slots[: count // 2], [None, one])
+        assert torch.equal(bufs[0], want0) and torch.equal(bufs[1], want1)
+    # an offset view of a larger allocation (base not 16-byte aligned): the scalar path
+    big = torch.randn(10 * 8 + 1, generator=g).to(DEV)
+    view = big[1:].view(10, 8)
+    assert torch.equal(eng.rows_gather([view], [9, 0, 3])[0], view[[9, 0, 3]])
+    assert eng.rows_gather([view], [])[0].shape == (0, 8)
+    for bad in ([10], [-1]):
+        with pytest.raises(ValueError, match="outside"):        # HN_ERR_ARG
+            eng.rows_gather([view], bad)
+    with pytest.raises(ValueError):
+        eng.rows_scatter([view], [1, 2], [torch.zeros(3, 8, device=DEV)])
+
+
+def test_training_step_equals_the_reference_refill_loop_written_out(solver):
+    """Trainer.training_step decides its refill from a mask read behind the forward sweep on a side stream and writes the buffer back in a few batched
+    launches; hybridnet.py:431-463 is a Python loop over the samples with one device read each.  Both from the same seeds: the sampled slots, the
+    unrolled step, the kept / re-drawn decision, the fresh maps and the resulting buffer, iteration counters and weights are bit-identical."""
+    import random
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.training import Experience, Trainer
+    n, batch = 32, 6
+
+    def make():
+        torch.manual_seed(0)
+        s = IterativeSolver(domain_size=n, k=1.0, omega=1, PMLsize=8, sigma_max=2, source_location=[10, 16], activation_function="prelu",
+                            batch_size=batch, buffer_size=16, depth=4, features=8, learning_rate=1e-3, minimum_learning_rate=1e-4, weight_decay=1e-6,
+                            gradient_clip_val=1, max_iterations=100, source_amplitude=10, state_channels=2, state_depth=4, unrolling_steps=5)
+        s.to(DEV)
+        tr = Trainer(s)
+        tr.current_epoch = 1            # maxiter = 21: slots filled at iteration 10 c (c >= 2) and old advanced ones are re-drawn, young ones are kept
+        tr.fill_replay_buffer(torch.from_numpy(ring_sos_batch(n, 16, seed=3)))
+        return tr
+
+    def literal_step(tr, sos_batch):
+        hp = tr.solver.hparams
+        maxiter = min([tr.current_epoch * 20 + 1, hp.max_iterations])
+        wavefields, h_states, k_sqs, residual, sources, timesteps, indices = tr.replaybuffer.sample(hp.batch_size)
+        out = tr.loss_and_grad(wavefields, h_states, k_sqs, residual, sources)
+        tr.optimizer_step()
+        torch.cuda.synchronize()
+        iteration = np.random.choice(out["residuals"].shape[0])
+        counter = 0
+        for j in range(hp.batch_size):
+            new_timestep = timesteps[j] + iteration + 1
+            res = out["residuals"][iteration][j]
+            if res.pow(2).mean() < 1 and new_timestep < maxiter:
+                tr.replaybuffer.append(Experience(out["wavefields"][iteration][j], out["states"][iteration][j], k_sqs[j], res, sources[j], new_timestep), indices[j])
+            else:
+                tr.replaybuffer.append(tr._fresh_experience(random.choice(sos_batch).unsqueeze(0), 0), indices[j])
+                counter += 1
+        return counter
+
+    sos_batches = [torch.from_numpy(ring_sos_batch(n, batch, seed=20 + i)).to(DEV) for i in range(8)]
+    runs = {}
+    for kind in ("trainer", "literal"):
+        tr = make()
+        np.random.seed(5); random.seed(5)
+        fresh = []
+        for i, sb in enumerate(sos_batches):
+            fresh.append(tr.training_step(sb, i)["new_sos"] if kind == "trainer" else literal_step(tr, sb))
+        torch.cuda.synchronize()
+        runs[kind] = (fresh, tr.replaybuffer.iteration.copy(), {k: v.clone() for k, v in tr.replaybuffer.fields.items()}, tr.weights.clone())
+    a, b = runs["trainer"], runs["literal"]
+    print("fresh maps per step:", a[0], "iterations:", a[1].tolist())
+    assert a[0] == b[0] and 0 < sum(a[0]) < 8 * batch            # both branches of the decision were taken
+    assert np.array_equal(a[1], b[1])
+    for k in a[2]:
+        assert torch.equal(a[2][k], b[2][k]), k
+    assert torch.equal(a[3], b[3])
 
 
 def test_other_depth_and_fresh_weights(weights):
