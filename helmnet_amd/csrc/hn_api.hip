@@ -258,7 +258,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             ctx->opt_train_fused = value;
             break;
         case HN_OPT_TRAIN_OVERLAP:
-            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_OVERLAP must be 0 or 1 (got %d)", value);
+            if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_OVERLAP must be 0, 1 or 2 (got %d)", value);
             ctx->opt_train_overlap = value;
             break;
         case HN_OPT_DC_WINO:

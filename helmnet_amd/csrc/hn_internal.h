@@ -216,9 +216,10 @@ struct hn_ctx {
         int last_batch = 0;          // samples of the last hn_train_grad call in this workspace (hn_train_peek)
         int sumsq_batch = 0;         // samples per row of sumsq (lane 0 holds the whole batch's rows)
     } tr, tr_b;                      // tr_b: the second half of the batch when hn_train_grad runs as two lanes
-    int opt_train_overlap = 0;     // HN_OPT_TRAIN_OVERLAP: weight-gradient launches on a side stream beside the next iteration's backward chain.  Off:
-                                   // [measured, r4] 9.58 vs 9.61 ms at batch 32, 20.8 vs 21.3 at 128 -- the overlap is real (2.3 ms of kernel time per step run
-                                   // concurrently) but the chain's kernels slow down by as much (k_conv3<8> 16.5 -> 20.3 us, the batched conv_state 13 -> 60 us)
+    int opt_train_overlap = 2;     // HN_OPT_TRAIN_OVERLAP: weight-gradient launches on a side stream beside the next iteration's backward chain.  0: in line;
+                                   // 1: side stream, same launches ([measured, r4] no gain: 9.58 vs 9.61 ms at batch 32 -- the overlap is real, 2.3 ms of kernel time per
+                                   // step run concurrently, but the weight-gradient blocks hold the CUs' LDS and the chain's kernels slow down by as much); 2 (default):
+                                   // side stream AND the launches capped at ~2 blocks per CU where the chain is latency-bound (9.13 -> 8.77 ms; see hn_train_grad)
     int opt_train_fused = 7;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
                                    // bit 1 the backward-data pass of a big level's DoubleConv as one tiled launch (k_dc_bwd_tile), bit 2 the hidden-state
                                    // DoubleConvs of all levels as one launch per direction (k_dc_state_batch)

@@ -1206,6 +1206,7 @@ struct Trainer {
     bool small_level(int d) const { return side(d) <= kSmallS; }
     F3Layout F3;
     bool overlap = true;     // HN_OPT_TRAIN_OVERLAP 0 (A/B): the weight-gradient launches in line on the chain's stream (the r3 path)
+    int wg_cap = 0;          // > 0: at most this many blocks per weight-gradient launch (HN_OPT_TRAIN_OVERLAP 2, see hn_train_grad)
     bool tile_small = false; // HN_OPT_TRAIN_FUSED bit 3 (A/B): the small levels' backward DoubleConvs on the tiled kernel too instead of the per-sample k_dc_small
     bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
     bool fused_bwd = true;   // HN_OPT_TRAIN_FUSED bit 1 (A/B): the big levels' backward DoubleConvs as two k_conv3 launches (the r3 path)
@@ -1257,8 +1258,14 @@ struct Trainer {
         return HN_OK;
     }
     template <class J>
-    static int number_blocks(std::vector<J>& jobs) {
+    static int number_blocks(std::vector<J>& jobs, int cap = 0) {
         int total = 0;
+        for (J& j : jobs) total += j.nblk;
+        if (cap > 0 && total > cap) {   // fewer, longer-running blocks (a block walks more tiles): the launch leaves CU slots to a concurrent chain
+            const int t0 = total;
+            for (J& j : jobs) { const int nb = (int)((long)j.nblk * cap / t0); j.nblk = nb < 1 ? 1 : nb; }
+        }
+        total = 0;
         for (J& j : jobs) { j.blk0 = total; total += j.nblk; }
         return total;
     }
@@ -1268,7 +1275,7 @@ struct Trainer {
         auto& W = T();
         const size_t b8 = jobs8.size() * sizeof(Wg3Args), b2 = jobs2.size() * sizeof(Wg3Args), bk = jobsk.size() * sizeof(Wg8Args);
         if (b8 + b2 + bk > W.jobs_region) return fail(ctx, HN_ERR_STATE, "internal: weight-gradient job table overflow (%zu > %zu bytes)", b8 + b2 + bk, W.jobs_region);
-        const int n8 = number_blocks(jobs8), n2 = number_blocks(jobs2), nk = number_blocks(jobsk);
+        const int n8 = number_blocks(jobs8, wg_cap), n2 = number_blocks(jobs2, wg_cap / 4), nk = number_blocks(jobsk, wg_cap / 2);
         unsigned char* h = W.jobs_host + ((size_t)W.jobs_set * W.jobs_rows + t) * W.jobs_region;
         unsigned char* dv = W.jobs_dev + (size_t)t * W.jobs_region;
         if (b8) std::memcpy(h, jobs8.data(), b8);
@@ -1694,7 +1701,20 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
-    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.tile_small = (ctx->opt_train_fused & 8) != 0; t.overlap = ctx->opt_train_overlap != 0; }
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.tile_small = (ctx->opt_train_fused & 8) != 0; }
+    // Weight gradients beside the chain (HN_OPT_TRAIN_OVERLAP).  They are leaves of the backward pass, ~2 of the 9 ms of a step at 96^2 x 32, and the chain of
+    // data-gradient kernels they wait behind is latency-bound (VALU activity ~0.12) -- but launched as they are on a second stream they gain nothing [measured]:
+    // five of their 256-thread blocks hold 150 of a CU's 160 KB of LDS for ~100 us, so the chain's short kernels queue for workgroup slots behind them.  With the
+    // launch CAPPED at ~2 blocks per CU (each block walks more tiles: 2 x the time alone) the chain keeps half of every CU and the two overlap: 9.13 -> 8.77 ms.
+    // The window is narrow [measured, profiles/r4_train_wgcap.txt]: below ~200 k pixels per call the step is all launch floor (nothing to hide behind), above
+    // ~1 M the chain fills the chip by itself (a cap costs what it hides; the plain side stream is still -2 %).  Mode 1 keeps the launches' block counts (bit-identical
+    // to mode 0); mode 2 (default) applies the cap, i.e. another -- fixed -- order of the partial sums.
+    for (int l = 0; l < lanes; ++l) {
+        const long px = (long)lane_nb[l] * n * n;
+        const int mode = ctx->opt_train_overlap;
+        tr[l].overlap = mode == 1 || (mode == 2 && px >= 200000);
+        tr[l].wg_cap = mode == 2 && px >= 200000 && px < 1000000 ? (int)(px / 450 < 512 ? 512 : px / 450) : 0;
+    }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
     struct PrecisionGuard { hn_ctx* c; int saved; ~PrecisionGuard() { c->precision = saved; } } pg{ctx, ctx->precision};

@@ -94,10 +94,12 @@ enum hn_option {
                               * rounding), 2 (backward pass: both backward-data convolutions of a big level's DoubleConv as one tiled
                               * launch; bit-identical gradients) and 4 (the hidden-state DoubleConvs of all levels as one launch per
                               * direction instead of two; bit-identical); default 7, 0: every convolution as its own launch (round 3)  */
-    HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: 1: the three weight-gradient launches of unrolled iteration t run on a library
-                              * stream beside the backward chain of iteration t - 1 (two sets of gradient buffers); 0 (default): in line on
-                              * the caller's stream.  Bit-identical gradients (the launches keep their order).  Measured equal: the chain's
-                              * kernels slow down by what the overlap gains                                       */
+    HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: where the three weight-gradient launches of unrolled iteration t run.  0: in line on the
+                              * caller's stream.  1: on a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers), the
+                              * same launches: bit-identical gradients, and measured equal (their blocks hold the CUs' LDS; the chain slows down by what the
+                              * overlap gains).  2 (default): on the library stream AND, where the chain is latency-bound (200 k .. 1 M pixels per call), with at
+                              * most ~2 of their blocks per CU -- each walks more tiles, the chain keeps half of every CU: 9.13 -> 8.77 ms at 96^2 x 32.  The cap
+                              * changes how many partial sums a weight gradient is added up from: a fixed order (reproducible), not mode 0's  */
 };
 /* Diagnostics counters (hn_get_counter). */
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };

@@ -367,7 +367,8 @@ def test_fused_training_launches_keep_the_gradient_bits(solver, weights, g_train
     """HN_OPT_TRAIN_FUSED: bit 1 (a big level's backward DoubleConv as one tiled launch) and bit 2 (the hidden-state DoubleConvs as one
     launch per direction) do the same arithmetic per output in the same order as the launches they replace: loss, gradient and input
     gradients are BIT-identical.  Bit 0 (forward DoubleConvs on the fused matrix-core kernels) is another summation order: fp32 rounding.
-    HN_OPT_TRAIN_OVERLAP (weight gradients on a side stream) keeps the launches' order: bit-identical too."""
+    HN_OPT_TRAIN_OVERLAP 1 (weight gradients on a side stream) keeps the launches: bit-identical too.  Mode 2 (default) caps their block count where it
+    pays, i.e. adds each weight gradient up from fewer partial sums: reproducible, equal to mode 0 to fp32 rounding, per-sample results bit-identical."""
     n, b, k_sq, src, (wf0, res0, st0) = _fixture_inputs(g_train)
     solver.set_domain_size(n, source_location=[82, 48])
     eng = solver.engine()
@@ -375,24 +376,57 @@ def test_fused_training_launches_keep_the_gradient_bits(solver, weights, g_train
     args = [x.to(DEV).contiguous() for x in (wf0, res0, st0, k_sq, src)]
     outs = {}
     try:
-        for fused, overlap in ((7, 0), (3, 0), (1, 0), (0, 0), (7, 1)):
+        for fused, overlap in ((7, 0), (3, 0), (1, 0), (0, 0), (7, 1), (7, 2)):
             eng.set_option("train_fused", fused)
-            eng.set_option("train_overlap", overlap)
+            eng.set_option("train_overlap", int(overlap))
             o = eng.train_grad(blob, *args, 4, 1e4, input_grads=True)
             outs[(fused, overlap)] = tuple(o[k].clone() for k in ("loss", "grad", "grad_wf", "grad_res", "grad_states"))
     finally:
         eng.set_option("train_fused", 7)
-        eng.set_option("train_overlap", 0)
+        eng.set_option("train_overlap", 2)
     # (the LOSS is read off per-sample sums of squares that the spectral row kernel accumulates with float atomics: its last bit depends on
     # the order in which the workgroups of a sample arrive, so it is compared to rounding; nothing downstream reads it)
     for other in ((3, 0), (1, 0), (7, 1)):
         assert abs(float(outs[(7, 0)][0]) - float(outs[other][0])) <= 1e-6 * abs(float(outs[other][0]))
         for a, c in zip(outs[(7, 0)][1:], outs[other][1:]):
             assert torch.equal(a, c), other
+    # mode 2 at this size (2 samples: far below the window in which the cap applies) is mode 0
+    for a, c in zip(outs[(7, 2)][1:], outs[(7, 0)][1:]):
+        assert torch.equal(a, c)
     # the fused forward: fp32 rounding at most.  (At this size it is in fact bit-identical as well: the f32 matrix instruction is an exact fmaf
     # chain and k_dc_mfma_p walks (channel, row, tap) in k_conv3's order with the bias added last; the strip kernel of W >= 128 starts from the bias.)
     for a, c in zip(outs[(1, 0)], outs[(0, 0)]):
         assert float((a - c).abs().max()) <= 2e-5 * float(c.abs().max())
+
+
+def test_capped_weight_gradient_launches_beside_the_chain(solver, weights):
+    """HN_OPT_TRAIN_OVERLAP 2 at the reference's training shape (96^2 x 32 = 295 k pixels, inside the window): the weight-gradient launches run on the
+    library's side stream with ~2 blocks per CU.  Everything per sample (histories, input gradients) is bit-identical to the in-line mode; the weight
+    gradient is the same partial sums added up in another FIXED order: reproducible run to run, equal to mode 0 to fp32 rounding."""
+    n, b = 96, 32
+    solver.set_domain_size(n, source_location=[82, 48])
+    eng = solver.engine()
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=12)).to(DEV)
+    out = solver.forward(sos, num_iterations=4, return_wavefields=True, return_states=True)
+    args = [out["wavefields"][-1].contiguous(), out["residuals"][-1].contiguous(), out["states"][-1].contiguous(),
+            ((1.0 / sos) ** 2).contiguous(), solver.source.detach().repeat(b, 1, 1, 1).contiguous()]
+    blob = torch.from_numpy(pack_weights(weights)).to(DEV)
+    res = {}
+    try:
+        for mode in (0, 1, 2, 2.5):
+            eng.set_option("train_overlap", int(mode))
+            o = eng.train_grad(blob, *args, 3, 1e4, input_grads=True)
+            res[mode] = {k: o[k].clone() for k in ("grad", "grad_wf", "grad_res", "grad_states", "residuals", "states")}
+    finally:
+        eng.set_option("train_overlap", 2)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), k                      # side stream, same launches
+        assert torch.equal(res[2][k], res[2.5][k]), k                    # reproducible
+        if k != "grad":
+            assert torch.equal(res[2][k], res[0][k]), k
+    err = float((res[2]["grad"] - res[0]["grad"]).abs().max()) / float(res[0]["grad"].abs().max())
+    print("capped weight-gradient launches vs in-line: Linf / max", err, "bit-identical:", bool(torch.equal(res[2]["grad"], res[0]["grad"])))
+    assert err <= 2e-6
 
 
 def test_gradients_are_bit_reproducible_and_batch_independent(solver, weights, g_train):
@@ -502,12 +536,13 @@ def test_forward_event_fires_behind_the_forward_sweep(solver, weights):
     assert torch.isfinite(again["grad"]).all()
 
 
-def test_training_step_can_be_captured_in_a_hip_graph(solver, weights):
+@pytest.mark.parametrize("n,b", [(64, 4), (96, 32)])
+def test_training_step_can_be_captured_in_a_hip_graph(solver, weights, n, b):
     """hn_train_grad only enqueues work on the caller's stream (under capture it skips its host-side event bookkeeping), so a step can be
     recorded with torch.cuda.graph and replayed: the replay's gradient is bit-identical to the eager call's.  (Replay is NOT faster --
-    the cost of a small dependent launch is on the GPU side: tools/graph_train_ab.py)"""
-    n, b = 64, 4
-    solver.set_domain_size(n, source_location=[50, 32])
+    the cost of a small dependent launch is on the GPU side: tools/graph_train_ab.py)  96^2 x 32 is inside the window in which the
+    weight-gradient launches fork onto the library's side stream (HN_OPT_TRAIN_OVERLAP 2): the fork and the join are captured with the step."""
+    solver.set_domain_size(n, source_location=[n - 14, n // 2])
     eng = solver.engine()
     sos = torch.from_numpy(ring_sos_batch(n, b, seed=8)).to(DEV)
     out = solver.forward(sos, num_iterations=3, return_wavefields=True, return_states=True)
