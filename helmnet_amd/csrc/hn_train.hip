@@ -1479,7 +1479,16 @@ struct Trainer {
             if ((rc = dc_bwd(L.inc, slot_inc(), in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0)) != HN_OK) return rc;
         }
         cur_st = (cur_st + 1) % 3;
-        if (overlap) {   // the filed weight-gradient jobs: three launches on the side stream, beside the backward chain of iteration t - 1
+        if (overlap && t == 0 && wg_cap > 0) {
+            // the last launches have no chain left to hide behind: in line and at full width, behind the side stream's (they add to the same table rows)
+            for (int k = 0; k < 2; ++k)
+                if (W.wg_pending[k]) { HN_HIP(ctx, hipStreamWaitEvent(s, W.wg_done[k], 0)); W.wg_pending[k] = false; }
+            const int cap = wg_cap;
+            wg_cap = 0;
+            rc = flush_wgrads(t, s);
+            wg_cap = cap;
+            if (rc != HN_OK) return rc;
+        } else if (overlap) {   // the filed weight-gradient jobs: three launches on the side stream, beside the backward chain of iteration t - 1
             HN_HIP(ctx, hipEventRecord(W.wg_ready[par], s));
             HN_HIP(ctx, hipStreamWaitEvent(W.wg_stream, W.wg_ready[par], 0));
             if ((rc = flush_wgrads(t, W.wg_stream)) != HN_OK) return rc;

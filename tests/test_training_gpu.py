@@ -563,11 +563,12 @@ def test_training_step_can_be_captured_in_a_hip_graph(solver, weights, n, b):
             captured["loss"].zero_()
             graph.replay()
             torch.cuda.synchronize()
-            assert torch.equal(g, want) and torch.equal(captured["loss"], want_loss)
+            # (the loss is read off sums the spectral kernel accumulates with float atomics: its last bit is not reproducible once a sample has several workgroups)
+            assert torch.equal(g, want) and abs(float(captured["loss"]) - float(want_loss)) <= 1e-6 * float(want_loss)
     # and the eager path still works afterwards
     again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
     torch.cuda.synchronize()
-    assert torch.equal(g, want) and torch.equal(again["loss"], want_loss)
+    assert torch.equal(g, want) and abs(float(again["loss"]) - float(want_loss)) <= 1e-6 * float(want_loss)
 
 
 def test_adam_three_steps_match_the_reference_optimiser(solver, weights, g_train):
