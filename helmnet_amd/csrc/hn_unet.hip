@@ -466,6 +466,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         HN_HIP(ctx, hipEventRecord(ev, s));
         HN_HIP(ctx, hipStreamWaitEvent(side, ev, 0));
         for (int e = d0; e < d1; ++e) {
+#ifdef HN_EXP_SKIP_STATE   // timing experiment only (tools/r4_skip_state.sh): environment bit e skips conv_state_e -- the results are WRONG
+            static const int exp_skip = getenv("HN_EXP_SKIP_STATE") ? std::atoi(getenv("HN_EXP_SKIP_STATE")) : 0;
+            if (exp_skip >> e & 1) continue;
+#endif
             const int me = n >> e;
             const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
             const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
