@@ -72,6 +72,19 @@ __device__ __forceinline__ float act_general(float x, int act) {
         default: return x;
     }
 }
+// d act(x) / dx (the backward kernels); GEN = false: the piecewise-linear kinds (torch: the slope applies at x == 0)
+template <bool GEN>
+__device__ __forceinline__ float act_grad(float x, int kind, float slope) {
+    if (!GEN) return x > 0.f ? 1.f : slope;
+    switch (kind) {
+        case HN_ACT_CELU: return x > 0.f ? 1.f : expf(x);
+        case HN_ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
+        case HN_ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
+        case HN_ACT_TANHSHRINK: { const float t = tanhf(x); return t * t; }
+        case HN_ACT_SOFTPLUS: return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
+        default: return x > 0.f ? 1.f : slope;   // prelu / relu / leakyrelu
+    }
+}
 // 8x8 stride-2 conv / transposed conv weights re-packed [cin][8][8][cout], bias [cout].
 struct K8W {
     const float* w;
@@ -220,7 +233,7 @@ struct hn_ctx {
                                    // 1: side stream, same launches ([measured, r4] no gain: 9.58 vs 9.61 ms at batch 32 -- the overlap is real, 2.3 ms of kernel time per
                                    // step run concurrently, but the weight-gradient blocks hold the CUs' LDS and the chain's kernels slow down by as much); 2 (default):
                                    // side stream AND the launches capped at ~2 blocks per CU where the chain is latency-bound (9.13 -> 8.77 ms; see hn_train_grad)
-    int opt_train_fused = 7;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
+    int opt_train_fused = 23;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
                                    // bit 1 the backward-data pass of a big level's DoubleConv as one tiled launch (k_dc_bwd_tile), bit 2 the hidden-state
                                    // DoubleConvs of all levels as one launch per direction (k_dc_state_batch)
     hipEvent_t train_fwd_event = nullptr;   // caller-owned: recorded behind the forward sweep of hn_train_grad (hn_train_set_forward_event)
@@ -326,6 +339,22 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
                bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
 // training forward: the fused matrix-core DoubleConv with the pre-activation mid tensor stored to `z` ([B, 8, H, W]); fragments as pack_frag_3x3
 bool dc8_tape_applies(int H, int W);
+// Backward-data pass of an 8-channel DoubleConv (cin -> 8 -> 8) on the fp32 matrix core (hn_mfma.hip, k_dc_bwd_mfma_p): g_z = conv2^T(g) * act'(z),
+// g_in = conv1^T(g_z), one launch, the g_z tile (with its halo) in LDS.  Channel groups of g_in as in the forward concatenation.
+struct McBwdDst { float* p; long sb, sc; int nch; float scale; int accum; };   // p == nullptr: the group is discarded
+struct McBwd {
+    const float* g; long g_sb, g_sc;       // d loss / d output, 8 channels
+    const float* a1;                       // conv2^T as A fragments [8 c2][3][64]
+    const float* a2;                       // conv1^T as A fragments [passes][8 cm][3][64], pass p = input channels 8p .. 8p + 7 of the forward conv1
+    const float* z; long z_sb, z_sc;       // the tape's pre-activation mid tensor, 8 channels
+    float* gz; long gz_sb, gz_sc;          // g_z (8 channels): the weight-gradient kernels read it
+    const float* slope; int act;
+    double* slope_part;                    // PReLU: row [tile] += sum over the tile of conv2^T(g) * min(z, 0); nullptr otherwise
+    McBwdDst dst[3];
+};
+bool dc8_bwd_applies(int H, int W);
+int dc8_bwd_tiles(int H, int W, int batch);   // rows of slope_part a launch adds to
+int launch_dc8_bwd(hn_ctx* ctx, const McBwd& a, int cin, int H, int W, int batch, hipStream_t s);
 int launch_dc8_tape(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const float* frag1, const float* b1, const float* slope, const float* frag2,
                     const float* b2, int act, float* z, int H, int W, int batch, hipStream_t s);
 void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);

@@ -1387,6 +1387,239 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
 
 
 // ------------------------------------------------------------------------------------------
+// Backward-data pass of a DoubleConv on the same tiles (training step, hn_train.hip): the structure of k_dc_mfma_p with
+//   conv "1" = conv2^T : g (8 channels, halo 2) -> conv2^T(g) on the tile with halo 1; times act'(z) (z: the tape's pre-activation
+//              mid tensor, read from global memory behind the staging loads) = g_z -> LDS and, for the tile's own positions, global
+//              memory (the weight-gradient kernels read it); the PReLU slope's gradient sum(conv2^T(g) * min(z, 0)) as one float64 per tile
+//   conv "2" = conv1^T : g_z -> the gradient of the forward input, 8 channels per pass (NPASS = ceil(cin / 8)), written / accumulated
+//              into up to three channel groups with their scales (the forward concatenation)
+// Fragments: hn_train.hip packs the flipped, transposed weights in the layout of pack_frag_3x3.  [measured, r4] the vector-pipe
+// kernels this replaces (k_dc_bwd_tile, k_dc_small) took 27 - 33 us per launch at 96^2 x 32 where the forward launches of the same
+// shape take 7 - 17.
+// ------------------------------------------------------------------------------------------
+template <int NPASS, int TH_, int TW_, bool GEN>
+__global__ __launch_bounds__(256) void k_dc_bwd_mfma_p(McBwd a, int H, int W, int tiles_x, int tiles_y, int ntiles) {
+    using C = PcCfg<kFeat, 0, 0, TH_, TW_>;
+    constexpr int AF2 = C::AF_OFF + kFeat * 3 * 64;                                 // conv "2" fragments: NPASS x [8][3][64]
+    constexpr int LDS_FLOATS = AF2 + (NPASS * kFeat * 3 + 6) * 64 + 8;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ double s_red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);   // XCD-aware order (hn_internal.h)
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    // ---- every global load of the block is issued before the first LDS store: fragments, the g tile, z at this lane's mid slots ----
+    constexpr int N1 = kFeat * 3 * 16, N2 = NPASS * kFeat * 3 * 16;   // float4 counts
+    constexpr int L1 = cdiv_(N1, 256), L2 = cdiv_(N2, 256);
+    float4 f1[L1], f2[L2];
+#pragma unroll
+    for (int i = 0; i < L1; ++i) { const int j = tid + i * 256; f1[i] = reinterpret_cast<const float4*>(a.a1)[j < N1 ? j : 0]; }
+#pragma unroll
+    for (int i = 0; i < L2; ++i) { const int j = tid + i * 256; f2[i] = reinterpret_cast<const float4*>(a.a2)[j < N2 ? j : 0]; }
+    float2 stage[kFeat][C::NL];
+    unsigned okmask = 0;
+    int lrow[C::NL], lcol[C::NL];
+    {
+        int goff[C::NL];
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            const int e = tid + i * 256;
+            lrow[i] = e / (C::PI / 2);
+            lcol[i] = 2 * (e - lrow[i] * (C::PI / 2));
+            const int y = y0 - 2 + lrow[i], x = x0 - 2 + lcol[i];
+            const bool ok = (e < C::NP2) && y >= 0 && y < H && x >= 0 && x < W;  // W even: pairs never straddle
+            goff[i] = ok ? y * W + x : 0;
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int c = 0; c < kFeat; ++c) {
+            const float* p0 = a.g + (long)b * a.g_sb + (long)c * a.g_sc;
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i) stage[c][i] = *reinterpret_cast<const float2*>(p0 + goff[i]);
+        }
+    }
+    int boff1[C::GW1], boff2[C::GW2];
+    float zz[C::GW1][4];
+    unsigned min0 = 0, min1 = 0, mown0 = 0, mown1 = 0;   // per conv-"1" group: pixel x / x + 1 inside the image; ... and one of the tile's own positions
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) {
+        int s = 16 * (wave + 4 * gi) + n;
+        const bool slot = s < C::NS1;
+        s = slot ? s : C::NS1 - 1;
+        const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+        boff1[gi] = mrow * C::PI + 2 * pc + q;
+        const int y = y0 - 1 + mrow, x = x0 - 1 + 2 * pc;
+        const bool yin = slot && y >= 0 && y < H;
+        const bool in0 = yin && x >= 0 && x < W, in1 = yin && x + 1 >= 0 && x + 1 < W;
+        const bool own = mrow >= 1 && mrow <= C::TH;
+        min0 |= (in0 ? 1u : 0u) << gi; min1 |= (in1 ? 1u : 0u) << gi;
+        mown0 |= (in0 && own && pc >= 1 ? 1u : 0u) << gi; mown1 |= (in1 && own && 2 * pc + 1 <= C::TW ? 1u : 0u) << gi;
+        const float* zp = a.z + (long)b * a.z_sb + (long)(2 * q) * a.z_sc;
+        const long o0 = in0 ? (long)y * W + x : 0, o1 = in1 ? (long)y * W + x + 1 : 0;
+        zz[gi][0] = zp[o0]; zz[gi][1] = zp[o1]; zz[gi][2] = zp[a.z_sc + o0]; zz[gi][3] = zp[a.z_sc + o1];
+    }
+#pragma unroll
+    for (int gi = 0; gi < C::GW2; ++gi) {
+        const int s = 16 * (wave + 4 * gi) + n;
+        const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+        boff2[gi] = C::MID_OFF + orow * C::PM + 2 * pc + q;
+    }
+    const float slope = a.slope != nullptr ? a.slope[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < L1; ++i) { const int j = tid + i * 256; if (j < N1) *reinterpret_cast<float4*>(&lds[C::AF_OFF + 4 * j]) = f1[i]; }
+#pragma unroll
+    for (int i = 0; i < L2; ++i) { const int j = tid + i * 256; if (j < N2) *reinterpret_cast<float4*>(&lds[AF2 + 4 * j]) = f2[i]; }
+#pragma unroll
+    for (int c = 0; c < kFeat; ++c)
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i)
+            if (tid + i * 256 < C::NP2)
+                *reinterpret_cast<float2*>(&lds[c * C::PLANE + lrow[i] * C::PI + lcol[i]]) = (okmask >> i & 1u) ? stage[c][i] : make_float2(0.f, 0.f);
+    __syncthreads();   // (1)
+
+    // ---- conv "1": 8 x 3 steps, LDS reads of step k + 1 behind the MFMAs of step k ----
+    f32x4 acc1[C::GW1];
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) acc1[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        float bv[2][C::GW1], af[6], afn[6];
+#pragma unroll
+        for (int gi = 0; gi < C::GW1; ++gi) bv[0][gi] = lds[boff1[gi]];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) af[j] = lds[C::AF_OFF + j * 64 + lane];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int c2 = 0; c2 < kFeat / 2; ++c2) {
+            const float* tc = lds + 2 * c2 * C::PLANE;
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                const int nx = st + 1, nxt = (nx / 3) * C::PLANE + (nx % 3) * C::PI;   // past the last channel: the mid region (value unused)
+#pragma unroll
+                for (int gi = 0; gi < C::GW1; ++gi) bv[(st + 1) & 1][gi] = tc[boff1[gi] + nxt];
+                afn[st] = lds[C::AF_OFF + ((c2 + 1) * 6 + st) * 64 + lane];           // past the end: the conv "2" fragments (unused)
+#pragma unroll
+                for (int gi = 0; gi < C::GW1; ++gi) acc1[gi] = mfma4(af[st], bv[st & 1][gi], acc1[gi]);
+                interleave_mfma_dsread<C::GW1>();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; ++j) af[j] = afn[j];
+        }
+    }
+    // ---- g_z = conv2^T(g) * act'(z): LDS (zero outside the image), global memory (own positions), slope sum (own positions) ----
+    double sp = 0.0;
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) {
+        const int s = 16 * (wave + 4 * gi) + n;
+        if (s < C::NS1) {
+            const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+            const int y = y0 - 1 + mrow, x = x0 - 1 + 2 * pc;
+            const bool in0 = min0 >> gi & 1u, in1 = min1 >> gi & 1u, own0 = mown0 >> gi & 1u, own1 = mown1 >> gi & 1u;
+            float v[4] = {acc1[gi][0], acc1[gi][1], acc1[gi][2], acc1[gi][3]};
+            if (a.slope_part != nullptr) {
+                if (own0 && zz[gi][0] <= 0.f) sp += (double)v[0] * (double)zz[gi][0];
+                if (own1 && zz[gi][1] <= 0.f) sp += (double)v[1] * (double)zz[gi][1];
+                if (own0 && zz[gi][2] <= 0.f) sp += (double)v[2] * (double)zz[gi][2];
+                if (own1 && zz[gi][3] <= 0.f) sp += (double)v[3] * (double)zz[gi][3];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= act_grad<GEN>(zz[gi][r], a.act, slope);
+            float* gp = a.gz + (long)b * a.gz_sb + (long)(2 * q) * a.gz_sc + (long)y * W + x;
+            if (own0) { gp[0] = v[0]; gp[a.gz_sc] = v[2]; }
+            if (own1) { gp[1] = v[1]; gp[a.gz_sc + 1] = v[3]; }
+            float* m0 = lds + C::MID_OFF + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
+            *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
+            *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
+        }
+    }
+    if (a.slope_part != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sp += __shfl_down(sp, o, 64);
+        if (lane == 0) s_red[wave] = sp;
+    }
+    __syncthreads();   // (2) g_z complete
+    if (a.slope_part != nullptr && tid == 0) a.slope_part[tile] += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+
+    // ---- conv "2", 8 forward-input channels per pass ----
+    const float *dp0 = a.dst[0].p, *dp1 = a.dst[1].p, *dp2 = a.dst[2].p;
+    const long dsb0 = a.dst[0].sb, dsb1 = a.dst[1].sb, dsb2 = a.dst[2].sb, dsc0 = a.dst[0].sc, dsc1 = a.dst[1].sc, dsc2 = a.dst[2].sc;
+    const float df0 = a.dst[0].scale, df1 = a.dst[1].scale, df2 = a.dst[2].scale;
+    const int da0 = a.dst[0].accum, da1 = a.dst[1].accum, da2 = a.dst[2].accum;
+    const int dn0 = a.dst[0].nch, dn01 = dn0 + a.dst[1].nch, dnall = dn01 + a.dst[2].nch;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+        // this lane's two channels (2q, 2q + 1 of the pass; groups start at even channels, so both belong to one group)
+        const int c0 = 8 * pass + 2 * q;
+        const bool g1 = c0 >= dn0, g2 = c0 >= dn01;
+        float* dp = const_cast<float*>(g2 ? dp2 : g1 ? dp1 : dp0);
+        if (c0 >= dnall) dp = nullptr;
+        const int cd = g2 ? c0 - dn01 : g1 ? c0 - dn0 : c0;
+        const long dsb = g2 ? dsb2 : g1 ? dsb1 : dsb0, dsc = g2 ? dsc2 : g1 ? dsc1 : dsc0;
+        const float df = g2 ? df2 : g1 ? df1 : df0;
+        const bool acc_on = (g2 ? da2 : g1 ? da1 : da0) != 0;
+        float* const base = dp != nullptr ? dp + (long)b * dsb + (long)cd * dsc : nullptr;
+        float2 old[C::GW2][2];
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) {   // the old values of an accumulated destination arrive behind the MFMAs
+            old[gi][0] = old[gi][1] = make_float2(0.f, 0.f);
+            const int s = 16 * (wave + 4 * gi) + n;
+            const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+            const int y = y0 + orow, x = x0 + 2 * pc;
+            if (base != nullptr && acc_on && y < H && x < W) {
+                old[gi][0] = *reinterpret_cast<const float2*>(base + (long)y * W + x);
+                old[gi][1] = *reinterpret_cast<const float2*>(base + dsc + (long)y * W + x);
+            }
+        }
+        f32x4 acc2[C::GW2];
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        {
+            const int afb = AF2 + pass * kFeat * 3 * 64;
+            float bv[2][C::GW2], af[6], afn[6];
+#pragma unroll
+            for (int gi = 0; gi < C::GW2; ++gi) bv[0][gi] = lds[boff2[gi]];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) af[j] = lds[afb + j * 64 + lane];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+            for (int c2 = 0; c2 < kFeat / 2; ++c2) {
+                const float* tc = lds + 2 * c2 * C::MPLANE;
+#pragma unroll
+                for (int st = 0; st < 6; ++st) {
+                    const int nx = st + 1, nxt = (nx / 3) * C::MPLANE + (nx % 3) * C::PM;   // past the end: fragment region (unused)
+#pragma unroll
+                    for (int gi = 0; gi < C::GW2; ++gi) bv[(st + 1) & 1][gi] = tc[boff2[gi] + nxt];
+                    afn[st] = lds[afb + ((c2 + 1) * 6 + st) * 64 + lane];
+#pragma unroll
+                    for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = mfma4(af[st], bv[st & 1][gi], acc2[gi]);
+                    interleave_mfma_dsread<C::GW2>();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) af[j] = afn[j];
+            }
+        }
+        if (base != nullptr) {
+#pragma unroll
+            for (int gi = 0; gi < C::GW2; ++gi) {
+                const int s = 16 * (wave + 4 * gi) + n;
+                const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+                const int y = y0 + orow, x = x0 + 2 * pc;
+                if (y < H && x < W) {
+                    float* p = base + (long)y * W + x;
+                    *reinterpret_cast<float2*>(p) = make_float2(__fmul_rn(acc2[gi][0], df) + old[gi][0].x, __fmul_rn(acc2[gi][1], df) + old[gi][0].y);
+                    *reinterpret_cast<float2*>(p + dsc) = make_float2(__fmul_rn(acc2[gi][2], df) + old[gi][1].x, __fmul_rn(acc2[gi][3], df) + old[gi][1].y);
+                }
+            }
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // 8x8 stride-2 down convolution (architectures.py:209-211)
 //   P_h[Yw][X] = sum_ci sum_kx sum_{k<4} w[co][ci][4h + k][kx] * in[ci][2 Yw - 3 + k][2 X - 3 + kx]
 //   out[Y][X]  = b + P_0[Y][X] + P_1[Y + 2][X]
@@ -2146,6 +2379,33 @@ int launch_dc8_tape(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const f
         case 3: launch_dc_mfma<kFeat, kFeat, 0, 0>(0, a, b, c, out, mw, e, H, W, batch, s); break;
         default: return fail(ctx, HN_ERR_ARG, "internal: bad DoubleConv kind %d", kind);
     }
+    return HN_OK;
+}
+
+bool dc8_bwd_applies(int H, int W) { return (W & 1) == 0 && H > 0; }
+static inline void dc8_bwd_shape(int H, int W, int& tw, int& tx, int& ty) { tw = W > 16 ? 32 : 16; tx = cdiv_(W, tw); ty = cdiv_(H, 8); }
+int dc8_bwd_tiles(int H, int W, int batch) { int tw, tx, ty; dc8_bwd_shape(H, W, tw, tx, ty); return tx * ty * batch; }
+template <int NPASS>
+static void launch_dc8_bwd_n(const McBwd& a, int H, int W, int batch, hipStream_t s) {
+    int tw, tx, ty;
+    dc8_bwd_shape(H, W, tw, tx, ty);
+    const int nt = tx * ty * batch;
+    const bool gen = a.act > HN_ACT_LEAKYRELU;
+    if (tw == 32) {
+        if (gen) hipLaunchKernelGGL((k_dc_bwd_mfma_p<NPASS, 8, 32, true>), dim3(nt), dim3(256), 0, s, a, H, W, tx, ty, nt);
+        else hipLaunchKernelGGL((k_dc_bwd_mfma_p<NPASS, 8, 32, false>), dim3(nt), dim3(256), 0, s, a, H, W, tx, ty, nt);
+    } else {
+        if (gen) hipLaunchKernelGGL((k_dc_bwd_mfma_p<NPASS, 8, 16, true>), dim3(nt), dim3(256), 0, s, a, H, W, tx, ty, nt);
+        else hipLaunchKernelGGL((k_dc_bwd_mfma_p<NPASS, 8, 16, false>), dim3(nt), dim3(256), 0, s, a, H, W, tx, ty, nt);
+    }
+}
+int launch_dc8_bwd(hn_ctx* ctx, const McBwd& a, int cin, int H, int W, int batch, hipStream_t s) {
+    if (!dc8_bwd_applies(H, W) || cin < 1 || cin > 2 * kFeat) return fail(ctx, HN_ERR_ARG, "internal: no matrix-core backward DoubleConv for %d x %d, %d channels", H, W, cin);
+    for (const McBwdDst& d : a.dst)
+        if (d.nch & 1) return fail(ctx, HN_ERR_ARG, "internal: odd channel group in the matrix-core backward DoubleConv");
+    if (cin <= kFeat) launch_dc8_bwd_n<1>(a, H, W, batch, s);
+    else launch_dc8_bwd_n<2>(a, H, W, batch, s);
+    HN_HIP(ctx, hipGetLastError());
     return HN_OK;
 }
 

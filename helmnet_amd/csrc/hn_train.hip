@@ -88,18 +88,6 @@ __device__ __forceinline__ float act_fwd(float x, int kind, float slope) {
     if (!GEN || kind <= HN_ACT_LEAKYRELU) return x > 0.f ? x : slope * x;
     return act_general(x, kind);
 }
-template <bool GEN>
-__device__ __forceinline__ float act_grad(float x, int kind, float slope) {
-    if (!GEN) return x > 0.f ? 1.f : slope;
-    switch (kind) {
-        case HN_ACT_CELU: return x > 0.f ? 1.f : expf(x);
-        case HN_ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
-        case HN_ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * expf(-0.5f * x * x);
-        case HN_ACT_TANHSHRINK: { const float t = tanhf(x); return t * t; }
-        case HN_ACT_SOFTPLUS: return x > 20.f ? 1.f : 1.f / (1.f + expf(-x));
-        default: return x > 0.f ? 1.f : slope;   // prelu / relu / leakyrelu (torch: the slope applies at x == 0)
-    }
-}
 
 // A channel group of an implicit concatenation: element (b, c, y, x) at p[b*sb + c*sc + y*W + x]
 struct TSrc { const float* p; long sb, sc; int nch; float scale; int act; };   // act: the activation is applied while staging (p holds pre-activations)
@@ -1012,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_pack3(const float* __restrict__ raw, fl
 }
 // 3x3 weights of the 8-channel DoubleConvs as A-operand fragments of the fp32 matrix-core kernels (hn_mfma.hip, pack_frag_3x3):
 // raw [8][cin][3][3] -> [cin][3][64], lane l -> (co = (l & 15) >> 1, dxo = l & 1, t = l >> 4): raw[co][ci][dy][t - dxo] where that tap exists.
-struct F3Layout { size_t inc[2], sig[kMaxDepth][2], dec[kMaxDepth + 1][2], total; };
+struct F3Layout { size_t inc[2], sig[kMaxDepth][2], dec[kMaxDepth + 1][2], incb[2], sigb[kMaxDepth][2], decb[kMaxDepth + 1][2], total; };
 F3Layout f3_layout(int depth) {
     F3Layout F{};
     size_t pos = 0;
@@ -1020,17 +1008,34 @@ F3Layout f3_layout(int depth) {
     take(F.inc, kInCh);
     for (int d = 0; d < depth; ++d) take(F.sig[d], kFeat + kState);
     for (int d = 0; d <= depth; ++d) take(F.dec[d], d < depth ? 2 * kFeat : kFeat);
+    // backward-data fragments (k_dc_bwd_mfma_p): [0] conv2^T, 8 fragment channels; [1] conv1^T, ceil(cin / 8) passes of 8
+    auto takeb = [&](size_t (&o)[2], int cin) { o[0] = pos; pos += (size_t)kFeat * 192; o[1] = pos; pos += (size_t)cdiv(cin, kFeat) * kFeat * 192; };
+    takeb(F.incb, kInCh);
+    for (int d = 0; d < depth; ++d) takeb(F.sigb[d], kFeat + kState);
+    for (int d = 0; d <= depth; ++d) takeb(F.decb[d], d < depth ? 2 * kFeat : kFeat);
     F.total = pos;
     return F;
 }
-struct PackF3Jobs { int n; int raw[2 * (2 * kMaxDepth + 2)], dst[2 * (2 * kMaxDepth + 2)]; short cin[2 * (2 * kMaxDepth + 2)]; };
+// mode 0: the forward convolution raw [8][cin][3][3] -> [cin][3][64].  mode 1: the transposed convolution of raw [8 co][8 cm][3][3] (conv2) -- fragment
+// channel = co, output = cm, taps flipped.  mode 2: the transposed convolution of raw [8 cm][cin][3][3] (conv1) -- fragment channel = cm, output = forward
+// input channel 8 pass + .. (zero beyond cin), taps flipped, `rows` = passes * 8 fragment channels.
+struct PackF3Jobs { int n; int raw[4 * (2 * kMaxDepth + 2)], dst[4 * (2 * kMaxDepth + 2)]; short cin[4 * (2 * kMaxDepth + 2)], rows[4 * (2 * kMaxDepth + 2)], mode[4 * (2 * kMaxDepth + 2)]; };
 __global__ __launch_bounds__(256) void k_pack_frag3(const float* __restrict__ blob, float* __restrict__ f3, PackF3Jobs jobs) {
-    const int j = blockIdx.y, cin = jobs.cin[j];
+    const int j = blockIdx.y, cin = jobs.cin[j], rows = jobs.rows[j], mode = jobs.mode[j];
     const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= cin * 192) return;
+    if (e >= rows * 192) return;
     const int l = e & 63, dy = (e >> 6) % 3, ci = e / 192;
     const int co = (l & 15) >> 1, dx = (l >> 4) - (l & 1);
-    f3[jobs.dst[j] + e] = (dx >= 0 && dx <= 2) ? blob[jobs.raw[j] + ((co * cin + ci) * 3 + dy) * 3 + dx] : 0.f;
+    float v = 0.f;
+    if (dx >= 0 && dx <= 2) {
+        if (mode == 0) v = blob[jobs.raw[j] + ((co * cin + ci) * 3 + dy) * 3 + dx];
+        else if (mode == 1) v = blob[jobs.raw[j] + ((ci * kFeat + co) * 3 + (2 - dy)) * 3 + (2 - dx)];
+        else {
+            const int pass = ci / kFeat, cm = ci - pass * kFeat, fi = pass * kFeat + co;
+            if (fi < cin) v = blob[jobs.raw[j] + ((cm * cin + fi) * 3 + (2 - dy)) * 3 + (2 - dx)];
+        }
+    }
+    f3[jobs.dst[j] + e] = v;
 }
 __global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ grad, float* __restrict__ m, float* __restrict__ v,
                                               const unsigned char* __restrict__ trainable, size_t n, float step_size, float inv_sqrt_bc2, float b1,
@@ -1209,6 +1214,7 @@ struct Trainer {
     int wg_cap = 0;          // > 0: at most this many blocks per weight-gradient launch (HN_OPT_TRAIN_OVERLAP 2, see hn_train_grad)
     bool tile_small = false; // HN_OPT_TRAIN_FUSED bit 3 (A/B): the small levels' backward DoubleConvs on the tiled kernel too instead of the per-sample k_dc_small
     bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
+    bool mfma_bwd = true;    // HN_OPT_TRAIN_FUSED bit 4: the backward-data pass of the 8-channel DoubleConvs on the fp32 matrix core (k_dc_bwd_mfma_p) instead of the vector-pipe kernels
     bool fused_bwd = true;   // HN_OPT_TRAIN_FUSED bit 1 (A/B): the big levels' backward DoubleConvs as two k_conv3 launches (the r3 path)
     bool fused_fwd = true;   // HN_OPT_TRAIN_FUSED 0 (A/B): every convolution of the forward pass as its own direct launch (the r3 path)
     int dc_fwd(const RawDc& dc, const TSrc (&in)[3], float* z, TDst out, int d, const size_t (*f3)[2] = nullptr) {
@@ -1323,9 +1329,23 @@ struct Trainer {
         return wgrad3(in, feat(T().gz[slot], d, dc.cm), dc.cm, dc.w1, d, dc.slope);          // dW1, db1 from (in, g_z)
     }
     // DoubleConv backward: g_out (co channels) -> weight gradients, gradients of the inputs into `gin` (channel groups of the concatenation)
-    int dc_bwd(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d) {
+    int dc_bwd(const RawDc& dc, int slot, const TSrc (&in)[3], const float* z, TSrc g_out, const TDst (&gin)[3], int d, const size_t (*fb)[2] = nullptr) {
         int rc;
         if ((rc = dc_wgrads(dc, slot, in, z, g_out, d)) != HN_OK) return rc;
+        if (mfma_bwd && fb != nullptr && dc.cm == kFeat && dc.co == kFeat && g_out.act == 0 && g_out.scale == 1.f && dc8_bwd_applies(side(d), side(d)) &&
+            dc8_bwd_tiles(side(d), side(d), B) <= (int)T().slope_stride) {
+            McBwd a{};
+            a.g = g_out.p; a.g_sb = g_out.sb; a.g_sc = g_out.sc;
+            a.a1 = ctx->tr.f3 + (*fb)[0]; a.a2 = ctx->tr.f3 + (*fb)[1];
+            a.z = z; a.z_sb = dc.cm * plane(d); a.z_sc = plane(d);
+            a.gz = T().gz[slot]; a.gz_sb = dc.cm * plane(d); a.gz_sc = plane(d);
+            a.slope = w + dc.slope; a.act = act;
+            a.slope_part = act == HN_ACT_PRELU ? T().slope_part + (size_t)slot * T().slope_stride : nullptr;
+            for (int k = 0; k < 3; ++k) a.dst[k] = McBwdDst{gin[k].p, gin[k].sb, gin[k].sc, gin[k].p != nullptr ? gin[k].nch : 0, gin[k].scale, gin[k].accum};
+            // a discarded group in the middle keeps its channel count (the groups behind it keep their channel numbers)
+            for (int k = 0; k < 3; ++k) if (gin[k].p == nullptr) a.dst[k].nch = gin[k].nch;
+            return launch_dc8_bwd(ctx, a, dc.cin, side(d), side(d), B, s);
+        }
         if (!tile_small && small_level(d) && dc.cm == kFeat && (dc.cin == kFeat || dc.cin == kFeat + kState || dc.cin == 2 * kFeat)) {
             const DcSmallArgs q{bwd2_args(dc, slot, z, g_out, d), bwd1_args(dc, slot, gin, d)};
             return launch_dc_small(ctx, dc.cm, dc.cin, true, q, B, s);
@@ -1341,7 +1361,7 @@ struct Trainer {
     int slot_sig(int d) const { return 1 + d; }
     int slot_st(int d) const { return 1 + depth + d; }
     int slot_dec(int d) const { return 1 + 2 * depth + d; }
-    int slope_rows(int d) const { return cdiv(side(d), kC3TW) * cdiv(side(d), kC3TH) * B; }
+    int slope_rows(int d) const { (void)d; return (int)T().slope_stride; }   // every row of the slot (unused rows are zero): the kernels of a slot differ in their tile counts
 
     void wgrad8(const float* sm, int d_small, const float* bg, size_t grad_off, int bias_from_big) {   // weight [4096] and bias [8] are adjacent in the blob
         Wg8Args a{};
@@ -1452,7 +1472,7 @@ struct Trainer {
         for (int d = 0; d < depth; ++d) {   // decoder, top down
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
             const TDst gin[3] = {featdst(W.g_u[d], d), featdst(W.g_out[d], d, kFeat, 1), nodst()};
-            if ((rc = dc_bwd(L.dec[d], slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d)) != HN_OK) return rc;
+            if ((rc = dc_bwd(L.dec[d], slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d, &F3.decb[d])) != HN_OK) return rc;
             // up[d]: backward-data = the stride-2 convolution kernel on the transposed-convolution weights read as [out, in, kh, kw]
             launch_down(ctx, msrc(W.g_u[d], d), mdst(W.g_y[d + 1], d + 1), frag8(d, 3), ctx->tr.zero8, side(d), side(d), B, s);
             wgrad8(tape(t, W.o_y[d + 1]), d + 1, W.g_u[d], L.up[d].w, 1);
@@ -1460,7 +1480,7 @@ struct Trainer {
         {
             const TSrc in[3] = {feat(tape(t, W.o_x[depth]), depth), nosrc(), nosrc()};
             const TDst gin[3] = {featdst(W.g_x[depth], depth), nodst(), nodst()};
-            if ((rc = dc_bwd(L.dec[depth], slot_dec(depth), in, tape(t, W.o_zdec[depth]), feat(W.g_y[depth], depth), gin, depth)) != HN_OK) return rc;
+            if ((rc = dc_bwd(L.dec[depth], slot_dec(depth), in, tape(t, W.o_zdec[depth]), feat(W.g_y[depth], depth), gin, depth, &F3.decb[depth])) != HN_OK) return rc;
         }
         for (int d = depth - 1; d >= 0; --d) {   // encoder, bottom up
             // down[d]: backward-data = the transposed-convolution kernel on the convolution weights read as [in, out, kh, kw];
@@ -1470,13 +1490,13 @@ struct Trainer {
             {   // conv_signal: out = DC(cat[x, state])
                 const TSrc in[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
                 const TDst gin[3] = {featdst(W.g_x[d], d), state_dst(W.g_st[(cur_st + 1) % 3], d, 1), nodst()};
-                if ((rc = dc_bwd(L.sig[d], slot_sig(d), in, tape(t, W.o_zsig[d]), feat(W.g_out[d], d), gin, d)) != HN_OK) return rc;
+                if ((rc = dc_bwd(L.sig[d], slot_sig(d), in, tape(t, W.o_zsig[d]), feat(W.g_out[d], d), gin, d, &F3.sigb[d])) != HN_OK) return rc;
             }
         }
         {   // inc: DC(cat[wf, 1e3 * res, sigmas]); the sigma channels need no gradient
             const TSrc in[3] = {TSrc{wf_in, 2 * p0, p0, 2, 1.f, 0}, TSrc{res_in, 2 * p0, p0, 2, 1e3f, 0}, TSrc{ctx->tab.sigmas, 0, p0, 2, 1.f, 0}};
             const TDst gin[3] = {TDst{G, 2 * p0, p0, 2, 1.f, 1}, TDst{W.g_res, 2 * p0, p0, 2, 1e3f, 0}, nodst()};
-            if ((rc = dc_bwd(L.inc, slot_inc(), in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0)) != HN_OK) return rc;
+            if ((rc = dc_bwd(L.inc, slot_inc(), in, tape(t, W.o_zinc), feat(W.g_x[0], 0), gin, 0, &F3.incb)) != HN_OK) return rc;
         }
         cur_st = (cur_st + 1) % 3;
         if (overlap && t == 0 && wg_cap > 0) {
@@ -1588,7 +1608,7 @@ int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int 
     const size_t total = raw_layout(depth).total;
     W.part_floats = (size_t)kPartRows * total;
     HN_HIP(ctx, hipMalloc((void**)&W.part, sizeof(float) * W.part_floats));
-    W.slope_stride = (size_t)nb * cdiv(n, kC3TW) * cdiv(n, kC3TH);
+    W.slope_stride = (size_t)nb * cdiv(n, 16) * cdiv(n, 8);   // one row per tile of the finest tiling in use (k_dc_bwd_mfma_p: 8 x 32, 8 x 16 for W <= 16)
     HN_HIP(ctx, hipMalloc((void**)&W.slope_part, sizeof(double) * W.slope_stride * (3 * depth + 2)));
     HN_HIP(ctx, hipMalloc((void**)&W.w3, sizeof(float) * 2 * (total + 4)));   // both arrangements, each tensor at an even offset (pk_off)
     HN_HIP(ctx, hipMalloc((void**)&W.k8, sizeof(float) * (size_t)depth * 4 * 4096));
@@ -1710,7 +1730,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
-    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.tile_small = (ctx->opt_train_fused & 8) != 0; }
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.tile_small = (ctx->opt_train_fused & 8) != 0; t.mfma_bwd = (ctx->opt_train_fused & 16) != 0; }
     // Weight gradients beside the chain (HN_OPT_TRAIN_OVERLAP).  They are leaves of the backward pass, ~2 of the 9 ms of a step at 96^2 x 32, and the chain of
     // data-gradient kernels they wait behind is latency-bound (VALU activity ~0.12) -- but launched as they are on a second stream they gain nothing [measured]:
     // five of their 256-thread blocks hold 150 of a CU's 160 KB of LDS for ~100 us, so the chain's short kernels queue for workgroup slots behind them.  With the
@@ -1750,13 +1770,18 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         {
             const F3Layout F = f3_layout(depth);
             PackF3Jobs fj{};
-            auto addf = [&](const RawDc& dc, const size_t (&o)[2]) {
-                fj.raw[fj.n] = (int)dc.w1; fj.dst[fj.n] = (int)o[0]; fj.cin[fj.n] = (short)dc.cin; ++fj.n;
-                fj.raw[fj.n] = (int)dc.w2; fj.dst[fj.n] = (int)o[1]; fj.cin[fj.n] = (short)dc.cm; ++fj.n;
+            auto addf = [&](const RawDc& dc, const size_t (&o)[2], const size_t (&ob)[2]) {
+                auto put = [&](size_t raw, size_t dst, int cin, int rows, int mode) {
+                    fj.raw[fj.n] = (int)raw; fj.dst[fj.n] = (int)dst; fj.cin[fj.n] = (short)cin; fj.rows[fj.n] = (short)rows; fj.mode[fj.n] = (short)mode; ++fj.n;
+                };
+                put(dc.w1, o[0], dc.cin, dc.cin, 0);
+                put(dc.w2, o[1], dc.cm, dc.cm, 0);
+                put(dc.w2, ob[0], kFeat, kFeat, 1);
+                put(dc.w1, ob[1], dc.cin, cdiv(dc.cin, kFeat) * kFeat, 2);
             };
-            addf(L.inc, F.inc);
-            for (int d = 0; d < depth; ++d) addf(L.sig[d], F.sig[d]);
-            for (int d = 0; d <= depth; ++d) addf(L.dec[d], F.dec[d]);
+            addf(L.inc, F.inc, F.incb);
+            for (int d = 0; d < depth; ++d) addf(L.sig[d], F.sig[d], F.sigb[d]);
+            for (int d = 0; d <= depth; ++d) addf(L.dec[d], F.dec[d], F.decb[d]);
             hipLaunchKernelGGL(k_pack_frag3, dim3(cdiv(16 * 192, 256), fj.n), dim3(256), 0, s, weights, W.f3, fj);
         }
         HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));

@@ -92,8 +92,11 @@ enum hn_option {
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
                               * the inference path, which also store the pre-activation mid tensor to the tape; same tape within fp32
                               * rounding), 2 (backward pass: both backward-data convolutions of a big level's DoubleConv as one tiled
-                              * launch; bit-identical gradients) and 4 (the hidden-state DoubleConvs of all levels as one launch per
-                              * direction instead of two; bit-identical); default 7, 0: every convolution as its own launch (round 3)  */
+                              * launch; bit-identical gradients), 4 (the hidden-state DoubleConvs of all levels as one launch per
+                              * direction instead of two; bit-identical), 8 (experiment: the small levels' backward DoubleConvs on the tiled kernel) and
+                              * 16 (the backward-data pass of every 8-channel DoubleConv on the fp32 matrix core, k_dc_bwd_mfma_p: one launch, the g_z tile in
+                              * LDS; the f32 matrix instruction is an exact fmaf chain in the vector kernels' order: bit-identical gradients at the
+                              * training sizes); default 23, 0: every convolution as its own launch (round 3)                              */
     HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: where the three weight-gradient launches of unrolled iteration t run.  0: in line on the
                               * caller's stream.  1: on a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers), the
                               * same launches: bit-identical gradients, and measured equal (their blocks hold the CUs' LDS; the chain slows down by what the
