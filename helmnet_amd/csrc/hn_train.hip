@@ -1742,7 +1742,10 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         const long px = (long)lane_nb[l] * n * n;
         const int mode = ctx->opt_train_overlap;
         tr[l].overlap = mode == 1 || (mode == 2 && px >= 200000);
-        tr[l].wg_cap = mode == 2 && px >= 200000 && px < 1000000 ? (int)(px / 450 < 512 ? 512 : px / 450) : 0;
+#ifndef HN_WG_CAP_DIV
+#define HN_WG_CAP_DIV 350   // pixels per weight-gradient block of the capped launches (tools/build_variant.sh ... -DHN_WG_CAP_DIV=...)
+#endif
+        tr[l].wg_cap = mode == 2 && px >= 200000 && px < 1000000 ? (int)(px / HN_WG_CAP_DIV < 512 ? 512 : px / HN_WG_CAP_DIV) : 0;
     }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;
     // the training pass is fp32 whatever arithmetic the context's inference path is set to (the 8x8 launchers read it)
