@@ -254,7 +254,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             ctx->opt_train_lanes = value;
             break;
         case HN_OPT_TRAIN_FUSED:
-            if (value < 0 || value > 31) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_FUSED must be 0 .. 31 (got %d)", value);
+            if (value < 0 || value > 63) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_FUSED must be 0 .. 63 (got %d)", value);
             ctx->opt_train_fused = value;
             break;
         case HN_OPT_TRAIN_OVERLAP:

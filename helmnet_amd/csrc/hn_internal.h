@@ -233,7 +233,7 @@ struct hn_ctx {
                                    // 1: side stream, same launches ([measured, r4] no gain: 9.58 vs 9.61 ms at batch 32 -- the overlap is real, 2.3 ms of kernel time per
                                    // step run concurrently, but the weight-gradient blocks hold the CUs' LDS and the chain's kernels slow down by as much); 2 (default):
                                    // side stream AND the launches capped at ~2 blocks per CU where the chain is latency-bound (9.13 -> 8.77 ms; see hn_train_grad)
-    int opt_train_fused = 23;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
+    int opt_train_fused = 55;       // HN_OPT_TRAIN_FUSED: bit 0 the forward pass's 8-channel DoubleConvs as fused matrix-core launches with a z-store epilogue,
                                    // bit 1 the backward-data pass of a big level's DoubleConv as one tiled launch (k_dc_bwd_tile), bit 2 the hidden-state
                                    // DoubleConvs of all levels as one launch per direction (k_dc_state_batch)
     hipEvent_t train_fwd_event = nullptr;   // caller-owned: recorded behind the forward sweep of hn_train_grad (hn_train_set_forward_event)
@@ -352,6 +352,18 @@ struct McBwd {
     double* slope_part;                    // PReLU: row [tile] += sum over the tile of conv2^T(g) * min(z, 0); nullptr otherwise
     McBwdDst dst[3];
 };
+// The hidden-state DoubleConv of the same level (new_state = DC(cat[out, state]), 10 -> 2 -> 2) riding in the decoder's backward launch: both read gradients on
+// the same tile grid, and d loss / d out is the SUM of the decoder's skip gradient and conv_state's -- one store instead of a launch that opens the sum.
+struct McBwdAux {
+    const float* g; long g_sb, g_sc;       // d loss / d new state, 2 channels
+    const float* a1;                       // conv2^T fragments [2][3][64]
+    const float* a2;                       // conv1^T fragments [2 passes][2][3][64]: pass 0 -> d / d out (added to the decoder's channels 8 .. 15), pass 1 -> d / d old state
+    const float* z; long z_sb, z_sc;       // 2 channels
+    float* gz; long gz_sb, gz_sc;
+    const float* slope; double* slope_part;
+    McBwdDst dst;                          // d loss / d old state
+};
+int launch_dc8_bwd_aux(hn_ctx* ctx, const McBwd& a, const McBwdAux& x, int H, int W, int batch, hipStream_t s);
 bool dc8_bwd_applies(int H, int W);
 int dc8_bwd_tiles(int H, int W, int batch);   // rows of slope_part a launch adds to
 int launch_dc8_bwd(hn_ctx* ctx, const McBwd& a, int cin, int H, int W, int batch, hipStream_t s);

@@ -1619,6 +1619,229 @@ __global__ __launch_bounds__(256) void k_dc_bwd_mfma_p(McBwd a, int H, int W, in
 }
 
 
+// One software-pipelined run of MFMA steps over `npairs` channel pairs of LDS planes (3 rows x 2 channels = 6 steps per pair): the B operands of step
+// k + 1 and the A fragments of the next pair are read while step k's MFMAs issue (the loops of k_dc_mfma_p).  Reads one pair past the end of both
+// regions (values unused): the caller's LDS map keeps that in bounds.
+template <int GW>
+__device__ __forceinline__ void mfma_pairs(f32x4 (&acc)[GW], const float* lds, const int (&boff)[GW], int base, int plane, int pitch, int frag, int npairs, int lane) {
+    float bv[2][GW], af[6], afn[6];
+#pragma unroll
+    for (int gi = 0; gi < GW; ++gi) bv[0][gi] = lds[base + boff[gi]];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) af[j] = lds[frag + j * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int c2 = 0; c2 < npairs; ++c2) {
+        const float* tc = lds + base + 2 * c2 * plane;
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+            const int nx = st + 1, nxt = (nx / 3) * plane + (nx % 3) * pitch;
+#pragma unroll
+            for (int gi = 0; gi < GW; ++gi) bv[(st + 1) & 1][gi] = tc[boff[gi] + nxt];
+            afn[st] = lds[frag + ((c2 + 1) * 6 + st) * 64 + lane];
+#pragma unroll
+            for (int gi = 0; gi < GW; ++gi) acc[gi] = mfma4(af[st], bv[st & 1][gi], acc[gi]);
+            interleave_mfma_dsread<GW>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) af[j] = afn[j];
+    }
+}
+
+// The decoder's backward-data pass (16 forward-input channels: g_up, g_skip) with the level's hidden-state DoubleConv riding along (McBwdAux): d loss / d out =
+// the decoder's skip gradient + conv_state's, added up in the accumulators of ONE pass (the decoder's 4 channel pairs of g_z, then conv_state's pair).
+template <int TH_, int TW_, bool GEN>
+__global__ __launch_bounds__(256) void k_dc_bwd_mfma_aux(McBwd a, McBwdAux x, int H, int W, int tiles_x, int tiles_y, int ntiles) {
+    using C = PcCfg<kFeat, 0, 0, TH_, TW_>;
+    constexpr int NG = kFeat + kState;                         // staged gradient planes / mid planes: the decoder's 8, then conv_state's 2
+    constexpr int MID = NG * C::PLANE, FR = MID + NG * C::MPLANE;
+    constexpr int F_A1 = FR, F_A1S = F_A1 + 24 * 64, F_A2 = F_A1S + 6 * 64, F_A2S = F_A2 + 48 * 64;
+    constexpr int LDS_FLOATS = F_A2S + (12 + 6) * 64 + 8;
+    __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
+    __shared__ double s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, q = lane >> 4;
+    int tile = blockIdx.x;
+    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);   // XCD-aware order (hn_internal.h)
+    const int tx = tile % tiles_x, ty = (tile / tiles_x) % tiles_y, b = tile / (tiles_x * tiles_y);
+    const int x0 = tx * C::TW, y0 = ty * C::TH;
+
+    // ---- every global load first: the four fragment sets, the two gradient tiles, z of both DoubleConvs at this lane's mid slots ----
+    float4 f1[2], f1s, f2[3], f2s;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int j = tid + i * 256; f1[i] = reinterpret_cast<const float4*>(a.a1)[j < 384 ? j : 0]; }
+    f1s = reinterpret_cast<const float4*>(x.a1)[tid < 96 ? tid : 0];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) f2[i] = reinterpret_cast<const float4*>(a.a2)[tid + i * 256];
+    f2s = reinterpret_cast<const float4*>(x.a2)[tid < 192 ? tid : 0];
+    float2 stage[NG][C::NL];
+    unsigned okmask = 0;
+    int lrow[C::NL], lcol[C::NL];
+    {
+        int goff[C::NL];
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i) {
+            const int e = tid + i * 256;
+            lrow[i] = e / (C::PI / 2);
+            lcol[i] = 2 * (e - lrow[i] * (C::PI / 2));
+            const int y = y0 - 2 + lrow[i], xx = x0 - 2 + lcol[i];
+            const bool ok = (e < C::NP2) && y >= 0 && y < H && xx >= 0 && xx < W;
+            goff[i] = ok ? y * W + xx : 0;
+            okmask |= (ok ? 1u : 0u) << i;
+        }
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            const float* p0 = c < kFeat ? a.g + (long)b * a.g_sb + (long)c * a.g_sc : x.g + (long)b * x.g_sb + (long)(c - kFeat) * x.g_sc;
+#pragma unroll
+            for (int i = 0; i < C::NL; ++i) stage[c][i] = *reinterpret_cast<const float2*>(p0 + goff[i]);
+        }
+    }
+    int boff1[C::GW1], boff2[C::GW2];
+    float zz[C::GW1][4], zs[C::GW1][4];
+    unsigned min0 = 0, min1 = 0, mown0 = 0, mown1 = 0;
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) {
+        int s = 16 * (wave + 4 * gi) + n;
+        const bool slot = s < C::NS1;
+        s = slot ? s : C::NS1 - 1;
+        const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+        boff1[gi] = mrow * C::PI + 2 * pc + q;
+        const int y = y0 - 1 + mrow, xx = x0 - 1 + 2 * pc;
+        const bool yin = slot && y >= 0 && y < H;
+        const bool in0 = yin && xx >= 0 && xx < W, in1 = yin && xx + 1 >= 0 && xx + 1 < W;
+        const bool own = mrow >= 1 && mrow <= C::TH;
+        min0 |= (in0 ? 1u : 0u) << gi; min1 |= (in1 ? 1u : 0u) << gi;
+        mown0 |= (in0 && own && pc >= 1 ? 1u : 0u) << gi; mown1 |= (in1 && own && 2 * pc + 1 <= C::TW ? 1u : 0u) << gi;
+        const long o0 = in0 ? (long)y * W + xx : 0, o1 = in1 ? (long)y * W + xx + 1 : 0;
+        const float* zp = a.z + (long)b * a.z_sb + (long)(2 * q) * a.z_sc;
+        zz[gi][0] = zp[o0]; zz[gi][1] = zp[o1]; zz[gi][2] = zp[a.z_sc + o0]; zz[gi][3] = zp[a.z_sc + o1];
+        const float* zq = x.z + (long)b * x.z_sb;   // conv_state's two mid channels live in the q == 0 lanes (rows 0 .. 3 of D)
+        const bool q0 = q == 0;
+        zs[gi][0] = zq[q0 ? o0 : 0]; zs[gi][1] = zq[q0 ? o1 : 0]; zs[gi][2] = zq[q0 ? x.z_sc + o0 : 0]; zs[gi][3] = zq[q0 ? x.z_sc + o1 : 0];
+    }
+#pragma unroll
+    for (int gi = 0; gi < C::GW2; ++gi) {
+        const int s = 16 * (wave + 4 * gi) + n;
+        const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+        boff2[gi] = orow * C::PM + 2 * pc + q;
+    }
+    const float slope = a.slope != nullptr ? a.slope[0] : 0.f, slope_s = x.slope != nullptr ? x.slope[0] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int j = tid + i * 256; if (j < 384) *reinterpret_cast<float4*>(&lds[F_A1 + 4 * j]) = f1[i]; }
+    if (tid < 96) *reinterpret_cast<float4*>(&lds[F_A1S + 4 * tid]) = f1s;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(&lds[F_A2 + 4 * (tid + i * 256)]) = f2[i];
+    if (tid < 192) *reinterpret_cast<float4*>(&lds[F_A2S + 4 * tid]) = f2s;
+#pragma unroll
+    for (int c = 0; c < NG; ++c)
+#pragma unroll
+        for (int i = 0; i < C::NL; ++i)
+            if (tid + i * 256 < C::NP2)
+                *reinterpret_cast<float2*>(&lds[c * C::PLANE + lrow[i] * C::PI + lcol[i]]) = (okmask >> i & 1u) ? stage[c][i] : make_float2(0.f, 0.f);
+    __syncthreads();   // (1)
+
+    // ---- conv "1" of both DoubleConvs ----
+    f32x4 acc1[C::GW1], acc1s[C::GW1];
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) acc1[gi] = acc1s[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mfma_pairs<C::GW1>(acc1, lds, boff1, 0, C::PLANE, C::PI, F_A1, kFeat / 2, lane);
+    mfma_pairs<C::GW1>(acc1s, lds, boff1, kFeat * C::PLANE, C::PLANE, C::PI, F_A1S, kState / 2, lane);
+    double sp = 0.0, sps = 0.0;
+#pragma unroll
+    for (int gi = 0; gi < C::GW1; ++gi) {
+        const int s = 16 * (wave + 4 * gi) + n;
+        if (s < C::NS1) {
+            const int mrow = s / C::PPR1, pc = s - mrow * C::PPR1;
+            const int y = y0 - 1 + mrow, xx = x0 - 1 + 2 * pc;
+            const bool in0 = min0 >> gi & 1u, in1 = min1 >> gi & 1u, own0 = mown0 >> gi & 1u, own1 = mown1 >> gi & 1u;
+            float v[4] = {acc1[gi][0], acc1[gi][1], acc1[gi][2], acc1[gi][3]};
+            if (a.slope_part != nullptr) {
+                if (own0 && zz[gi][0] <= 0.f) sp += (double)v[0] * (double)zz[gi][0];
+                if (own1 && zz[gi][1] <= 0.f) sp += (double)v[1] * (double)zz[gi][1];
+                if (own0 && zz[gi][2] <= 0.f) sp += (double)v[2] * (double)zz[gi][2];
+                if (own1 && zz[gi][3] <= 0.f) sp += (double)v[3] * (double)zz[gi][3];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] *= act_grad<GEN>(zz[gi][r], a.act, slope);
+            float* gp = a.gz + (long)b * a.gz_sb + (long)(2 * q) * a.gz_sc + (long)y * W + xx;
+            if (own0) { gp[0] = v[0]; gp[a.gz_sc] = v[2]; }
+            if (own1) { gp[1] = v[1]; gp[a.gz_sc + 1] = v[3]; }
+            float* m0 = lds + MID + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
+            *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
+            *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
+            if (q == 0) {   // conv_state's g_z
+                float u[4] = {acc1s[gi][0], acc1s[gi][1], acc1s[gi][2], acc1s[gi][3]};
+                if (x.slope_part != nullptr) {
+                    if (own0 && zs[gi][0] <= 0.f) sps += (double)u[0] * (double)zs[gi][0];
+                    if (own1 && zs[gi][1] <= 0.f) sps += (double)u[1] * (double)zs[gi][1];
+                    if (own0 && zs[gi][2] <= 0.f) sps += (double)u[2] * (double)zs[gi][2];
+                    if (own1 && zs[gi][3] <= 0.f) sps += (double)u[3] * (double)zs[gi][3];
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) u[r] *= act_grad<GEN>(zs[gi][r], a.act, slope_s);
+                float* gq = x.gz + (long)b * x.gz_sb + (long)y * W + xx;
+                if (own0) { gq[0] = u[0]; gq[x.gz_sc] = u[2]; }
+                if (own1) { gq[1] = u[1]; gq[x.gz_sc + 1] = u[3]; }
+                float* m1 = lds + MID + kFeat * C::MPLANE + mrow * C::PM + 2 * pc;
+                *reinterpret_cast<float2*>(m1) = make_float2(in0 ? u[0] : 0.f, in1 ? u[1] : 0.f);
+                *reinterpret_cast<float2*>(m1 + C::MPLANE) = make_float2(in0 ? u[2] : 0.f, in1 ? u[3] : 0.f);
+            }
+        }
+    }
+    if (a.slope_part != nullptr || x.slope_part != nullptr) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sp += __shfl_down(sp, o, 64); sps += __shfl_down(sps, o, 64); }
+        if (lane == 0) { s_red[wave] = sp; s_red[4 + wave] = sps; }
+    }
+    __syncthreads();   // (2) both g_z tiles complete
+    if (tid == 0) {
+        if (a.slope_part != nullptr) a.slope_part[tile] += (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        if (x.slope_part != nullptr) x.slope_part[tile] += (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+    }
+
+    // ---- conv "2": pass 0 = the decoder's channels 0 .. 7, pass 1 = its channels 8 .. 15 + conv_state's d / d out, pass 2 = conv_state's d / d old state ----
+    auto store = [&](const McBwdDst& d, int cd, const f32x4 (&acc2)[C::GW2]) {   // this lane's channels cd, cd + 1 of group d
+        if (d.p == nullptr) return;
+        float* const base = d.p + (long)b * d.sb + (long)cd * d.sc;
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) {
+            const int s = 16 * (wave + 4 * gi) + n;
+            const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
+            const int y = y0 + orow, xx = x0 + 2 * pc;
+            if (y < H && xx < W) {
+                float* p = base + (long)y * W + xx;
+                float2 o0 = make_float2(0.f, 0.f), o1 = o0;
+                if (d.accum) { o0 = *reinterpret_cast<const float2*>(p); o1 = *reinterpret_cast<const float2*>(p + d.sc); }
+                *reinterpret_cast<float2*>(p) = make_float2(__fmul_rn(acc2[gi][0], d.scale) + o0.x, __fmul_rn(acc2[gi][1], d.scale) + o0.y);
+                *reinterpret_cast<float2*>(p + d.sc) = make_float2(__fmul_rn(acc2[gi][2], d.scale) + o1.x, __fmul_rn(acc2[gi][3], d.scale) + o1.y);
+            }
+        }
+    };
+    {
+        f32x4 acc2[C::GW2];
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID, C::MPLANE, C::PM, F_A2, kFeat / 2, lane);
+        store(a.dst[0], 2 * q, acc2);
+    }
+    {
+        f32x4 acc2[C::GW2];
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID, C::MPLANE, C::PM, F_A2 + 24 * 64, kFeat / 2, lane);
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID + kFeat * C::MPLANE, C::MPLANE, C::PM, F_A2S, kState / 2, lane);
+        store(a.dst[1], 2 * q, acc2);
+    }
+    {
+        f32x4 acc2[C::GW2];
+#pragma unroll
+        for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID + kFeat * C::MPLANE, C::MPLANE, C::PM, F_A2S + 6 * 64, kState / 2, lane);
+        if (q == 0) store(x.dst, 0, acc2);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // 8x8 stride-2 down convolution (architectures.py:209-211)
 //   P_h[Yw][X] = sum_ci sum_kx sum_{k<4} w[co][ci][4h + k][kx] * in[ci][2 Yw - 3 + k][2 X - 3 + kx]
@@ -2405,6 +2628,24 @@ int launch_dc8_bwd(hn_ctx* ctx, const McBwd& a, int cin, int H, int W, int batch
         if (d.nch & 1) return fail(ctx, HN_ERR_ARG, "internal: odd channel group in the matrix-core backward DoubleConv");
     if (cin <= kFeat) launch_dc8_bwd_n<1>(a, H, W, batch, s);
     else launch_dc8_bwd_n<2>(a, H, W, batch, s);
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
+int launch_dc8_bwd_aux(hn_ctx* ctx, const McBwd& a, const McBwdAux& x, int H, int W, int batch, hipStream_t s) {
+    if (!dc8_bwd_applies(H, W) || a.dst[0].nch != kFeat || a.dst[1].nch != kFeat || x.dst.nch != kState)
+        return fail(ctx, HN_ERR_ARG, "internal: the decoder + hidden-state backward kernel needs channel groups 8 | 8 and 2");
+    int tw, tx, ty;
+    dc8_bwd_shape(H, W, tw, tx, ty);
+    const int nt = tx * ty * batch;
+    const bool gen = a.act > HN_ACT_LEAKYRELU;
+    if (tw == 32) {
+        if (gen) hipLaunchKernelGGL((k_dc_bwd_mfma_aux<8, 32, true>), dim3(nt), dim3(256), 0, s, a, x, H, W, tx, ty, nt);
+        else hipLaunchKernelGGL((k_dc_bwd_mfma_aux<8, 32, false>), dim3(nt), dim3(256), 0, s, a, x, H, W, tx, ty, nt);
+    } else {
+        if (gen) hipLaunchKernelGGL((k_dc_bwd_mfma_aux<8, 16, true>), dim3(nt), dim3(256), 0, s, a, x, H, W, tx, ty, nt);
+        else hipLaunchKernelGGL((k_dc_bwd_mfma_aux<8, 16, false>), dim3(nt), dim3(256), 0, s, a, x, H, W, tx, ty, nt);
+    }
     HN_HIP(ctx, hipGetLastError());
     return HN_OK;
 }

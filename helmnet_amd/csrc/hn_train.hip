@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_pack3(const float* __restrict__ raw, fl
 }
 // 3x3 weights of the 8-channel DoubleConvs as A-operand fragments of the fp32 matrix-core kernels (hn_mfma.hip, pack_frag_3x3):
 // raw [8][cin][3][3] -> [cin][3][64], lane l -> (co = (l & 15) >> 1, dxo = l & 1, t = l >> 4): raw[co][ci][dy][t - dxo] where that tap exists.
-struct F3Layout { size_t inc[2], sig[kMaxDepth][2], dec[kMaxDepth + 1][2], incb[2], sigb[kMaxDepth][2], decb[kMaxDepth + 1][2], total; };
+struct F3Layout { size_t inc[2], sig[kMaxDepth][2], dec[kMaxDepth + 1][2], incb[2], sigb[kMaxDepth][2], decb[kMaxDepth + 1][2], stb[kMaxDepth][2], total; };
 F3Layout f3_layout(int depth) {
     F3Layout F{};
     size_t pos = 0;
@@ -1013,15 +1013,17 @@ F3Layout f3_layout(int depth) {
     takeb(F.incb, kInCh);
     for (int d = 0; d < depth; ++d) takeb(F.sigb[d], kFeat + kState);
     for (int d = 0; d <= depth; ++d) takeb(F.decb[d], d < depth ? 2 * kFeat : kFeat);
+    // the hidden-state DoubleConv's (10 -> 2 -> 2): conv2^T [2][3][64]; conv1^T two passes of [2][3][64] (k_dc_bwd_mfma_aux)
+    for (int d = 0; d < depth; ++d) { F.stb[d][0] = pos; pos += (size_t)kState * 192; F.stb[d][1] = pos; pos += (size_t)2 * kState * 192; }
     F.total = pos;
     return F;
 }
 // mode 0: the forward convolution raw [8][cin][3][3] -> [cin][3][64].  mode 1: the transposed convolution of raw [8 co][8 cm][3][3] (conv2) -- fragment
 // channel = co, output = cm, taps flipped.  mode 2: the transposed convolution of raw [8 cm][cin][3][3] (conv1) -- fragment channel = cm, output = forward
 // input channel 8 pass + .. (zero beyond cin), taps flipped, `rows` = passes * 8 fragment channels.
-struct PackF3Jobs { int n; int raw[4 * (2 * kMaxDepth + 2)], dst[4 * (2 * kMaxDepth + 2)]; short cin[4 * (2 * kMaxDepth + 2)], rows[4 * (2 * kMaxDepth + 2)], mode[4 * (2 * kMaxDepth + 2)]; };
+struct PackF3Jobs { int n; int raw[5 * (2 * kMaxDepth + 2)], dst[5 * (2 * kMaxDepth + 2)]; short cin[5 * (2 * kMaxDepth + 2)], rows[5 * (2 * kMaxDepth + 2)], mode[5 * (2 * kMaxDepth + 2)], cm[5 * (2 * kMaxDepth + 2)]; };
 __global__ __launch_bounds__(256) void k_pack_frag3(const float* __restrict__ blob, float* __restrict__ f3, PackF3Jobs jobs) {
-    const int j = blockIdx.y, cin = jobs.cin[j], rows = jobs.rows[j], mode = jobs.mode[j];
+    const int j = blockIdx.y, cin = jobs.cin[j], rows = jobs.rows[j], mode = jobs.mode[j], cmid = jobs.cm[j];
     const int e = blockIdx.x * 256 + threadIdx.x;
     if (e >= rows * 192) return;
     const int l = e & 63, dy = (e >> 6) % 3, ci = e / 192;
@@ -1029,9 +1031,10 @@ __global__ __launch_bounds__(256) void k_pack_frag3(const float* __restrict__ bl
     float v = 0.f;
     if (dx >= 0 && dx <= 2) {
         if (mode == 0) v = blob[jobs.raw[j] + ((co * cin + ci) * 3 + dy) * 3 + dx];
-        else if (mode == 1) v = blob[jobs.raw[j] + ((ci * kFeat + co) * 3 + (2 - dy)) * 3 + (2 - dx)];
-        else {
-            const int pass = ci / kFeat, cm = ci - pass * kFeat, fi = pass * kFeat + co;
+        else if (mode == 1) {          // raw [rows = co'][cmid][3][3]: fragment channel ci = co', output co = mid channel (zero beyond cmid)
+            if (co < cmid) v = blob[jobs.raw[j] + ((ci * cmid + co) * 3 + (2 - dy)) * 3 + (2 - dx)];
+        } else {                       // raw [cmid][cin][3][3]: fragment channel = (pass, mid channel), output = forward input channel 8 pass + co (zero beyond cin)
+            const int pass = ci / cmid, cm = ci - pass * cmid, fi = pass * kFeat + co;
             if (fi < cin) v = blob[jobs.raw[j] + ((cm * cin + fi) * 3 + (2 - dy)) * 3 + (2 - dx)];
         }
     }
@@ -1214,6 +1217,7 @@ struct Trainer {
     int wg_cap = 0;          // > 0: at most this many blocks per weight-gradient launch (HN_OPT_TRAIN_OVERLAP 2, see hn_train_grad)
     bool tile_small = false; // HN_OPT_TRAIN_FUSED bit 3 (A/B): the small levels' backward DoubleConvs on the tiled kernel too instead of the per-sample k_dc_small
     bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
+    bool merge_state = true; // (with bits 2 and 4) the hidden-state DoubleConv's backward-data pass rides in the decoder's launch of the same level (k_dc_bwd_mfma_aux)
     bool mfma_bwd = true;    // HN_OPT_TRAIN_FUSED bit 4: the backward-data pass of the 8-channel DoubleConvs on the fp32 matrix core (k_dc_bwd_mfma_p) instead of the vector-pipe kernels
     bool fused_bwd = true;   // HN_OPT_TRAIN_FUSED bit 1 (A/B): the big levels' backward DoubleConvs as two k_conv3 launches (the r3 path)
     bool fused_fwd = true;   // HN_OPT_TRAIN_FUSED 0 (A/B): every convolution of the forward pass as its own direct launch (the r3 path)
@@ -1357,6 +1361,13 @@ struct Trainer {
         if ((rc = launch_conv3(ctx, dc.cm, true, bwd2_args(dc, slot, z, g_out, d), B, s)) != HN_OK) return rc;
         return launch_conv3(ctx, dc.cin, false, bwd1_args(dc, slot, gin, d), B, s);
     }
+    // conv_state's backward-data pass inside the decoder's launch: needs the matrix-core backward kernels at every level and the z-stride layout of the tape
+    bool merged_state() const {
+        if (!(merge_state && mfma_bwd && fused_state)) return false;
+        for (int d = 0; d < depth; ++d)
+            if (!dc8_bwd_applies(side(d), side(d)) || dc8_bwd_tiles(side(d), side(d), B) > (int)T().slope_stride) return false;
+        return true;
+    }
     int slot_inc() const { return 0; }
     int slot_sig(int d) const { return 1 + d; }
     int slot_st(int d) const { return 1 + depth + d; }
@@ -1459,7 +1470,9 @@ struct Trainer {
                 const TDst gin[3] = {featdst(W.g_out[d], d, kFeat, 0), state_dst(W.g_st[(cur_st + 1) % 3], d, 0), nodst()};
                 q1.job[d] = bwd1_args(dc, slot_st(d), gin, d);
             }
-            if (fused_state) {
+            if (merged_state()) {
+                // (k_dc_bwd_mfma_aux: each level's pass rides in the decoder's backward launch below)
+            } else if (fused_state) {
                 DcBatch qb{};
                 qb.njobs = depth;
                 for (int d = 0; d < depth; ++d) qb.job[d] = DcSmallArgs{q2.job[d], q1.job[d]};
@@ -1471,8 +1484,34 @@ struct Trainer {
         }
         for (int d = 0; d < depth; ++d) {   // decoder, top down
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
-            const TDst gin[3] = {featdst(W.g_u[d], d), featdst(W.g_out[d], d, kFeat, 1), nodst()};
-            if ((rc = dc_bwd(L.dec[d], slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d, &F3.decb[d])) != HN_OK) return rc;
+            if (merged_state()) {   // the decoder's backward-data pass and conv_state's in one launch: g_out[d] = skip gradient + conv_state's, written once
+                const RawDc &dc = L.dec[d], &ds = L.st[d];
+                if ((rc = dc_wgrads(dc, slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), d)) != HN_OK) return rc;
+                McBwd a{};
+                a.g = W.g_y[d]; a.g_sb = kFeat * plane(d); a.g_sc = plane(d);
+                a.a1 = ctx->tr.f3 + F3.decb[d][0]; a.a2 = ctx->tr.f3 + F3.decb[d][1];
+                a.z = tape(t, W.o_zdec[d]); a.z_sb = kFeat * plane(d); a.z_sc = plane(d);
+                a.gz = W.gz[slot_dec(d)]; a.gz_sb = kFeat * plane(d); a.gz_sc = plane(d);
+                a.slope = w + dc.slope; a.act = act;
+                a.slope_part = act == HN_ACT_PRELU ? W.slope_part + (size_t)slot_dec(d) * W.slope_stride : nullptr;
+                a.dst[0] = McBwdDst{W.g_u[d], kFeat * plane(d), plane(d), kFeat, 1.f, 0};
+                a.dst[1] = McBwdDst{W.g_out[d], kFeat * plane(d), plane(d), kFeat, 1.f, 0};
+                a.dst[2] = McBwdDst{nullptr, 0, 0, 0, 1.f, 0};
+                McBwdAux x{};
+                const TSrc g_new = state_src(W.g_st[cur_st], d);
+                x.g = g_new.p; x.g_sb = g_new.sb; x.g_sc = g_new.sc;
+                x.a1 = ctx->tr.f3 + F3.stb[d][0]; x.a2 = ctx->tr.f3 + F3.stb[d][1];
+                x.z = tape(t, W.o_zst[d]); x.z_sb = kState * plane(d); x.z_sc = plane(d);
+                x.gz = W.gz[slot_st(d)]; x.gz_sb = kState * plane(d); x.gz_sc = plane(d);
+                x.slope = w + ds.slope;
+                x.slope_part = act == HN_ACT_PRELU ? W.slope_part + (size_t)slot_st(d) * W.slope_stride : nullptr;
+                const TDst g_old = state_dst(W.g_st[(cur_st + 1) % 3], d, 0);
+                x.dst = McBwdDst{g_old.p, g_old.sb, g_old.sc, kState, 1.f, 0};
+                if ((rc = launch_dc8_bwd_aux(ctx, a, x, side(d), side(d), B, s)) != HN_OK) return rc;
+            } else {
+                const TDst gin[3] = {featdst(W.g_u[d], d), featdst(W.g_out[d], d, kFeat, 1), nodst()};
+                if ((rc = dc_bwd(L.dec[d], slot_dec(d), in, tape(t, W.o_zdec[d]), feat(W.g_y[d], d), gin, d, &F3.decb[d])) != HN_OK) return rc;
+            }
             // up[d]: backward-data = the stride-2 convolution kernel on the transposed-convolution weights read as [out, in, kh, kw]
             launch_down(ctx, msrc(W.g_u[d], d), mdst(W.g_y[d + 1], d + 1), frag8(d, 3), ctx->tr.zero8, side(d), side(d), B, s);
             wgrad8(tape(t, W.o_y[d + 1]), d + 1, W.g_u[d], L.up[d].w, 1);
@@ -1730,7 +1769,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     Trainer tr[2] = {
         Trainer{ctx, ls[0], weights, L, lane_nb[0], n, depth, ctx->act_kind, (long)ctx->state_len, ws[0], ctx->tr.sumsq, batch},
         Trainer{ctx, ls[1], weights, L, lane_nb[1], n, depth, ctx->act_kind, (long)ctx->state_len, ws[1], ctx->tr.sumsq + lane_b0[1], batch}};
-    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.tile_small = (ctx->opt_train_fused & 8) != 0; t.mfma_bwd = (ctx->opt_train_fused & 16) != 0; }
+    for (Trainer& t : tr) { t.F3 = f3_layout(depth); t.fused_fwd = (ctx->opt_train_fused & 1) != 0; t.fused_bwd = (ctx->opt_train_fused & 2) != 0; t.fused_state = (ctx->opt_train_fused & 4) != 0; t.tile_small = (ctx->opt_train_fused & 8) != 0; t.mfma_bwd = (ctx->opt_train_fused & 16) != 0; t.merge_state = (ctx->opt_train_fused & 32) != 0; }
     // Weight gradients beside the chain (HN_OPT_TRAIN_OVERLAP).  They are leaves of the backward pass, ~2 of the 9 ms of a step at 96^2 x 32, and the chain of
     // data-gradient kernels they wait behind is latency-bound (VALU activity ~0.12) -- but launched as they are on a second stream they gain nothing [measured]:
     // five of their 256-thread blocks hold 150 of a CU's 160 KB of LDS for ~100 us, so the chain's short kernels queue for workgroup slots behind them.  With the
@@ -1773,18 +1812,22 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         {
             const F3Layout F = f3_layout(depth);
             PackF3Jobs fj{};
+            auto put = [&](size_t raw, size_t dst, int cin, int rows, int mode, int cm) {
+                fj.raw[fj.n] = (int)raw; fj.dst[fj.n] = (int)dst; fj.cin[fj.n] = (short)cin; fj.rows[fj.n] = (short)rows; fj.mode[fj.n] = (short)mode; fj.cm[fj.n] = (short)cm; ++fj.n;
+            };
             auto addf = [&](const RawDc& dc, const size_t (&o)[2], const size_t (&ob)[2]) {
-                auto put = [&](size_t raw, size_t dst, int cin, int rows, int mode) {
-                    fj.raw[fj.n] = (int)raw; fj.dst[fj.n] = (int)dst; fj.cin[fj.n] = (short)cin; fj.rows[fj.n] = (short)rows; fj.mode[fj.n] = (short)mode; ++fj.n;
-                };
-                put(dc.w1, o[0], dc.cin, dc.cin, 0);
-                put(dc.w2, o[1], dc.cm, dc.cm, 0);
-                put(dc.w2, ob[0], kFeat, kFeat, 1);
-                put(dc.w1, ob[1], dc.cin, cdiv(dc.cin, kFeat) * kFeat, 2);
+                put(dc.w1, o[0], dc.cin, dc.cin, 0, kFeat);
+                put(dc.w2, o[1], dc.cm, dc.cm, 0, kFeat);
+                put(dc.w2, ob[0], kFeat, kFeat, 1, kFeat);
+                put(dc.w1, ob[1], dc.cin, cdiv(dc.cin, kFeat) * kFeat, 2, kFeat);
             };
             addf(L.inc, F.inc, F.incb);
             for (int d = 0; d < depth; ++d) addf(L.sig[d], F.sig[d], F.sigb[d]);
             for (int d = 0; d <= depth; ++d) addf(L.dec[d], F.dec[d], F.decb[d]);
+            for (int d = 0; d < depth; ++d) {   // conv_state: [2][2][3][3] and [2][10][3][3]
+                put(L.st[d].w2, F.stb[d][0], kState, kState, 1, kState);
+                put(L.st[d].w1, F.stb[d][1], kFeat + kState, 2 * kState, 2, kState);
+            }
             hipLaunchKernelGGL(k_pack_frag3, dim3(cdiv(16 * 192, 256), fj.n), dim3(256), 0, s, weights, W.f3, fj);
         }
         HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));

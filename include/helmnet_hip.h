@@ -96,7 +96,9 @@ enum hn_option {
                               * direction instead of two; bit-identical), 8 (experiment: the small levels' backward DoubleConvs on the tiled kernel) and
                               * 16 (the backward-data pass of every 8-channel DoubleConv on the fp32 matrix core, k_dc_bwd_mfma_p: one launch, the g_z tile in
                               * LDS; the f32 matrix instruction is an exact fmaf chain in the vector kernels' order: bit-identical gradients at the
-                              * training sizes); default 23, 0: every convolution as its own launch (round 3)                              */
+                              * training sizes) and 32 (with 4 and 16: conv_state's backward-data pass rides in the decoder's launch of the same level,
+                              * k_dc_bwd_mfma_aux; d loss / d out is added up in one accumulator: fp32 rounding); default 55, 0: every convolution as its own
+                              * launch (round 3)                                                                                         */
     HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: where the three weight-gradient launches of unrolled iteration t run.  0: in line on the
                               * caller's stream.  1: on a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers), the
                               * same launches: bit-identical gradients, and measured equal (their blocks hold the CUs' LDS; the chain slows down by what the

@@ -376,13 +376,13 @@ def test_fused_training_launches_keep_the_gradient_bits(solver, weights, g_train
     args = [x.to(DEV).contiguous() for x in (wf0, res0, st0, k_sq, src)]
     outs = {}
     try:
-        for fused, overlap in ((7, 0), (3, 0), (1, 0), (0, 0), (7, 1), (7, 2), (23, 0)):
+        for fused, overlap in ((7, 0), (3, 0), (1, 0), (0, 0), (7, 1), (7, 2), (23, 0), (55, 0)):
             eng.set_option("train_fused", fused)
             eng.set_option("train_overlap", int(overlap))
             o = eng.train_grad(blob, *args, 4, 1e4, input_grads=True)
             outs[(fused, overlap)] = tuple(o[k].clone() for k in ("loss", "grad", "grad_wf", "grad_res", "grad_states"))
     finally:
-        eng.set_option("train_fused", 23)
+        eng.set_option("train_fused", 55)
         eng.set_option("train_overlap", 2)
     # (the LOSS is read off per-sample sums of squares that the spectral row kernel accumulates with float atomics: its last bit depends on
     # the order in which the workgroups of a sample arrive, so it is compared to rounding; nothing downstream reads it)
@@ -399,6 +399,12 @@ def test_fused_training_launches_keep_the_gradient_bits(solver, weights, g_train
         worst = max(worst, float((a - c).abs().max()) / float(c.abs().max()))
     print("matrix-core backward DoubleConvs vs the vector-pipe ones: worst Linf / max over (loss, grad, grad_wf, grad_res, grad_states)", worst,
           "bit-identical:", all(bool(torch.equal(a, c)) for a, c in zip(outs[(23, 0)][1:], outs[(7, 0)][1:])))
+    assert worst <= 2e-5
+    # bit 5 (default): conv_state's backward-data pass inside the decoder's launch -- d loss / d out is added up in one accumulator instead of two launches
+    worst = 0.0
+    for a, c in zip(outs[(55, 0)], outs[(23, 0)]):
+        worst = max(worst, float((a - c).abs().max()) / float(c.abs().max()))
+    print("decoder + hidden-state backward in one launch vs two: worst Linf / max", worst, "bit-identical:", all(bool(torch.equal(a, c)) for a, c in zip(outs[(55, 0)][1:], outs[(23, 0)][1:])))
     assert worst <= 2e-5
     # the fused forward: fp32 rounding at most.  (At this size it is in fact bit-identical as well: the f32 matrix instruction is an exact fmaf
     # chain and k_dc_mfma_p walks (channel, row, tap) in k_conv3's order with the bias added last; the strip kernel of W >= 128 starts from the bias.)
