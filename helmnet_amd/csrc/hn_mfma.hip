@@ -1623,7 +1623,7 @@ __global__ __launch_bounds__(256) void k_dc_bwd_mfma_p(McBwd a, int H, int W, in
 // k + 1 and the A fragments of the next pair are read while step k's MFMAs issue (the loops of k_dc_mfma_p).  Reads one pair past the end of both
 // regions (values unused): the caller's LDS map keeps that in bounds.
 template <int GW>
-__device__ __forceinline__ void mfma_pairs(f32x4 (&acc)[GW], const float* lds, const int (&boff)[GW], int base, int plane, int pitch, int frag, int npairs, int lane) {
+__device__ __forceinline__ void mfma_pairs(f32x4 (&acc)[GW], const float* lds, const int (&boff)[GW], int base, int plane, int pitch, int frag, int npairs, int lane, int frag_rows = 1 << 20) {
     float bv[2][GW], af[6], afn[6];
 #pragma unroll
     for (int gi = 0; gi < GW; ++gi) bv[0][gi] = lds[base + boff[gi]];
@@ -1638,7 +1638,8 @@ __device__ __forceinline__ void mfma_pairs(f32x4 (&acc)[GW], const float* lds, c
             const int nx = st + 1, nxt = (nx / 3) * plane + (nx % 3) * pitch;
 #pragma unroll
             for (int gi = 0; gi < GW; ++gi) bv[(st + 1) & 1][gi] = tc[boff[gi] + nxt];
-            afn[st] = lds[frag + ((c2 + 1) * 6 + st) * 64 + lane];
+            const int nrow = (c2 + 1) * 6 + st;   // (scalar) the read ahead of the last pair stays inside the caller's fragment rows
+            afn[st] = lds[frag + (nrow < frag_rows ? nrow : frag_rows - 1) * 64 + lane];
 #pragma unroll
             for (int gi = 0; gi < GW; ++gi) acc[gi] = mfma4(af[st], bv[st & 1][gi], acc[gi]);
             interleave_mfma_dsread<GW>();
@@ -1655,9 +1656,10 @@ template <int TH_, int TW_, bool GEN>
 __global__ __launch_bounds__(256) void k_dc_bwd_mfma_aux(McBwd a, McBwdAux x, int H, int W, int tiles_x, int tiles_y, int ntiles) {
     using C = PcCfg<kFeat, 0, 0, TH_, TW_>;
     constexpr int NG = kFeat + kState;                         // staged gradient planes / mid planes: the decoder's 8, then conv_state's 2
-    constexpr int MID = NG * C::PLANE, FR = MID + NG * C::MPLANE;
+    constexpr int PM = C::TW + 2, MPLANE = C::MR * PM;         // mid pitch without the forward kernel's padding: 53.9 KB at 8 x 32 = three blocks per CU
+    constexpr int MID = NG * C::PLANE, FR = MID + NG * MPLANE;
     constexpr int F_A1 = FR, F_A1S = F_A1 + 24 * 64, F_A2 = F_A1S + 6 * 64, F_A2S = F_A2 + 48 * 64;
-    constexpr int LDS_FLOATS = F_A2S + (12 + 6) * 64 + 8;
+    constexpr int LDS_FLOATS = F_A2S + 12 * 64;                // (the last fragment set's read-ahead is clamped: mfma_pairs' frag_rows)
     __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
     __shared__ double s_red[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1724,7 +1726,7 @@ __global__ __launch_bounds__(256) void k_dc_bwd_mfma_aux(McBwd a, McBwdAux x, in
     for (int gi = 0; gi < C::GW2; ++gi) {
         const int s = 16 * (wave + 4 * gi) + n;
         const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
-        boff2[gi] = orow * C::PM + 2 * pc + q;
+        boff2[gi] = orow * PM + 2 * pc + q;
     }
     const float slope = a.slope != nullptr ? a.slope[0] : 0.f, slope_s = x.slope != nullptr ? x.slope[0] : 0.f;
 #pragma unroll
@@ -1767,9 +1769,9 @@ __global__ __launch_bounds__(256) void k_dc_bwd_mfma_aux(McBwd a, McBwdAux x, in
             float* gp = a.gz + (long)b * a.gz_sb + (long)(2 * q) * a.gz_sc + (long)y * W + xx;
             if (own0) { gp[0] = v[0]; gp[a.gz_sc] = v[2]; }
             if (own1) { gp[1] = v[1]; gp[a.gz_sc + 1] = v[3]; }
-            float* m0 = lds + MID + (2 * q) * C::MPLANE + mrow * C::PM + 2 * pc;
+            float* m0 = lds + MID + (2 * q) * MPLANE + mrow * PM + 2 * pc;
             *reinterpret_cast<float2*>(m0) = make_float2(in0 ? v[0] : 0.f, in1 ? v[1] : 0.f);
-            *reinterpret_cast<float2*>(m0 + C::MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
+            *reinterpret_cast<float2*>(m0 + MPLANE) = make_float2(in0 ? v[2] : 0.f, in1 ? v[3] : 0.f);
             if (q == 0) {   // conv_state's g_z
                 float u[4] = {acc1s[gi][0], acc1s[gi][1], acc1s[gi][2], acc1s[gi][3]};
                 if (x.slope_part != nullptr) {
@@ -1783,9 +1785,9 @@ __global__ __launch_bounds__(256) void k_dc_bwd_mfma_aux(McBwd a, McBwdAux x, in
                 float* gq = x.gz + (long)b * x.gz_sb + (long)y * W + xx;
                 if (own0) { gq[0] = u[0]; gq[x.gz_sc] = u[2]; }
                 if (own1) { gq[1] = u[1]; gq[x.gz_sc + 1] = u[3]; }
-                float* m1 = lds + MID + kFeat * C::MPLANE + mrow * C::PM + 2 * pc;
+                float* m1 = lds + MID + kFeat * MPLANE + mrow * PM + 2 * pc;
                 *reinterpret_cast<float2*>(m1) = make_float2(in0 ? u[0] : 0.f, in1 ? u[1] : 0.f);
-                *reinterpret_cast<float2*>(m1 + C::MPLANE) = make_float2(in0 ? u[2] : 0.f, in1 ? u[3] : 0.f);
+                *reinterpret_cast<float2*>(m1 + MPLANE) = make_float2(in0 ? u[2] : 0.f, in1 ? u[3] : 0.f);
             }
         }
     }
@@ -1822,22 +1824,22 @@ __global__ __launch_bounds__(256) void k_dc_bwd_mfma_aux(McBwd a, McBwdAux x, in
         f32x4 acc2[C::GW2];
 #pragma unroll
         for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mfma_pairs<C::GW2>(acc2, lds, boff2, MID, C::MPLANE, C::PM, F_A2, kFeat / 2, lane);
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID, MPLANE, PM, F_A2, kFeat / 2, lane);
         store(a.dst[0], 2 * q, acc2);
     }
     {
         f32x4 acc2[C::GW2];
 #pragma unroll
         for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mfma_pairs<C::GW2>(acc2, lds, boff2, MID, C::MPLANE, C::PM, F_A2 + 24 * 64, kFeat / 2, lane);
-        mfma_pairs<C::GW2>(acc2, lds, boff2, MID + kFeat * C::MPLANE, C::MPLANE, C::PM, F_A2S, kState / 2, lane);
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID, MPLANE, PM, F_A2 + 24 * 64, kFeat / 2, lane);
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID + kFeat * MPLANE, MPLANE, PM, F_A2S, kState / 2, lane);
         store(a.dst[1], 2 * q, acc2);
     }
     {
         f32x4 acc2[C::GW2];
 #pragma unroll
         for (int gi = 0; gi < C::GW2; ++gi) acc2[gi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mfma_pairs<C::GW2>(acc2, lds, boff2, MID + kFeat * C::MPLANE, C::MPLANE, C::PM, F_A2S + 6 * 64, kState / 2, lane);
+        mfma_pairs<C::GW2>(acc2, lds, boff2, MID + kFeat * MPLANE, MPLANE, PM, F_A2S + 6 * 64, kState / 2, lane, 6);
         if (q == 0) store(x.dst, 0, acc2);
     }
 }
