@@ -2387,7 +2387,10 @@ void launch_dc_mfma(int x16, Src a, Src b, Src c, Dst out, const McW& w, const M
         else hipLaunchKernelGGL((k_dc_x16<SplitBf16x2, CA, CB, CC, EPI>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
         return;
     }
-    if (W >= 128 && even && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
+#ifndef HN_STRIP_MIN_W
+#define HN_STRIP_MIN_W 128   // narrowest level on the strip kernel (experiment: tools/build_variant.sh ... -DHN_STRIP_MIN_W=256)
+#endif
+    if (W >= HN_STRIP_MIN_W && even && off32 && (!scaled || ScCfg<CA, CB, CC>::SCALED)) {
         hipLaunchKernelGGL((k_dc_mfma_s<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, H, W);
     } else if (even && W > 16) {
         // small levels are latency-bound: whole input tile staged at once (one barrier), small 8 x 32
