@@ -146,9 +146,11 @@ def _one_step_case(solver_, weights, n, b, act, seed, force_mids):
     return bwd
 
 
-@pytest.mark.parametrize("n,b", [(96, 2), (64, 3), (256, 1), (48, 1)])
+@pytest.mark.parametrize("n,b", [(96, 2), (64, 3), (256, 1), (48, 1), (80, 2), (112, 1)])
 def test_one_unrolled_iteration_matches_oracle_autograd_tensor_by_tensor(solver, weights, n, b):
-    """The shipped PReLU network; pow2 (64, 256), 3 * 2^k (96, 48) domains; tile grids from 1 x 1 to 8 x 8."""
+    """The shipped PReLU network; pow2 (64, 256), 3 * 2^k (96, 48), 5 * 2^k (80) and 7 * 2^k (112) domains; tile grids from 1 x 1 to 8 x 8.  80 and 112
+    have levels whose height is not a multiple of the 8-row tiles of the matrix-core backward kernels (10, 14) next to an odd deepest level (5, 7:
+    the vector-pipe kernels), i.e. both backward paths in one network."""
     _report(_one_step_case(solver, weights, n, b, "prelu", 500 + n, force_mids=True), 1e-4)
 
 
