@@ -207,6 +207,8 @@ struct hn_ctx {
         hipStream_t wg_stream = nullptr;
         hipEvent_t wg_ready[2]{}, wg_done[2]{};
         bool wg_pending[2]{};
+        hipEvent_t st_fork = nullptr, st_done = nullptr;   // forward sweep: the hidden-state DoubleConvs of an iteration on wg_stream (idle then) beside its decoder
+        bool st_pending = false;
         float* part = nullptr;       // [640 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
         size_t part_floats = 0;
         double* slope_part = nullptr; // [3 depth + 2 DoubleConvs][slope_stride]: per-block sums of the PReLU-slope gradients (float64)

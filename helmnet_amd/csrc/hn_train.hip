@@ -1227,6 +1227,7 @@ struct Trainer {
     int wg_cap = 0;          // > 0: at most this many blocks per weight-gradient launch (HN_OPT_TRAIN_OVERLAP 2, see hn_train_grad)
     bool tile_small = false; // HN_OPT_TRAIN_FUSED bit 3 (A/B): the small levels' backward DoubleConvs on the tiled kernel too instead of the per-sample k_dc_small
     bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
+    bool side_state_fwd = false; // forward sweep: the hidden-state DoubleConvs of an iteration on the (then idle) weight-gradient stream, joined in front of the next iteration's conv_signal
     bool merge_state = true; // (with bits 2 and 4) the hidden-state DoubleConv's backward-data pass rides in the decoder's launch of the same level (k_dc_bwd_mfma_aux)
     bool mfma_bwd = true;    // HN_OPT_TRAIN_FUSED bit 4: the backward-data pass of the 8-channel DoubleConvs on the fp32 matrix core (k_dc_bwd_mfma_p) instead of the vector-pipe kernels
     bool fused_bwd = true;   // HN_OPT_TRAIN_FUSED bit 1 (A/B): the big levels' backward DoubleConvs as two k_conv3 launches (the r3 path)
@@ -1405,6 +1406,7 @@ struct Trainer {
             const TSrc in[3] = {TSrc{wf, 2 * p0, p0, 2, 1.f, 0}, TSrc{res, 2 * p0, p0, 2, 1e3f, 0}, TSrc{ctx->tab.sigmas, 0, p0, 2, 1.f, 0}};
             if ((rc = dc_fwd(L.inc, in, tape(t, W.o_zinc), featdst(tape(t, W.o_x[0]), 0), 0, &F3.inc)) != HN_OK) return rc;
         }
+        if (W.st_pending) { HN_HIP(ctx, hipStreamWaitEvent(s, W.st_done, 0)); W.st_pending = false; }   // the previous iteration's new states
         for (int d = 0; d < depth; ++d) {
             const TSrc in_sig[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
             if ((rc = dc_fwd(L.sig[d], in_sig, tape(t, W.o_zsig[d]), featdst(tape(t, W.o_out[d]), d), d, &F3.sig[d])) != HN_OK) return rc;
@@ -1423,7 +1425,13 @@ struct Trainer {
                 q2.job[d] = fwd_args(mid, dc.w2, dc.b2, dc.slope, state_dst(st_next, d), d);
                 qf.job[d] = DcSmallArgs{q1.job[d], q2.job[d]};
             }
-            if (fused_state) {   // both convolutions of every level's hidden-state DoubleConv in ONE launch (k_dc_state_batch)
+            if (fused_state && side_state_fwd) {   // ... beside the decoder: nothing reads the new states before the next iteration
+                HN_HIP(ctx, hipEventRecord(W.st_fork, s));
+                HN_HIP(ctx, hipStreamWaitEvent(W.wg_stream, W.st_fork, 0));
+                if ((rc = launch_dc_state_batch(ctx, false, qf, B, W.wg_stream)) != HN_OK) return rc;
+                HN_HIP(ctx, hipEventRecord(W.st_done, W.wg_stream));
+                W.st_pending = true;
+            } else if (fused_state) {   // both convolutions of every level's hidden-state DoubleConv in ONE launch (k_dc_state_batch)
                 if ((rc = launch_dc_state_batch(ctx, false, qf, B, s)) != HN_OK) return rc;
             } else {
                 if ((rc = launch_conv3_batch(ctx, kState, false, q1, B, s)) != HN_OK) return rc;
@@ -1582,6 +1590,9 @@ void train_free_ws(hn_ctx::TrainWs& W) {
     for (hipEvent_t e : W.jobs_copied)
         if (e != nullptr) (void)hipEventDestroy(e);
     if (W.wg_stream != nullptr) (void)hipStreamDestroy(W.wg_stream);
+    if (W.st_fork != nullptr) (void)hipEventDestroy(W.st_fork);
+    if (W.st_done != nullptr) (void)hipEventDestroy(W.st_done);
+    W.st_fork = W.st_done = nullptr; W.st_pending = false;
     for (int k = 0; k < 2; ++k) {
         if (W.wg_ready[k] != nullptr) (void)hipEventDestroy(W.wg_ready[k]);
         if (W.wg_done[k] != nullptr) (void)hipEventDestroy(W.wg_done[k]);
@@ -1650,6 +1661,8 @@ int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int 
     W.g_wf[0] = W.gbuf + o_wf0; W.g_wf[1] = W.gbuf + o_wf1; W.g_res = W.gbuf + o_res;
     for (int k = 0; k < 3; ++k) W.g_st[k] = W.gbuf + o_st[k];
     HN_HIP(ctx, hipStreamCreateWithFlags(&W.wg_stream, hipStreamNonBlocking));
+    HN_HIP(ctx, hipEventCreateWithFlags(&W.st_fork, hipEventDisableTiming));
+    HN_HIP(ctx, hipEventCreateWithFlags(&W.st_done, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) {
         HN_HIP(ctx, hipEventCreateWithFlags(&W.wg_ready[k], hipEventDisableTiming));
         HN_HIP(ctx, hipEventCreateWithFlags(&W.wg_done[k], hipEventDisableTiming));
@@ -1791,6 +1804,10 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         const long px = (long)lane_nb[l] * n * n;
         const int mode = ctx->opt_train_overlap;
         tr[l].overlap = mode == 1 || (mode == 2 && px >= 200000);
+        // ... and the forward sweep's hidden-state launch on that (then idle) stream beside the decoder: a fork whose join comes an iteration later.  [measured,
+        // profiles/r4_side_state_fwd.txt] 7.36 -> 7.19 ms at 96^2 x 32, -2 % at 128^2 x 32 / 256^2 x 8 / 96^2 x 128; +7 % at 96^2 x 8 and 64^2 x 32, where the event packets cost
+        // more than the 24 us kernel they take off the chain -- hence the same window
+        tr[l].side_state_fwd = mode == 2 && px >= 200000;
 #ifndef HN_WG_CAP_DIV
 #define HN_WG_CAP_DIV 350   // pixels per weight-gradient block of the capped launches (tools/build_variant.sh ... -DHN_WG_CAP_DIV=...)
 #endif
@@ -1860,6 +1877,8 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         for (int l = 0; l < lanes; ++l)
             for (int k = 0; k < 2; ++k)
                 if (ws[l]->wg_pending[k]) { (void)hipStreamWaitEvent(ls[l], ws[l]->wg_done[k], 0); ws[l]->wg_pending[k] = false; }
+        for (int l = 0; l < lanes; ++l)
+            if (ws[l]->st_pending) { (void)hipStreamWaitEvent(ls[l], ws[l]->st_done, 0); ws[l]->st_pending = false; }
         if (lanes == 2) {
             (void)hipEventRecord(ctx->train_join, ctx->train_stream);
             (void)hipStreamWaitEvent(s, ctx->train_join, 0);
@@ -1872,6 +1891,8 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
                                     k_sq + (size_t)lane_b0[l] * n * n, src + (src_batch == 1 ? 0 : (size_t)lane_b0[l] * p2), src_batch == 1 ? 1 : lane_nb[l]);
         }
     if (rc != HN_OK) { join_streams(); return rc; }
+    for (int l = 0; l < lanes; ++l)   // the last iteration's new states: st_hist is complete behind this
+        if (ws[l]->st_pending) { HN_HIP(ctx, hipStreamWaitEvent(ls[l], ws[l]->st_done, 0)); ws[l]->st_pending = false; }
     if (ctx->train_fwd_event != nullptr && !capturing) {   // the histories are complete: the caller's host logic may read them while the backward pass runs (not recorded into a captured graph)
         if (lanes == 2) {                    // (the second lane's forward sweep joins first)
             HN_HIP(ctx, hipEventRecord(ctx->train_join, ctx->train_stream));

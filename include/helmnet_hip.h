@@ -103,7 +103,8 @@ enum hn_option {
                               * caller's stream.  1: on a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers), the
                               * same launches: bit-identical gradients, and measured equal (their blocks hold the CUs' LDS; the chain slows down by what the
                               * overlap gains).  2 (default): on the library stream AND, where the chain is latency-bound (200 k .. 1 M pixels per call), with at
-                              * most ~2 of their blocks per CU -- each walks more tiles, the chain keeps half of every CU: 9.13 -> 8.77 ms at 96^2 x 32.  The cap
+                              * most ~2 of their blocks per CU -- each walks more tiles, the chain keeps half of every CU: 9.13 -> 8.77 ms at 96^2 x 32 -- and the forward
+                              * sweep's hidden-state launch on that stream beside the decoder.  The cap
                               * changes how many partial sums a weight gradient is added up from: a fixed order (reproducible), not mode 0's  */
 };
 /* Diagnostics counters (hn_get_counter). */
