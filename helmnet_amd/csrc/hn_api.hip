@@ -189,7 +189,7 @@ int hn_create(hn_ctx** out, int device_id) {
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
                                                             {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}};
-    if (const char* v = getenv("HN_SIDE_PRIORITY")) c->opt_side_low_priority = std::atoi(v) != 0;
+    if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 2 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
         if (const char* v = getenv(k.env)) {
@@ -644,7 +644,7 @@ struct StepArgs {
     float* rmse_hist;   // base of the [n_iter, batch] table (rows are selected on the device through it_counter)
 };
 
-int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side) {
+int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, int bank) {
     while (ctx->n_streams < ns) {
         const int j = ctx->n_streams;
         HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));
@@ -656,13 +656,11 @@ int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side) {
     if (!ctx->it_counter) HN_HIP(ctx, hipMalloc((void**)&ctx->it_counter, 8 * sizeof(int)));
     if (want_side) {
         for (int j = 0; j < ns; ++j) {
-            auto& sl = ctx->side[j];
+            auto& sl = ctx->side[j + 8 * bank];
             if (sl.stream) continue;
-            // HN_SIDE_PRIORITY=1 (A/B only): lowest stream priority, so that the hidden-state kernels only fill what the main chain
-            // leaves idle -- measured 1 % SLOWER than the default priority (r3), so it stays off
             int least = 0, greatest = 0;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            HN_HIP(ctx, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, ctx->opt_side_low_priority ? least : 0));
+            HN_HIP(ctx, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, bank ? least : 0));
             for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&sl.ev[d], hipEventDisableTiming));
             HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
@@ -683,7 +681,7 @@ int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, in
     const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
     const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
     int rc = unet_forward(ctx, s_wf, s_res, s_sig, parity ? st_tmp : st_user, parity ? st_user : st_tmp, nullptr, wf_j, nb, sj, b0,
-                          stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr, defer_join);
+                          stagger, ctx->opt_side_stream ? &ctx->side[lane + 8 * ctx->side_bank] : nullptr, defer_join);
     if (rc != HN_OK) return rc;
     const float* src_j = a.src_batch == 1 ? a.src : a.src + (size_t)b0 * 2 * plane;
     return spec_apply(ctx, wf_j, res_j, a.k_sq + (size_t)b0 * plane, src_j, a.src_batch == 1 ? 1 : nb, nb,
@@ -772,7 +770,9 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     const long L = ctx->state_len;
     int ns = ctx->opt_lanes;
     if (batch < 2 * ns) ns = 1;                       // tiny batches: not worth splitting
-    if ((rc = ensure_step_resources(ctx, ns, ctx->opt_side_stream != 0)) != HN_OK) return rc;
+    // the side lanes' priority bank (hn_internal.h: opt_side_priority): a caller on a stream of its own gets the lowest-priority lanes
+    ctx->side_bank = ctx->opt_side_priority == 1 || (ctx->opt_side_priority == 0 && s != nullptr) ? 1 : 0;
+    if ((rc = ensure_step_resources(ctx, ns, ctx->opt_side_stream != 0, ctx->side_bank)) != HN_OK) return rc;
     if (rmse_hist) {
         HN_HIP(ctx, hipMemsetAsync(rmse_hist, 0, sizeof(float) * (size_t)n_iter * batch, s));
         HN_HIP(ctx, hipMemsetAsync(ctx->it_counter, 0, 8 * sizeof(int), s));

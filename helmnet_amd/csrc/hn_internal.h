@@ -137,7 +137,9 @@ struct hn_ctx {
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
     int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
     int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
-    bool opt_side_low_priority = false;  // side stream at the lowest stream priority (HN_SIDE_PRIORITY=1): measured -1 % (1961 / 1974 vs 1979 / 2001 it/s)
+    int opt_side_priority = 0;     // HN_SIDE_PRIORITY: 0 (default) the side stream at normal priority when the caller's stream is the default stream, at the LOWEST otherwise --
+                                   // streams of one priority share the runtime's few hardware queues, and a caller stream on the side stream's queue loses the overlap
+                                   // ([measured, r4] one torch side stream in three: 1788 vs 1946-1962 it/s); 1 always lowest (-0.7 % with the default stream), 2 always normal
     int opt_defer_join = 0;    // HN_DEFER_JOIN=1 (A/B): hn_step joins the side stream behind the NEXT iteration's input layer instead of at the end of
                                // the UNet -- measured no gain (1902 / 1927 / 1938 vs 1932 / 1933 / 1946 it/s, r3): the ~6 us bubble is the event
                                // packet itself, wherever it sits
@@ -174,7 +176,8 @@ struct hn_ctx {
         hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr;
         bool pending = false;   // `done` has been recorded on the side stream and not been waited for yet (deferred join, hn_step)
     };
-    SideLane side[8];
+    SideLane side[16];         // [0, 8): normal stream priority, [8, 16): lowest (side_bank picks one per hn_step call)
+    int side_bank = 0;
     int n_streams = 0;         // internal streams created so far
     hipStream_t sub_stream[8]{};
     hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};
