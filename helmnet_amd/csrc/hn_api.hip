@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <cstdio>
 #include "hn_internal.h"
 
 namespace hn {
@@ -300,12 +301,16 @@ void hn_destroy(hn_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_stagger[j]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    for (auto& sl : ctx->side) {
-        if (!sl.stream) continue;
-        (void)hipStreamDestroy(sl.stream);
+    for (int j = 0; j < 8; ++j) {
+        auto& sl = ctx->side[j];
+        if (!sl.done) continue;
+        if (j > 0 && sl.stream) (void)hipStreamDestroy(sl.stream);   // (lane 0's stream is one of picks[0]'s candidates)
         for (int d = 0; d < kMaxDepth; ++d) (void)hipEventDestroy(sl.ev[d]);
         (void)hipEventDestroy(sl.done);
     }
+    for (auto& pk : ctx->picks)
+        for (hipStream_t& c : pk.cand)
+            if (c) { (void)hipStreamDestroy(c); c = nullptr; }
     for (auto& r : ctx->prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (hipEvent_t e : ctx->prof_pool) (void)hipEventDestroy(e);
     delete ctx;
@@ -644,7 +649,63 @@ struct StepArgs {
     float* rmse_hist;   // base of the [n_iter, batch] table (rows are selected on the device through it_counter)
 };
 
-int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, int bank) {
+__global__ void k_probe_spin(long ticks) {
+    const long t0 = (long)wall_clock64();   // 100 MHz
+    while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+// do commands on `b` run while a kernel on `a` is still running?  (both streams are drained first: once per (slot, caller stream))
+static bool probe_overlap(hipStream_t a, hipStream_t b) {
+    hipEvent_t ea = nullptr, eb = nullptr;
+    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return true;
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 20000L);   // 200 us
+    (void)hipEventRecord(ea, a);
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, b, 0L);
+    (void)hipEventRecord(eb, b);
+    (void)hipEventSynchronize(ea);
+    (void)hipEventSynchronize(eb);
+    float ms = 0.f;
+    const bool ok = hipEventElapsedTime(&ms, eb, ea) == hipSuccess;
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    (void)hipGetLastError();
+    return !ok || ms > 0.08f;   // the candidate's marker completed >= 80 us before the spin kernel's: another hardware queue
+}
+}  // namespace
+int side_stream_for(hn_ctx* ctx, int slot, hipStream_t caller, bool may_sync, hipStream_t* out) {
+    auto& pk = ctx->picks[slot];
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int prio[4] = {0, least, greatest, least};
+    auto cand = [&](int i) -> int {
+        if (pk.cand[i] == nullptr) HN_HIP(ctx, hipStreamCreateWithPriority(&pk.cand[i], hipStreamNonBlocking, prio[i]));
+        return HN_OK;
+    };
+    int rc;
+    if (ctx->opt_side_priority != 0) {   // A/B: no probing
+        const int i = ctx->opt_side_priority == 1 ? 1 : 0;
+        if ((rc = cand(i)) != HN_OK) return rc;
+        *out = pk.cand[i];
+        return HN_OK;
+    }
+    if (!(pk.probed && pk.caller == caller) && may_sync) {
+        pk.chosen = 0;
+        for (int i = 0; i < 4; ++i) {
+            if ((rc = cand(i)) != HN_OK) return rc;
+            if (probe_overlap(caller, pk.cand[i])) { pk.chosen = i; break; }
+        }
+        pk.probed = true;
+        pk.caller = caller;
+        if (getenv("HN_DEBUG_PICK")) fprintf(stderr, "[helmnet_hip] side stream of slot %d for caller stream %p: candidate %d (priority %d)\n", slot, (void*)caller, pk.chosen, prio[pk.chosen]);
+    }
+    if ((rc = cand(pk.chosen)) != HN_OK) return rc;
+    *out = pk.cand[pk.chosen];
+    return HN_OK;
+}
+
+namespace {
+int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, hipStream_t caller, bool may_sync) {
     while (ctx->n_streams < ns) {
         const int j = ctx->n_streams;
         HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));
@@ -656,11 +717,13 @@ int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, int bank) {
     if (!ctx->it_counter) HN_HIP(ctx, hipMalloc((void**)&ctx->it_counter, 8 * sizeof(int)));
     if (want_side) {
         for (int j = 0; j < ns; ++j) {
-            auto& sl = ctx->side[j + 8 * bank];
-            if (sl.stream) continue;
-            int least = 0, greatest = 0;
-            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            HN_HIP(ctx, hipStreamCreateWithPriority(&sl.stream, hipStreamNonBlocking, bank ? least : 0));
+            auto& sl = ctx->side[j];
+            if (j == 0) {   // the stream that demonstrably overlaps with the caller's (re-checked when the caller's stream changes)
+                int rc = side_stream_for(ctx, 0, caller, may_sync, &sl.stream);
+                if (rc != HN_OK) return rc;
+            }
+            if (sl.done) continue;
+            if (j > 0) HN_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&sl.ev[d], hipEventDisableTiming));
             HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }
@@ -681,7 +744,7 @@ int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, in
     const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
     const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
     int rc = unet_forward(ctx, s_wf, s_res, s_sig, parity ? st_tmp : st_user, parity ? st_user : st_tmp, nullptr, wf_j, nb, sj, b0,
-                          stagger, ctx->opt_side_stream ? &ctx->side[lane + 8 * ctx->side_bank] : nullptr, defer_join);
+                          stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr, defer_join);
     if (rc != HN_OK) return rc;
     const float* src_j = a.src_batch == 1 ? a.src : a.src + (size_t)b0 * 2 * plane;
     return spec_apply(ctx, wf_j, res_j, a.k_sq + (size_t)b0 * plane, src_j, a.src_batch == 1 ? 1 : nb, nb,
@@ -770,9 +833,9 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     const long L = ctx->state_len;
     int ns = ctx->opt_lanes;
     if (batch < 2 * ns) ns = 1;                       // tiny batches: not worth splitting
-    // the side lanes' priority bank (hn_internal.h: opt_side_priority): a caller on a stream of its own gets the lowest-priority lanes
-    ctx->side_bank = ctx->opt_side_priority == 1 || (ctx->opt_side_priority == 0 && s != nullptr) ? 1 : 0;
-    if ((rc = ensure_step_resources(ctx, ns, ctx->opt_side_stream != 0, ctx->side_bank)) != HN_OK) return rc;
+    hipStreamCaptureStatus cap_status = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &cap_status);
+    if ((rc = ensure_step_resources(ctx, ns, ctx->opt_side_stream != 0, s, cap_status == hipStreamCaptureStatusNone)) != HN_OK) return rc;
     if (rmse_hist) {
         HN_HIP(ctx, hipMemsetAsync(rmse_hist, 0, sizeof(float) * (size_t)n_iter * batch, s));
         HN_HIP(ctx, hipMemsetAsync(ctx->it_counter, 0, 8 * sizeof(int), s));

@@ -137,9 +137,7 @@ struct hn_ctx {
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
     int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
     int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
-    int opt_side_priority = 0;     // HN_SIDE_PRIORITY: 0 (default) the side stream at normal priority when the caller's stream is the default stream, at the LOWEST otherwise --
-                                   // streams of one priority share the runtime's few hardware queues, and a caller stream on the side stream's queue loses the overlap
-                                   // ([measured, r4] one torch side stream in three: 1788 vs 1946-1962 it/s); 1 always lowest (-0.7 % with the default stream), 2 always normal
+    int opt_side_priority = 0;     // HN_SIDE_PRIORITY: 0 (default) probe (above); 1 / 2 (A/B): the lowest- / normal-priority candidate without probing
     int opt_defer_join = 0;    // HN_DEFER_JOIN=1 (A/B): hn_step joins the side stream behind the NEXT iteration's input layer instead of at the end of
                                // the UNet -- measured no gain (1902 / 1927 / 1938 vs 1932 / 1933 / 1946 it/s, r3): the ~6 us bubble is the event
                                // packet itself, wherever it sits
@@ -176,8 +174,13 @@ struct hn_ctx {
         hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr;
         bool pending = false;   // `done` has been recorded on the side stream and not been waited for yet (deferred join, hn_step)
     };
-    SideLane side[16];         // [0, 8): normal stream priority, [8, 16): lowest (side_bank picks one per hn_step call)
-    int side_bank = 0;
+    SideLane side[8];          // (lane 0's stream belongs to picks[0]: side_stream_for)
+    // Side-stream picker (hn_api.hip: side_stream_for).  HIP streams are dealt onto a few hardware queues, and two streams on ONE queue run in submission order:
+    // a library side stream that lands on the caller's queue silently loses its overlap (inference -9 %) or serialises behind capped launches (training step
+    // 7.2 -> 21 ms) -- which streams share a queue depends on how many streams of which priority the PROCESS has created, not on anything the library controls
+    // [measured, r4: profiles/r4_caller_stream.txt, r4_wg_prio.txt, r4_stream_probe.txt].  So per (slot, caller stream) the library PROBES its candidates once:
+    // a 200 us spin kernel on the caller's stream, an empty one on the candidate -- did the second finish first? -- and keeps the first candidate that overlaps.
+    struct SidePick { hipStream_t cand[4]{}; hipStream_t caller = nullptr; bool probed = false; int chosen = 0; } picks[4];   // 0: hn_step lane 0; 1, 2: hn_train_grad lanes
     int n_streams = 0;         // internal streams created so far
     hipStream_t sub_stream[8]{};
     hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};
@@ -404,6 +407,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                  hn_ctx::SideLane* side_lane = nullptr, bool defer_join = false);
 // make stream s wait for the hidden-state kernels of the previous unet_forward(..., defer_join = true) on this lane
 int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
+int side_stream_for(hn_ctx* ctx, int slot, hipStream_t caller, bool may_sync, hipStream_t* out);
 
 // standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv): fp32 vector kernels of hn_unet.hip on packed device weights
 int module_double_conv(hn_ctx* ctx, const float* x, int cin, int cout, const DcW& w, float* out, int batch, int H, int W, hipStream_t s);

@@ -1589,7 +1589,7 @@ void train_free_ws(hn_ctx::TrainWs& W) {
     if (W.jobs_host != nullptr) (void)hipHostFree(W.jobs_host);
     for (hipEvent_t e : W.jobs_copied)
         if (e != nullptr) (void)hipEventDestroy(e);
-    if (W.wg_stream != nullptr) (void)hipStreamDestroy(W.wg_stream);
+    W.wg_stream = nullptr;   // (one of ctx->picks[1 / 2]'s candidates: side_stream_for)
     if (W.st_fork != nullptr) (void)hipEventDestroy(W.st_fork);
     if (W.st_done != nullptr) (void)hipEventDestroy(W.st_done);
     W.st_fork = W.st_done = nullptr; W.st_pending = false;
@@ -1660,13 +1660,6 @@ int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int 
     select_gset(W, 0);
     W.g_wf[0] = W.gbuf + o_wf0; W.g_wf[1] = W.gbuf + o_wf1; W.g_res = W.gbuf + o_res;
     for (int k = 0; k < 3; ++k) W.g_st[k] = W.gbuf + o_st[k];
-    {   // The side stream at the LOWEST priority: streams of one priority share the runtime's few hardware queues, and a caller whose stream happens to sit on
-        // the same queue as this one gets no overlap at all ([measured, profiles/r4_wg_prio.txt] 8.95 vs 7.19 ms per step with a torch side stream as the
-        // caller's); another priority is another queue.  With the default stream as the caller's the priority itself changes nothing (7.18 - 7.22 ms).
-        int least = 0, greatest = 0;
-        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        HN_HIP(ctx, hipStreamCreateWithPriority(&W.wg_stream, hipStreamNonBlocking, least));
-    }
     HN_HIP(ctx, hipEventCreateWithFlags(&W.st_fork, hipEventDisableTiming));
     HN_HIP(ctx, hipEventCreateWithFlags(&W.st_done, hipEventDisableTiming));
     for (int k = 0; k < 2; ++k) {
@@ -1806,6 +1799,8 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     // The window is narrow [measured, profiles/r4_train_wgcap.txt]: below ~200 k pixels per call the step is all launch floor (nothing to hide behind), above
     // ~1 M the chain fills the chip by itself (a cap costs what it hides; the plain side stream is still -2 %).  Mode 1 keeps the launches' block counts (bit-identical
     // to mode 0); mode 2 (default) applies the cap, i.e. another -- fixed -- order of the partial sums.
+    for (int l = 0; l < lanes; ++l)   // the side stream that demonstrably overlaps with this lane's chain (hn_internal.h: SidePick)
+        if ((rc = side_stream_for(ctx, 1 + l, ls[l], !capturing, &ws[l]->wg_stream)) != HN_OK) return rc;
     for (int l = 0; l < lanes; ++l) {
         const long px = (long)lane_nb[l] * n * n;
         const int mode = ctx->opt_train_overlap;
