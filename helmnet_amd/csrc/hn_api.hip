@@ -296,7 +296,7 @@ void hn_destroy(hn_ctx* ctx) {
     (void)hipFree(ctx->wdev);
     (void)hipFree(ctx->fragdev);
     for (int j = 0; j < ctx->n_streams; ++j) {
-        (void)hipStreamDestroy(ctx->sub_stream[j]);
+        if (j >= 2) (void)hipStreamDestroy(ctx->sub_stream[j]);   // (lanes 0 and 1: candidates of ctx->picks)
         (void)hipEventDestroy(ctx->ev_join[j]);
         (void)hipEventDestroy(ctx->ev_stagger[j]);
     }
@@ -304,7 +304,7 @@ void hn_destroy(hn_ctx* ctx) {
     for (int j = 0; j < 8; ++j) {
         auto& sl = ctx->side[j];
         if (!sl.done) continue;
-        if (j > 0 && sl.stream) (void)hipStreamDestroy(sl.stream);   // (lane 0's stream is one of picks[0]'s candidates)
+        if (j >= 2 && sl.stream) (void)hipStreamDestroy(sl.stream);   // (lanes 0 and 1: candidates of ctx->picks)
         for (int d = 0; d < kMaxDepth; ++d) (void)hipEventDestroy(sl.ev[d]);
         (void)hipEventDestroy(sl.done);
     }
@@ -673,7 +673,7 @@ static bool probe_overlap(hipStream_t a, hipStream_t b) {
     return !ok || ms > 0.08f;   // the candidate's marker completed >= 80 us before the spin kernel's: another hardware queue
 }
 }  // namespace
-int side_stream_for(hn_ctx* ctx, int slot, hipStream_t caller, bool may_sync, hipStream_t* out) {
+int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, bool may_sync, hipStream_t* out) {
     auto& pk = ctx->picks[slot];
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -689,15 +689,19 @@ int side_stream_for(hn_ctx* ctx, int slot, hipStream_t caller, bool may_sync, hi
         *out = pk.cand[i];
         return HN_OK;
     }
-    if (!(pk.probed && pk.caller == caller) && may_sync) {
+    bool same = pk.nref == nrefs;
+    for (int k = 0; same && k < nrefs; ++k) same = pk.ref[k] == refs[k];
+    if (!same && may_sync) {
         pk.chosen = 0;
         for (int i = 0; i < 4; ++i) {
             if ((rc = cand(i)) != HN_OK) return rc;
-            if (probe_overlap(caller, pk.cand[i])) { pk.chosen = i; break; }
+            bool ok = true;
+            for (int k = 0; ok && k < nrefs; ++k) ok = probe_overlap(refs[k], pk.cand[i]);
+            if (ok) { pk.chosen = i; break; }
         }
-        pk.probed = true;
-        pk.caller = caller;
-        if (getenv("HN_DEBUG_PICK")) fprintf(stderr, "[helmnet_hip] side stream of slot %d for caller stream %p: candidate %d (priority %d)\n", slot, (void*)caller, pk.chosen, prio[pk.chosen]);
+        pk.nref = nrefs;
+        for (int k = 0; k < nrefs; ++k) pk.ref[k] = refs[k];
+        if (getenv("HN_DEBUG_PICK")) fprintf(stderr, "[helmnet_hip] stream of slot %d beside %d other(s) (first %p): candidate %d (priority %d)\n", slot, nrefs, nrefs ? (void*)refs[0] : nullptr, pk.chosen, prio[pk.chosen]);
     }
     if ((rc = cand(pk.chosen)) != HN_OK) return rc;
     *out = pk.cand[pk.chosen];
@@ -706,24 +710,32 @@ int side_stream_for(hn_ctx* ctx, int slot, hipStream_t caller, bool may_sync, hi
 
 namespace {
 int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, hipStream_t caller, bool may_sync) {
+    int rc;
     while (ctx->n_streams < ns) {
         const int j = ctx->n_streams;
-        HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));
+        if (j >= 2) HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->sub_stream[j], hipStreamNonBlocking));   // (lanes 0 and 1: picked below)
         HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_join[j], hipEventDisableTiming));
         HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_stagger[j], hipEventDisableTiming));
         ctx->n_streams = j + 1;
+    }
+    if (ns >= 2) {   // two pipeline lanes: four library streams that demonstrably run side by side (picks 3 .. 6)
+        if ((rc = side_stream_for(ctx, 3, nullptr, 0, may_sync, &ctx->sub_stream[0])) != HN_OK) return rc;
+        if ((rc = side_stream_for(ctx, 4, ctx->sub_stream, 1, may_sync, &ctx->sub_stream[1])) != HN_OK) return rc;
     }
     if (!ctx->ev_fork) HN_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     if (!ctx->it_counter) HN_HIP(ctx, hipMalloc((void**)&ctx->it_counter, 8 * sizeof(int)));
     if (want_side) {
         for (int j = 0; j < ns; ++j) {
             auto& sl = ctx->side[j];
-            if (j == 0) {   // the stream that demonstrably overlaps with the caller's (re-checked when the caller's stream changes)
-                int rc = side_stream_for(ctx, 0, caller, may_sync, &sl.stream);
-                if (rc != HN_OK) return rc;
+            if (ns == 1) {          // the stream that demonstrably overlaps with the caller's (re-checked when the caller's stream changes)
+                if ((rc = side_stream_for(ctx, 0, &caller, 1, may_sync, &sl.stream)) != HN_OK) return rc;
+            } else if (j < 2) {
+                const hipStream_t refs[3] = {ctx->sub_stream[0], ctx->sub_stream[1], ctx->side[0].stream};
+                if ((rc = side_stream_for(ctx, 5 + j, refs, 2 + j, may_sync, &sl.stream)) != HN_OK) return rc;
+            } else if (sl.stream == nullptr) {
+                HN_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             }
             if (sl.done) continue;
-            if (j > 0) HN_HIP(ctx, hipStreamCreateWithFlags(&sl.stream, hipStreamNonBlocking));
             for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&sl.ev[d], hipEventDisableTiming));
             HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
         }

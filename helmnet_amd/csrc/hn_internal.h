@@ -180,7 +180,8 @@ struct hn_ctx {
     // 7.2 -> 21 ms) -- which streams share a queue depends on how many streams of which priority the PROCESS has created, not on anything the library controls
     // [measured, r4: profiles/r4_caller_stream.txt, r4_wg_prio.txt, r4_stream_probe.txt].  So per (slot, caller stream) the library PROBES its candidates once:
     // a 200 us spin kernel on the caller's stream, an empty one on the candidate -- did the second finish first? -- and keeps the first candidate that overlaps.
-    struct SidePick { hipStream_t cand[4]{}; hipStream_t caller = nullptr; bool probed = false; int chosen = 0; } picks[4];   // 0: hn_step lane 0; 1, 2: hn_train_grad lanes
+    struct SidePick { hipStream_t cand[4]{}; hipStream_t ref[3]{}; int nref = -1; int chosen = 0; } picks[8];   // 0: hn_step's side stream; 1, 2: hn_train_grad lanes;
+                                                                                                               // 3 .. 6: two pipeline lanes (chain 0, chain 1, side 0, side 1: mutually overlapping)
     int n_streams = 0;         // internal streams created so far
     hipStream_t sub_stream[8]{};
     hipEvent_t ev_fork = nullptr, ev_join[8]{}, ev_stagger[8]{};
@@ -407,7 +408,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                  hn_ctx::SideLane* side_lane = nullptr, bool defer_join = false);
 // make stream s wait for the hidden-state kernels of the previous unet_forward(..., defer_join = true) on this lane
 int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
-int side_stream_for(hn_ctx* ctx, int slot, hipStream_t caller, bool may_sync, hipStream_t* out);
+int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, bool may_sync, hipStream_t* out);   // a stream that overlaps with every stream in refs
 
 // standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv): fp32 vector kernels of hn_unet.hip on packed device weights
 int module_double_conv(hn_ctx* ctx, const float* x, int cin, int cout, const DcW& w, float* out, int batch, int H, int W, hipStream_t s);

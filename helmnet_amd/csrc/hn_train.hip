@@ -1800,7 +1800,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     // ~1 M the chain fills the chip by itself (a cap costs what it hides; the plain side stream is still -2 %).  Mode 1 keeps the launches' block counts (bit-identical
     // to mode 0); mode 2 (default) applies the cap, i.e. another -- fixed -- order of the partial sums.
     for (int l = 0; l < lanes; ++l)   // the side stream that demonstrably overlaps with this lane's chain (hn_internal.h: SidePick)
-        if ((rc = side_stream_for(ctx, 1 + l, ls[l], !capturing, &ws[l]->wg_stream)) != HN_OK) return rc;
+        if ((rc = side_stream_for(ctx, 1 + l, &ls[l], 1, !capturing, &ws[l]->wg_stream)) != HN_OK) return rc;
     for (int l = 0; l < lanes; ++l) {
         const long px = (long)lane_nb[l] * n * n;
         const int mode = ctx->opt_train_overlap;
