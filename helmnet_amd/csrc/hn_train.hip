@@ -1703,7 +1703,6 @@ int train_ready(hn_ctx* ctx, int batch, int n_unroll) {
 void train_free(hn_ctx* ctx) {
     train_free_ws(ctx->tr);
     train_free_ws(ctx->tr_b);
-    if (ctx->train_stream != nullptr) (void)hipStreamDestroy(ctx->train_stream);
     if (ctx->train_fork != nullptr) (void)hipEventDestroy(ctx->train_fork);
     if (ctx->train_join != nullptr) (void)hipEventDestroy(ctx->train_join);
     ctx->train_stream = nullptr;
@@ -1761,10 +1760,15 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     }
     if ((rc = train_reserve(ctx, ctx->tr, lane_nb[0], n_unroll, batch)) != HN_OK) return rc;
     if (lanes == 2 && (rc = train_reserve(ctx, ctx->tr_b, lane_nb[1], n_unroll, 1)) != HN_OK) return rc;
-    if (lanes == 2 && ctx->train_stream == nullptr) {
-        HN_HIP(ctx, hipStreamCreateWithFlags(&ctx->train_stream, hipStreamNonBlocking));
-        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->train_fork, hipEventDisableTiming));
-        HN_HIP(ctx, hipEventCreateWithFlags(&ctx->train_join, hipEventDisableTiming));
+    if (lanes == 2) {   // lane 1's chain: a stream that demonstrably overlaps with the caller's (hn_internal.h: SidePick)
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing((hipStream_t)stream, &cs);
+        const hipStream_t ref = (hipStream_t)stream;
+        if ((rc = side_stream_for(ctx, 7, &ref, 1, cs == hipStreamCaptureStatusNone, &ctx->train_stream)) != HN_OK) return rc;
+        if (ctx->train_fork == nullptr) {
+            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->train_fork, hipEventDisableTiming));
+            HN_HIP(ctx, hipEventCreateWithFlags(&ctx->train_join, hipEventDisableTiming));
+        }
     }
     const hipStream_t ls[2] = {s, lanes == 2 ? ctx->train_stream : s};
     // Under stream capture (a caller recording the step into a HIP graph) nothing may wait on the host: the job tables of a captured
@@ -1799,8 +1803,12 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     // The window is narrow [measured, profiles/r4_train_wgcap.txt]: below ~200 k pixels per call the step is all launch floor (nothing to hide behind), above
     // ~1 M the chain fills the chip by itself (a cap costs what it hides; the plain side stream is still -2 %).  Mode 1 keeps the launches' block counts (bit-identical
     // to mode 0); mode 2 (default) applies the cap, i.e. another -- fixed -- order of the partial sums.
-    for (int l = 0; l < lanes; ++l)   // the side stream that demonstrably overlaps with this lane's chain (hn_internal.h: SidePick)
-        if ((rc = side_stream_for(ctx, 1 + l, &ls[l], 1, !capturing, &ws[l]->wg_stream)) != HN_OK) return rc;
+    {   // the side stream(s) that demonstrably overlap with the chain(s) -- and, with two lanes, with each other (hn_internal.h: SidePick)
+        const hipStream_t r0[2] = {ls[0], ls[1]};
+        if ((rc = side_stream_for(ctx, 1, r0, lanes, !capturing, &ws[0]->wg_stream)) != HN_OK) return rc;
+        const hipStream_t r1[3] = {ls[0], ls[1], ws[0]->wg_stream};
+        if (lanes == 2 && (rc = side_stream_for(ctx, 2, r1, 3, !capturing, &ws[1]->wg_stream)) != HN_OK) return rc;
+    }
     for (int l = 0; l < lanes; ++l) {
         const long px = (long)lane_nb[l] * n * n;
         const int mode = ctx->opt_train_overlap;
