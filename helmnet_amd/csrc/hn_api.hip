@@ -190,7 +190,7 @@ int hn_create(hn_ctx** out, int device_id) {
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
                                                             {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}};
-    if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 2 ? 0 : p; }
+    if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 3 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
         if (const char* v = getenv(k.env)) {
@@ -684,7 +684,7 @@ int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, b
     };
     int rc;
     if (ctx->opt_side_priority != 0) {   // A/B: no probing
-        const int i = ctx->opt_side_priority == 1 ? 1 : 0;
+        const int i = ctx->opt_side_priority == 1 ? 1 : ctx->opt_side_priority == 3 ? 2 : 0;
         if ((rc = cand(i)) != HN_OK) return rc;
         *out = pk.cand[i];
         return HN_OK;

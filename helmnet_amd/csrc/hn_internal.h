@@ -137,7 +137,7 @@ struct hn_ctx {
     // tuning knobs (hn_set_option; defaults from HN_STREAMS / HN_SIDE_STREAM / HN_GRAPH at hn_create only)
     int opt_lanes = 1;         // hn_step pipelines this many sub-batches on internal streams
     int opt_side_stream = 1;   // conv_state kernels on a side stream, overlapping the deep levels
-    int opt_side_priority = 0;     // HN_SIDE_PRIORITY: 0 (default) probe (above); 1 / 2 (A/B): the lowest- / normal-priority candidate without probing
+    int opt_side_priority = 0;     // HN_SIDE_PRIORITY: 0 (default) probe (above); 1 / 2 / 3 (A/B): the lowest- / normal- / highest-priority candidate without probing
     int opt_defer_join = 0;    // HN_DEFER_JOIN=1 (A/B): hn_step joins the side stream behind the NEXT iteration's input layer instead of at the end of
                                // the UNet -- measured no gain (1902 / 1927 / 1938 vs 1932 / 1933 / 1946 it/s, r3): the ~6 us bubble is the event
                                // packet itself, wherever it sits
