@@ -113,6 +113,7 @@ void free_workspace(hn_ctx* c) {
         (void)hipFree(c->buf_a[d]); c->buf_a[d] = nullptr;
         (void)hipFree(c->buf_y[d]); c->buf_y[d] = nullptr;
         if (d < kMaxDepth) { (void)hipFree(c->buf_o[d]); c->buf_o[d] = nullptr; }
+        if (d < 2) { (void)hipFree(c->buf_p[d]); c->buf_p[d] = nullptr; }
     }
     (void)hipFree(c->st_tmp); c->st_tmp = nullptr;
     c->cap_batch = 0;
@@ -189,7 +190,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}};
+                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_SKIP_PRE", HN_OPT_SKIP_PRE}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 3 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -262,6 +263,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_OVERLAP must be 0, 1 or 2 (got %d)", value);
             ctx->opt_train_overlap = value;
             break;
+        case HN_OPT_SKIP_PRE:
+            if (value < 0 || value > 7) return fail(ctx, HN_ERR_ARG, "HN_OPT_SKIP_PRE must be a sum of 1 (level 0), 2 (level 1), 4 (one join) (got %d)", value);
+            ctx->opt_skip_pre = value;
+            break;
         case HN_OPT_DC_WINO:
             if (value < 0 || value > 63 || (value & 4))
                 return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_WINO must be a sum of 1 (inc), 2 (conv_signal), 8 (decoder), 16 / 32 (conv_signal / decoder one level down) (got %d)", value);
@@ -307,6 +312,7 @@ void hn_destroy(hn_ctx* ctx) {
         if (j >= 2 && sl.stream) (void)hipStreamDestroy(sl.stream);   // (lanes 0 and 1: candidates of ctx->picks)
         for (int d = 0; d < kMaxDepth; ++d) (void)hipEventDestroy(sl.ev[d]);
         (void)hipEventDestroy(sl.done);
+        if (sl.pre_done) (void)hipEventDestroy(sl.pre_done);
     }
     for (auto& pk : ctx->picks)
         for (hipStream_t& c : pk.cand)
@@ -499,6 +505,7 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
         HN_HIP(ctx, hipMalloc((void**)&ctx->buf_a[d], bytes));
         if (d < depth) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_o[d], bytes));
         if (d > 0) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_y[d], bytes));
+        if (d < 2 && d < depth) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_p[d], bytes));
     }
     HN_HIP(ctx, hipMalloc((void**)&ctx->st_tmp, sizeof(float) * (size_t)max_batch * kState * ctx->state_len));
     ctx->cap_batch = max_batch;
@@ -738,6 +745,7 @@ int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, hipStream_t calle
             if (sl.done) continue;
             for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&sl.ev[d], hipEventDisableTiming));
             HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            HN_HIP(ctx, hipEventCreateWithFlags(&sl.pre_done, hipEventDisableTiming));
         }
     }
     return HN_OK;

@@ -152,6 +152,9 @@ struct hn_ctx {
     bool cols_t_attr_set = false, cols512_attr_set = false;
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     int opt_dc_valu = 1;       // fp32 DoubleConvs of the big levels on the packed vector FMA (hn_dcv.hip): 0 none, 1 inc + decoder, 2 all
+    int opt_skip_pre = 0;      // HN_OPT_SKIP_PRE: bit d (d = 0, 1): the skip half of decode_d's first convolution runs ahead of time on the side stream, in
+                               // the shadow of the small levels (hn_dcv.hip: k_conv3_pre); needs the side stream (policy 1) and the vector-pipe decoder.
+                               // bit 2 (A/B): ONE join in front of the first such decoder for everything on the side stream instead of an event of its own
     int opt_dc_wino = 0;       // level-0 DoubleConvs as Winograd F(2x2, 3x3) on the vector FMA (hn_wino.hip): bit mask over the kinds
                                // (1 inc, 2 conv_signal, 8 decoder), 0 none
     const float* zero_page = nullptr;   // 256 zero bytes (out-of-image staging loads of hn_wino.hip)
@@ -166,12 +169,13 @@ struct hn_ctx {
     float* buf_a[hn::kMaxDepth + 1]{};  // x_d, later reused for the upsampled tensor u_d
     float* buf_o[hn::kMaxDepth]{};      // out_d (skip connections)
     float* buf_y[hn::kMaxDepth + 1]{};  // decoder outputs y_d
+    float* buf_p[2]{};                  // levels 0, 1: the skip half of the decoder's first convolution, summed ahead of time on the side stream (opt_skip_pre)
     float* st_tmp = nullptr;            // second flat state buffer for hn_step ping-pong
     // hn_step pipelines sub-batches on internal streams (samples are independent): while one
     // sub-batch walks the small, latency-bound UNet levels the other one keeps the CUs busy
     // conv_state kernels run on a side stream per pipeline lane (HN_SIDE_STREAM, hn_step only)
     struct SideLane {
-        hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr; hipEvent_t pre_done = nullptr;
         bool pending = false;   // `done` has been recorded on the side stream and not been waited for yet (deferred join, hn_step)
     };
     SideLane side[8];          // (lane 0's stream belongs to picks[0]: side_stream_for)
@@ -290,7 +294,8 @@ enum KernelId : int {
     KID_SPEC_ROWS = 33,   // spectral row pass + residual terms (or the dense operator)
     KID_DEEP = 34,        // deepest level in one per-sample kernel: conv_signal, conv_state, down, bottleneck, up, decoder
     KID_SPEC_PAIR = 35,   // one bracket around both spectral passes (the HBM-bound part of the path as a whole)
-    KID_COUNT = 36
+    KID_PRE0 = 36,        // + d (d = 0, 1): skip half of decode_d's conv1 ahead of time (side stream)
+    KID_COUNT = 38
 };
 
 // RAII event pair around one launch when that kernel id is selected by hn_profile_enable.
@@ -345,7 +350,7 @@ void pack_frag_down_x16(const float* w_oihw, float* dst_split, float* dst_half);
 void pack_frag_up_x16(const float* w_iohw, float* dst_split, float* dst_half);
 // kind: 0 inc (2+2+2 ch), 1 conv_signal (8+2), 2 bottleneck (8), 3 decoder (8+8; final_epi adds outc + wf update)
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
-               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
+               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s, const Src* pin = nullptr);
 // training forward: the fused matrix-core DoubleConv with the pre-activation mid tensor stored to `z` ([B, 8, H, W]); fragments as pack_frag_3x3
 bool dc8_tape_applies(int H, int W);
 // Backward-data pass of an 8-channel DoubleConv (cin -> 8 -> 8) on the fp32 matrix core (hn_mfma.hip, k_dc_bwd_mfma_p): g_z = conv2^T(g) * act'(z),
@@ -386,7 +391,9 @@ void pack_valu_q(const float* w_oihw, int cin, float* dst);            // conv1 
 void pack_outc3x3_valu(const float* w2, const float* wo, float* dst);   // conv2 composed with the out-conv -> [8 cm][3][3][2]
 bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
 void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
-                    int W, int batch, hipStream_t s);
+                    int W, int batch, hipStream_t s, const Src* pin = nullptr);
+// the skip half of decoder w's first convolution ahead of time: p = b1 + conv3x3(skip; W1[:, 8:16]); the decoder then takes it as `pin`
+void launch_skip_pre(Src skip, Dst p, const DcW& w, int H, int W, int batch, hipStream_t s);
 
 // ---- Winograd F(2x2, 3x3) DoubleConv of the big levels (hn_wino.hip) ----
 void pack_wino(const float* w_oihw, int cin, const float* scale, float* dst);   // [8][cin][3][3] -> [cin][2][8][8]

@@ -99,6 +99,13 @@ enum hn_option {
                               * training sizes) and 32 (with 4 and 16: conv_state's backward-data pass rides in the decoder's launch of the same level,
                               * k_dc_bwd_mfma_aux; d loss / d out is added up in one accumulator: fp32 rounding); default 55, 0: every convolution as its own
                               * launch (round 3)                                                                                         */
+    HN_OPT_SKIP_PRE = 12,    /* hn_step: the skip half of a decoder's first convolution (decode_d's conv1 runs over cat[up(x), skip_d],
+                              * architectures.py:458-460, and is linear in its input channels) summed ahead of time on the library side stream,
+                              * beside the small levels of the main chain; the decoder then starts from that sum and walks the upsampled half
+                              * only.  Sum of 1 (level 0), 2 (level 1; both only where the vector-pipe decoder runs, HN_OPT_DC_VALU >= 1 and
+                              * W >= 256, and with HN_OPT_SIDE_STREAM 1), 4 (A/B: one join for everything on the side stream); default 0: [measured, r5] the
+                              * decoder gains 17 us and the small levels beside the longer side stream lose as much (1905-1933 vs 1920-1941 it/s).
+                              * The same fp32 products summed skip half first: agrees with 0 to fp32 rounding                    */
     HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: where the three weight-gradient launches of unrolled iteration t run.  0: in line on the
                               * caller's stream.  1: on a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers), the
                               * same launches: bit-identical gradients, and measured equal (their blocks hold the CUs' LDS; the chain slows down by what the
@@ -297,10 +304,11 @@ int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_
  *   20+2d up(d) | 21+2d decoder(d) (d=0 includes outc + wavefield update) |
  *   32 spectral column pass | 33 spectral row pass (or the dense operator) |
  *   34 the fused deepest level (conv_signal, conv_state, down, bottleneck, up, decoder of level depth-1 in one kernel;
- *      those six ids then do not occur) | 35 both spectral passes under ONE event pair.
+ *      those six ids then do not occur) | 35 both spectral passes under ONE event pair
+ *      | 36 + d (d = 0, 1) the skip half of decode_d's first convolution ahead of time (side stream, HN_OPT_SKIP_PRE).
  * hn_profile_collect synchronises the recorded events, returns per-id total milliseconds and
  * launch counts for ids [0, n_ids) and resets the accumulators. */
-#define HN_KERNEL_IDS 36
+#define HN_KERNEL_IDS 38
 int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
 /* Bracket only every `every_nth` launch of a selected kernel (default 1), starting every_nth / 2 launches in.  An event pair
  * costs a few microseconds of stream gap, so timed runs sample instead of bracketing every launch. */

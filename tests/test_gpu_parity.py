@@ -501,6 +501,48 @@ def test_winograd_doubleconvs_match_the_direct_ones_and_the_oracle(weights, n, b
         assert not torch.equal(outs[mask][0], outs[0][0])   # another kernel did run
 
 
+@pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])
+def test_skip_half_of_the_decoder_ahead_of_time_matches_the_plain_decoder_and_the_oracle(weights, n, b):
+    """HN_OPT_SKIP_PRE (hn_dcv.hip: k_conv3_pre on the side stream + k_dc_valu<..., PIN>): decode_d's first convolution over cat[up(x), skip]
+    (architectures.py:458-460) with the skip half summed ahead of time, against the one-kernel decoder (option 0) and the oracle.  The same
+    fp32 products summed skip half first: within 4e-6 * max of the plain decoder and 1e-5 * max of the oracle.  At 512 level 1 (W = 256)
+    takes the path too (masks 1, 2, 3); mask 7 joins the side stream once; 320 has partial tiles; several iterations through hn_step, so
+    that the side stream's buffers are reused across iterations."""
+    from helmnet_amd import IterativeSolver
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=31337).items()}
+    src = SRC.get(n, [n // 3, n // 2])
+    outs, runs = {}, {}
+    for mask in (0, 3, 1, 2, 7):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=src)
+        s.engine().set_option("dc_valu", 1)
+        s.engine().set_option("skip_pre", mask)
+        g = {k: v.to(DEV) for k, v in ti.items()}
+        k_sq, _ = s.get_initials(g["sos"])
+        s.f.set_states(g["states"], flatten=True)
+        wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
+        outs[mask] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
+        o = s.forward(g["sos"], num_iterations=12)
+        runs[mask] = (o["wavefields"][0].cpu(), o["residuals"][-1].cpu())
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, src, 10.0), t)
+    want = (want[0], want[1], O.flatten_states(want[2]))
+    for mask in (3, 1, 2, 7):
+        for a, d, w in zip(outs[mask], outs[0], want):
+            scale = w.abs().max().item()
+            assert (a - d).abs().max().item() <= 4e-6 * scale, (mask, (a - d).abs().max().item() / scale)
+            assert (a - w).abs().max().item() <= 1e-5 * scale, (mask, (a - w).abs().max().item() / scale)
+        for a, d in zip(runs[mask], runs[0]):   # 12 free-running iterations: rounding differences grow, slowly
+            assert (a - d).abs().max().item() <= 1e-4 * d.abs().max().item(), (mask, (a - d).abs().max().item() / d.abs().max().item())
+    assert not torch.equal(outs[1][0], outs[0][0])                       # the pin decoder did run at level 0
+    assert torch.equal(outs[7][0], outs[3][0])                           # the join policy changes no bit
+    if n >= 512:
+        assert not torch.equal(outs[2][0], outs[0][0]) and not torch.equal(outs[3][0], outs[1][0])   # ... and at level 1
+    else:
+        assert torch.equal(outs[2][0], outs[0][0])                       # W = 128 stays on the matrix core: mask 2 is a no-op at 256 / 320
+
+
 def test_graph_replay_is_bit_identical_to_kernel_by_kernel_launches(solver):
     """HN_OPT_GRAPH: one captured iteration per graph, and 4 iterations per graph, against the default launches -- the
     same kernels with the same arguments in the same order, so every output bit agrees (the RMSE history goes through
