@@ -67,7 +67,7 @@ struct Packer {
     DcW dc(int cin, int cm, int co) {
         DcW w;
         w.act = act;
-        w.w1q = nullptr;   // set by hn_load_weights for the 8-channel DoubleConvs
+        w.w1q = w.wa = nullptr;   // set by hn_load_weights for the 8-channel DoubleConvs
         w.u1 = w.u2 = nullptr;
         repack_oihw(src + pos, dst.data() + pos, cm, cin, 9);
         w.w1 = dev + pos; pos += (size_t)cm * cin * 9;
@@ -240,7 +240,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             ctx->opt_pfa = value;
             break;
         case HN_OPT_DC_VALU:
-            if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0, 1 or 2 (got %d)", value);
+            if (value < 0 || value > 4) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0 .. 4 (got %d)", value);
             ctx->opt_dc_valu = value;
             break;
         case HN_OPT_SPECTRAL_RADIX16:
@@ -366,7 +366,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     HN_HIP(ctx, hipMemcpy(ctx->wdev, packed.data(), want * sizeof(float), hipMemcpyHostToDevice));
     {   // A-operand fragments for the matrix-core kernels, built from the original OIHW tensors
         std::vector<float> fr;
-        std::vector<size_t> off, offq, offu;   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order; offu: its
+        std::vector<size_t> off, offq, offu, offa;   // offa: conv1 for the hand-scheduled kernel (hn_dca.hip)   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order; offu: its
                                                // two convolutions in the Winograd domain (hn_wino.hip)
         size_t pos = 0;
         auto dc = [&](int cin, int cm, int co) {  // returns offsets of (frag1, frag2) or (npos, npos)
@@ -378,6 +378,10 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
                 return;
             }
             offq.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 72); pack_valu_q(w1, cin, fr.data() + offq.back());
+            {
+                static const float inc_scale_a[kInCh] = {1.f, 1.f, 1000.f, 1000.f, 1.f, 1.f};
+                offa.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 72); pack_dca(w1, cin, cin == kInCh ? inc_scale_a : nullptr, fr.data() + offa.back());
+            }
             {   // U = G g G^T; the input layer (cin == 6) carries the reference's 1e3 on its residual channels (hybridnet.py:566)
                 static const float inc_scale[kInCh] = {1.f, 1.f, 1000.f, 1000.f, 1.f, 1.f};
                 offu.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 128); pack_wino(w1, cin, cin == kInCh ? inc_scale : nullptr, fr.data() + offu.back());
@@ -444,6 +448,10 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             ctx->inc.w1q = ctx->fragdev + offq[iq++];
             for (int d = 0; d < depth; ++d) ctx->sig[d].w1q = ctx->fragdev + offq[iq++];
             for (int d = 0; d <= depth; ++d) ctx->dec[d].w1q = ctx->fragdev + offq[iq++];
+            size_t ia = 0;
+            ctx->inc.wa = ctx->fragdev + offa[ia++];
+            for (int d = 0; d < depth; ++d) ctx->sig[d].wa = ctx->fragdev + offa[ia++];
+            for (int d = 0; d <= depth; ++d) ctx->dec[d].wa = ctx->fragdev + offa[ia++];
             size_t iu = 0;
             auto setu = [&](DcW& w) { w.u1 = ctx->fragdev + offu[iu++]; w.u2 = ctx->fragdev + offu[iu++]; };
             setu(ctx->inc);

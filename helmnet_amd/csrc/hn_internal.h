@@ -40,6 +40,7 @@ struct DcW {
     const float* b2;
     int act;   // hn_act
     const float* w1q;   // conv1 again as [cin][2 channel halves][3][3][4] (8-channel DoubleConvs only; hn_dcv.hip)
+    const float* wa;    // conv1 again as [cin][3 kx][3 ky][8] with the input scales folded in (8-channel DoubleConvs only; hn_dca.hip)
     const float *u1, *u2;   // both convolutions in the Winograd F(2x2, 3x3) domain: [cin][2 halves][8 freq][8 cout] (hn_wino.hip)
 };
 
@@ -151,7 +152,8 @@ struct hn_ctx {
     int opt_cols_t = 1;        // 256-point column pass through an LDS transpose: 0 the r2 kernel (16-byte global accesses), 1: 16 columns per block, 2: 32
     bool cols_t_attr_set = false, cols512_attr_set = false;
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
-    int opt_dc_valu = 1;       // fp32 DoubleConvs of the big levels on the packed vector FMA (hn_dcv.hip): 0 none, 1 inc + decoder, 2 all
+    int opt_dc_valu = 1;       // fp32 DoubleConvs of the big levels on the packed vector FMA: 0 none, 1 inc + decoder (hn_dcv.hip), 2 all three;
+                               // 3 / 4: the same two / three on the hand-scheduled kernel (hn_dca.hip)
     int opt_skip_pre = 0;      // HN_OPT_SKIP_PRE: bit d (d = 0, 1): the skip half of decode_d's first convolution runs ahead of time on the side stream, in
                                // the shadow of the small levels (hn_dcv.hip: k_conv3_pre); needs the side stream (policy 1) and the vector-pipe decoder.
                                // bit 2 (A/B): ONE join in front of the first such decoder for everything on the side stream instead of an event of its own
@@ -394,6 +396,12 @@ void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const D
                     int W, int batch, hipStream_t s, const Src* pin = nullptr);
 // the skip half of decoder w's first convolution ahead of time: p = b1 + conv3x3(skip; W1[:, 8:16]); the decoder then takes it as `pin`
 void launch_skip_pre(Src skip, Dst p, const DcW& w, int H, int W, int batch, hipStream_t s);
+
+// ---- the same with a hand-scheduled conv1 loop and LDS-direct staging (hn_dca.hip) ----
+void pack_dca(const float* w_oihw, int cin, const float* scale, float* dst);   // conv1 [8][cin][3][3] -> [cin][3 kx][3 ky][8]
+bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
+void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H, int W,
+                   int batch, hipStream_t s);
 
 // ---- Winograd F(2x2, 3x3) DoubleConv of the big levels (hn_wino.hip) ----
 void pack_wino(const float* w_oihw, int cin, const float* scale, float* dst);   // [8][cin][3][3] -> [cin][2][8][8]

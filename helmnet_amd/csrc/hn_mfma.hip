@@ -2573,6 +2573,10 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
         launch_dc_wino(ctx, kind, a, b, c, out, w, final_epi, d_out, wf, H, W, batch, s);
         return HN_OK;
     }
+    if (dc_asm_applies(ctx, w.act, a, b, c, kind, H, W)) {
+        launch_dc_asm(ctx, kind, a, b, c, out, w, final_epi, d_out, wf, H, W, batch, s);
+        return HN_OK;
+    }
     if (dc_valu_applies(ctx, w.act, a, b, c, kind, H, W)) {
         launch_dc_valu(ctx, kind, a, b, c, out, w, final_epi, d_out, wf, H, W, batch, s);
         return HN_OK;

@@ -439,17 +439,19 @@ def test_fused_deep_level_kernel_matches_the_layer_by_layer_path(weights):
     assert (outs[1][2][:, :, L3] - want[2][:, :, L3]).abs().max().item() <= 1e-5 * want[2][:, :, L3].abs().max().item()
 
 
-@pytest.mark.parametrize("n,b", [(256, 2), (512, 1)])
+@pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])
 def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weights, n, b):
-    """hn_dcv.hip (level-0 DoubleConvs on v_pk_fma_f32, the default at W >= 256) against the fp32 matrix-core kernels
-    (HN_OPT_DC_VALU = 0) and against the oracle: the same fp32 FMAs in another order, so both sit within 1e-5 * max of the
-    oracle and within 4e-6 * max of each other; at 512 the option also covers level 1 (W = 256)."""
+    """The level-0 DoubleConvs on v_pk_fma_f32 -- hn_dca.hip (hand-scheduled conv1 loop, LDS-direct staging; HN_OPT_DC_VALU 3 / 4) and
+    hn_dcv.hip (compiler-scheduled; 1 / 2) -- against the fp32 matrix-core kernels (0) and against the oracle: the same fp32 FMAs in
+    another order, so all sit within 1e-5 * max of the oracle and within 4e-6 * max of each other; at 512 the option also covers
+    level 1 (W = 256); 320 has partial tiles (out-of-image float4s of the LDS-direct loads read the zero page)."""
     from helmnet_amd import IterativeSolver
     ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=777).items()}
+    src = SRC.get(n, [n // 3, n // 2])
     outs = {}
-    for valu in (2, 1, 0):   # all three level-0 DoubleConvs on the vector pipe / inc + decoder (the default) / none
+    for valu in (4, 3, 2, 1, 0):   # all three level-0 DoubleConvs / inc + decoder on the hand-scheduled kernel; the same on hn_dcv.hip; none
         s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
-        s.set_domain_size(n, source_location=SRC[n])
+        s.set_domain_size(n, source_location=src)
         s.engine().set_option("dc_wino", 0)   # (the Winograd kernels would take the level-0 DoubleConvs whatever dc_valu says)
         s.engine().set_option("dc_valu", valu)
         g = {k: v.to(DEV) for k, v in ti.items()}
@@ -459,15 +461,17 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
         outs[valu] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
     t = O.SpectralTables(n, 8, 2, 1.0)
     k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
-    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, SRC[n], 10.0), t)
+    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, src, 10.0), t)
     want = (want[0], want[1], O.flatten_states(want[2]))
-    for a2, a, bb, w in zip(outs[2], outs[1], outs[0], want):
-        scale = w.abs().max().item()
-        assert (a - bb).abs().max().item() <= 4e-6 * scale and (a2 - bb).abs().max().item() <= 4e-6 * scale
-        assert (a - w).abs().max().item() <= 1e-5 * scale
-        assert (a2 - w).abs().max().item() <= 1e-5 * scale
-        assert (bb - w).abs().max().item() <= 1e-5 * scale
-    assert not torch.equal(outs[1][0], outs[0][0]) and not torch.equal(outs[2][0], outs[1][0])   # three different kernel sets did run
+    for valu in (4, 3, 2, 1):
+        for a, bb, w in zip(outs[valu], outs[0], want):
+            scale = w.abs().max().item()
+            assert (a - bb).abs().max().item() <= 4e-6 * scale, (valu, (a - bb).abs().max().item() / scale)
+            assert (a - w).abs().max().item() <= 1e-5 * scale, (valu, (a - w).abs().max().item() / scale)
+    for a, w in zip(outs[0], want):
+        assert (a - w).abs().max().item() <= 1e-5 * w.abs().max().item()
+    wfs = [outs[v][0] for v in (4, 3, 2, 1, 0)]
+    assert all(not torch.equal(wfs[i], wfs[j]) for i in range(5) for j in range(i))   # five different kernel sets did run
 
 
 @pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])
