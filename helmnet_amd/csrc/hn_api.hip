@@ -190,7 +190,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_SKIP_PRE", HN_OPT_SKIP_PRE}};
+                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_SKIP_PRE", HN_OPT_SKIP_PRE}, {"HN_DC_VALU", HN_OPT_DC_VALU}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 3 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -240,7 +240,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             ctx->opt_pfa = value;
             break;
         case HN_OPT_DC_VALU:
-            if (value < 0 || value > 4) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0 .. 4 (got %d)", value);
+            if (value < 0 || value > 6) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0 .. 6 (got %d)", value);
             ctx->opt_dc_valu = value;
             break;
         case HN_OPT_SPECTRAL_RADIX16:

@@ -446,7 +446,7 @@ bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, 
     // pipe.  [measured on four boxes, 3 x 300 steps each] all-vector 1808 / 1987 / 1873 / 1929 it/s, all-matrix 1884 / 1902 / 1904 /
     // 1894, this mix 1887 / 1982 / 1925 / 1919: the packed-FMA kernels pull the shader clock down (median 2.22-2.30 GHz in the loop
     // instead of a held 2.40, tools/clock_probe.py) by an amount that depends on the box, and every other kernel pays for it.
-    if ((ctx->opt_dc_valu == 1 || ctx->opt_dc_valu == 3) && kind == 1) return false;   // (3 / 4: hn_dca.hip takes what it can; the rest falls through to here)
+    if ((ctx->opt_dc_valu == 1 || ctx->opt_dc_valu == 3 || ctx->opt_dc_valu == 5) && kind == 1) return false;   // (3 / 4: hn_dca.hip takes what it can; the rest falls through to here)
 #ifdef HN_EXP_MFMA_KINDS
     if ((HN_EXP_MFMA_KINDS >> kind) & 1) return false;   // A/B: these DoubleConv kinds stay on the matrix core
 #endif

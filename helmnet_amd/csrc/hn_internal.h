@@ -152,8 +152,8 @@ struct hn_ctx {
     int opt_cols_t = 1;        // 256-point column pass through an LDS transpose: 0 the r2 kernel (16-byte global accesses), 1: 16 columns per block, 2: 32
     bool cols_t_attr_set = false, cols512_attr_set = false;
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
-    int opt_dc_valu = 1;       // fp32 DoubleConvs of the big levels on the packed vector FMA: 0 none, 1 inc + decoder (hn_dcv.hip), 2 all three;
-                               // 3 / 4: the same two / three on the hand-scheduled kernel (hn_dca.hip)
+    int opt_dc_valu = 4;       // fp32 DoubleConvs of the big levels on the packed vector FMA: 0 none, 1 inc + decoder (hn_dcv.hip), 2 all three;
+                               // 3 / 4 (default): the same two / three on the hand-scheduled kernel (hn_dca.hip); 5 / 6: its two-wavefront form
     int opt_skip_pre = 0;      // HN_OPT_SKIP_PRE: bit d (d = 0, 1): the skip half of decode_d's first convolution runs ahead of time on the side stream, in
                                // the shadow of the small levels (hn_dcv.hip: k_conv3_pre); needs the side stream (policy 1) and the vector-pipe decoder.
                                // bit 2 (A/B): ONE join in front of the first such decoder for everything on the side stream instead of an event of its own

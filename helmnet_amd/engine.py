@@ -193,7 +193,7 @@ class Engine:
 
     def set_option(self, name: str, value: int):
         """Library tuning knobs (enum hn_option of include/helmnet_hip.h): 'lanes' 1..8, 'side_stream' 0..3, 'graph' 0, 1 or an even
-        number <= 64 of iterations per graph, 'deep' 0/1, 'spectral_pfa' 0/1, 'spectral_radix16' 0..2, 'dc_valu' 0..2,
+        number <= 64 of iterations per graph, 'deep' 0/1, 'spectral_pfa' 0/1, 'spectral_radix16' 0..2, 'dc_valu' 0..6,
         'spectral_cols' 0..2, 'train_lanes' 1/2 (hn_train_grad: the halves of the batch as two chains of launches on two streams).
         'spectral_pfa' is read when the spectral tables are built: changing it re-builds them."""
         if name not in _lib.HN_OPTION:

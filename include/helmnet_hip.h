@@ -76,8 +76,10 @@ enum hn_option {
                               * read by the next hn_set_domain)                                                     */
     HN_OPT_SPECTRAL_RADIX16 = 5, /* 256-point lines: 0 the radix-4 kernels, 1 radix-16 columns + 8x4x8 rows (default), 2 radix-16 rows too */
     HN_OPT_DC_VALU = 6,      /* fp32 DoubleConvs of the largest level (W >= 256) on the packed vector FMA (every FMA useful, same peak as the
-                              * fp32 MFMA, whose 3x3 packing fills 75 % of its slots): 0 none (matrix core), 1 inc and the decoder
-                              * (default; conv_signal stays on the matrix core: the vector kernels lower the sustained clock), 2 all three */
+                              * fp32 MFMA, whose 3x3 packing fills 75 % of its slots): 0 none (matrix core); 1 inc and the decoder, 2 all three on the
+                              * compiler-scheduled kernel (hn_dcv.hip); 3 inc and the decoder, 4 (default) all three on the hand-scheduled kernel
+                              * (hn_dca.hip: all 8 mid channels per wavefront, LDS-direct staging; [measured, r5] +3 % it/s over 1); 5 / 6 its
+                              * two-wavefront form (one round of blocks; measured behind 4) */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
     HN_OPT_TRAIN_LANES = 8,  /* hn_train_grad: 1 (default) the whole batch as one chain of launches; 2: the two halves of the batch as

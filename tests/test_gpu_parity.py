@@ -449,7 +449,7 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
     ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=777).items()}
     src = SRC.get(n, [n // 3, n // 2])
     outs = {}
-    for valu in (4, 3, 2, 1, 0):   # all three level-0 DoubleConvs / inc + decoder on the hand-scheduled kernel; the same on hn_dcv.hip; none
+    for valu in (6, 5, 4, 3, 2, 1, 0):   # all three level-0 DoubleConvs / inc + decoder on the hand-scheduled kernels (two-wave blocks: 6 / 5; four-wave: 4 / 3); the same on hn_dcv.hip; none
         s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
         s.set_domain_size(n, source_location=src)
         s.engine().set_option("dc_wino", 0)   # (the Winograd kernels would take the level-0 DoubleConvs whatever dc_valu says)
@@ -463,15 +463,15 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
     k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
     want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, src, 10.0), t)
     want = (want[0], want[1], O.flatten_states(want[2]))
-    for valu in (4, 3, 2, 1):
+    for valu in (6, 5, 4, 3, 2, 1):
         for a, bb, w in zip(outs[valu], outs[0], want):
             scale = w.abs().max().item()
             assert (a - bb).abs().max().item() <= 4e-6 * scale, (valu, (a - bb).abs().max().item() / scale)
             assert (a - w).abs().max().item() <= 1e-5 * scale, (valu, (a - w).abs().max().item() / scale)
     for a, w in zip(outs[0], want):
         assert (a - w).abs().max().item() <= 1e-5 * w.abs().max().item()
-    wfs = [outs[v][0] for v in (4, 3, 2, 1, 0)]
-    assert all(not torch.equal(wfs[i], wfs[j]) for i in range(5) for j in range(i))   # five different kernel sets did run
+    wfs = [outs[v][0] for v in (6, 5, 4, 3, 2, 1, 0)]
+    assert all(not torch.equal(wfs[i], wfs[j]) for i in range(7) for j in range(i))   # seven different kernel sets did run
 
 
 @pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])

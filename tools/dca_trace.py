@@ -10,7 +10,7 @@ from helmnet_amd.phantoms import ring_sos_batch
 s = IterativeSolver.from_exported_weights(); s.freeze(); s.to("cuda:0")
 s.set_domain_size(256, source_location=[30, 128])
 sos = torch.from_numpy(ring_sos_batch(256, 32, seed=0)).cuda()
-eng = s.engine(); eng.reserve(32); eng.set_option("dc_valu", 4)
+eng = s.engine(); eng.reserve(32); eng.set_option("dc_valu", int(sys.argv[2]) if len(sys.argv) > 2 else 4)
 k_sq, wf = s.get_initials(sos); s.f.clear_states(wf); res = s.get_residual(wf, k_sq)
 st = s.f.get_states(flatten=True).contiguous(); k_sq = k_sq.contiguous(); src = s.source.detach().contiguous()
 eng.step(wf, res, st, k_sq, src, 300); torch.cuda.synchronize()
@@ -20,7 +20,7 @@ rc = lib.hn_debug_dca_trace(buf.ctypes.data_as(ctypes.c_void_p)); assert rc == 0
 t = buf[:2048, :7].astype(np.int64); hw = buf[:2048, 7]
 t0 = t[:, 0].min(); t = (t - t0) * 0.01   # us
 print("kernel span (first block start .. last block end): %.1f us" % (t[:, 6].max()))
-names = ["plan+first issue", "conv1 loop", "barrier A", "exchange+finish", "conv2 setup+barrier", "conv2 loop", ]
+names = ["plan+first issue", "conv1 loop", "barrier A", "exchange+finish | put half 0", "conv2 setup+barrier | conv2 half 0", "conv2 loop | put half 1 + conv2 half 1", ]
 for i, nme in enumerate(names):
     d = t[:, i + 1] - t[:, i]
     print(f"  {nme:22s} mean {d.mean():6.2f} us  median {np.median(d):6.2f}  p95 {np.percentile(d, 95):6.2f}")
