@@ -68,7 +68,6 @@ struct Packer {
         DcW w;
         w.act = act;
         w.w1q = w.wa = nullptr;   // set by hn_load_weights for the 8-channel DoubleConvs
-        w.u1 = w.u2 = nullptr;
         repack_oihw(src + pos, dst.data() + pos, cm, cin, 9);
         w.w1 = dev + pos; pos += (size_t)cm * cin * 9;
         std::memcpy(dst.data() + pos, src + pos, sizeof(float) * cm);
@@ -113,7 +112,6 @@ void free_workspace(hn_ctx* c) {
         (void)hipFree(c->buf_a[d]); c->buf_a[d] = nullptr;
         (void)hipFree(c->buf_y[d]); c->buf_y[d] = nullptr;
         if (d < kMaxDepth) { (void)hipFree(c->buf_o[d]); c->buf_o[d] = nullptr; }
-        if (d < 2) { (void)hipFree(c->buf_p[d]); c->buf_p[d] = nullptr; }
     }
     (void)hipFree(c->st_tmp); c->st_tmp = nullptr;
     c->cap_batch = 0;
@@ -189,8 +187,8 @@ int hn_create(hn_ctx** out, int device_id) {
         if (hn_set_unet_precision(c, mode) != HN_OK) return bad_env("HN_UNET_IMPL", v);
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
-                                                            {"HN_GRAPH", HN_OPT_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_OPT_TRAIN_LANES}, {"HN_DC_WINO", HN_OPT_DC_WINO}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_SKIP_PRE", HN_OPT_SKIP_PRE}, {"HN_DC_VALU", HN_OPT_DC_VALU}};
+                                                            {"HN_GRAPH", HN_EXP_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
+                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 3 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -226,9 +224,9 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             if (value < 0 || value > 3) return fail(ctx, HN_ERR_ARG, "HN_OPT_SIDE_STREAM must be in [0, 3] (got %d)", value);
             ctx->opt_side_stream = value;
             break;
-        case HN_OPT_GRAPH:
+        case HN_EXP_GRAPH:
             if (value < 0 || value > 64 || (value > 1 && (value & 1)))
-                return fail(ctx, HN_ERR_ARG, "HN_OPT_GRAPH must be 0, 1 or an even number of iterations per graph <= 64 (got %d)", value);
+                return fail(ctx, HN_ERR_ARG, "HN_EXP_GRAPH must be 0, 1 or an even number of iterations per graph <= 64 (got %d)", value);
             ctx->opt_graph = value;
             break;
         case HN_OPT_DEEP:
@@ -240,7 +238,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             ctx->opt_pfa = value;
             break;
         case HN_OPT_DC_VALU:
-            if (value < 0 || value > 6) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0 .. 6 (got %d)", value);
+            if (value < 0 || value > 4) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0 .. 4 (got %d)", value);
             ctx->opt_dc_valu = value;
             break;
         case HN_OPT_SPECTRAL_RADIX16:
@@ -251,8 +249,8 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_SPECTRAL_COLS must be 0, 1 or 2 (got %d)", value);
             ctx->opt_cols_t = value;
             break;
-        case HN_OPT_TRAIN_LANES:
-            if (value < 1 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_LANES must be 1 or 2 (got %d)", value);
+        case HN_EXP_TRAIN_LANES:
+            if (value < 1 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_EXP_TRAIN_LANES must be 1 or 2 (got %d)", value);
             ctx->opt_train_lanes = value;
             break;
         case HN_OPT_TRAIN_FUSED:
@@ -262,15 +260,6 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_TRAIN_OVERLAP:
             if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_TRAIN_OVERLAP must be 0, 1 or 2 (got %d)", value);
             ctx->opt_train_overlap = value;
-            break;
-        case HN_OPT_SKIP_PRE:
-            if (value < 0 || value > 7) return fail(ctx, HN_ERR_ARG, "HN_OPT_SKIP_PRE must be a sum of 1 (level 0), 2 (level 1), 4 (one join) (got %d)", value);
-            ctx->opt_skip_pre = value;
-            break;
-        case HN_OPT_DC_WINO:
-            if (value < 0 || value > 63 || (value & 4))
-                return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_WINO must be a sum of 1 (inc), 2 (conv_signal), 8 (decoder), 16 / 32 (conv_signal / decoder one level down) (got %d)", value);
-            ctx->opt_dc_wino = value;
             break;
         default: return fail(ctx, HN_ERR_ARG, "hn_set_option: unknown option %d", option);
     }
@@ -284,6 +273,9 @@ int64_t hn_get_counter(const hn_ctx* ctx, int counter) {
         case HN_CNT_GRAPH_REPLAYS: return ctx->graph_replays;
         case HN_CNT_EAGER_ITERATIONS: return ctx->eager_iterations;
         case HN_CNT_GRAPHS_CAPTURED: return ctx->graphs_captured;
+        case HN_CNT_STREAM_PROBES: return ctx->probes_run;
+        case HN_CNT_TRAIN_FWD_EVENTS: return ctx->train_fwd_events;
+        case HN_CNT_SIDE_CANDIDATE: return ctx->picks[0].known.empty() ? -1 : ctx->picks[0].last_chosen;
         default: return -1;
     }
 }
@@ -312,7 +304,6 @@ void hn_destroy(hn_ctx* ctx) {
         if (j >= 2 && sl.stream) (void)hipStreamDestroy(sl.stream);   // (lanes 0 and 1: candidates of ctx->picks)
         for (int d = 0; d < kMaxDepth; ++d) (void)hipEventDestroy(sl.ev[d]);
         (void)hipEventDestroy(sl.done);
-        if (sl.pre_done) (void)hipEventDestroy(sl.pre_done);
     }
     for (auto& pk : ctx->picks)
         for (hipStream_t& c : pk.cand)
@@ -366,7 +357,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     HN_HIP(ctx, hipMemcpy(ctx->wdev, packed.data(), want * sizeof(float), hipMemcpyHostToDevice));
     {   // A-operand fragments for the matrix-core kernels, built from the original OIHW tensors
         std::vector<float> fr;
-        std::vector<size_t> off, offq, offu, offa;   // offa: conv1 for the hand-scheduled kernel (hn_dca.hip)   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order; offu: its
+        std::vector<size_t> off, offq, offa;   // offq / offa: conv1 of every 8-channel DoubleConv re-packed for hn_dcv.hip / hn_dca.hip, in blob order   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order; offu: its
                                                // two convolutions in the Winograd domain (hn_wino.hip)
         size_t pos = 0;
         auto dc = [&](int cin, int cm, int co) {  // returns offsets of (frag1, frag2) or (npos, npos)
@@ -381,11 +372,6 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             {
                 static const float inc_scale_a[kInCh] = {1.f, 1.f, 1000.f, 1000.f, 1.f, 1.f};
                 offa.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 72); pack_dca(w1, cin, cin == kInCh ? inc_scale_a : nullptr, fr.data() + offa.back());
-            }
-            {   // U = G g G^T; the input layer (cin == 6) carries the reference's 1e3 on its residual channels (hybridnet.py:566)
-                static const float inc_scale[kInCh] = {1.f, 1.f, 1000.f, 1000.f, 1.f, 1.f};
-                offu.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 128); pack_wino(w1, cin, cin == kInCh ? inc_scale : nullptr, fr.data() + offu.back());
-                offu.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * 128); pack_wino(w2, kFeat, nullptr, fr.data() + offu.back());
             }
             // each fp32 fragment block is followed by its split-bf16 and fp16 twins (launch_dc8 relies on this order)
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3(w1, cin, fr.data() + off.back());
@@ -430,7 +416,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         }
         fr.resize((fr.size() + 3) / 4 * 4);   // 16-byte aligned
         const size_t off_zero = fr.size();
-        fr.resize(fr.size() + 64, 0.f);       // the zero page out-of-image staging loads read (hn_wino.hip)
+        fr.resize(fr.size() + 64, 0.f);       // the zero page out-of-image staging loads read (hn_dca.hip)
         (void)hipFree(ctx->fragdev);
         ctx->fragdev = nullptr;
         HN_HIP(ctx, hipMalloc((void**)&ctx->fragdev, fr.size() * sizeof(float)));
@@ -452,11 +438,6 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             ctx->inc.wa = ctx->fragdev + offa[ia++];
             for (int d = 0; d < depth; ++d) ctx->sig[d].wa = ctx->fragdev + offa[ia++];
             for (int d = 0; d <= depth; ++d) ctx->dec[d].wa = ctx->fragdev + offa[ia++];
-            size_t iu = 0;
-            auto setu = [&](DcW& w) { w.u1 = ctx->fragdev + offu[iu++]; w.u2 = ctx->fragdev + offu[iu++]; };
-            setu(ctx->inc);
-            for (int d = 0; d < depth; ++d) setu(ctx->sig[d]);
-            for (int d = 0; d <= depth; ++d) setu(ctx->dec[d]);
         }
         ctx->zero_page = ctx->fragdev + off_zero;
         ctx->f_dec0c = ctx->fragdev + off_comp;
@@ -513,7 +494,6 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
         HN_HIP(ctx, hipMalloc((void**)&ctx->buf_a[d], bytes));
         if (d < depth) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_o[d], bytes));
         if (d > 0) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_y[d], bytes));
-        if (d < 2 && d < depth) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_p[d], bytes));
     }
     HN_HIP(ctx, hipMalloc((void**)&ctx->st_tmp, sizeof(float) * (size_t)max_batch * kState * ctx->state_len));
     ctx->cap_batch = max_batch;
@@ -668,10 +648,12 @@ __global__ void k_probe_spin(long ticks) {
     const long t0 = (long)wall_clock64();   // 100 MHz
     while ((long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
-// do commands on `b` run while a kernel on `a` is still running?  (both streams are drained first: once per (slot, caller stream))
-static bool probe_overlap(hipStream_t a, hipStream_t b) {
+// do commands on `b` run while a kernel on `a` is still running?  One sample: both streams are drained, a 200 us spin kernel goes to `a`, an empty one to
+// `b`; overlap = b's marker completed >= 80 us before a's.  Returns 1 / 0, or -1 when no sample could be taken.
+static int probe_overlap_once(hipStream_t a, hipStream_t b) {
     hipEvent_t ea = nullptr, eb = nullptr;
-    if (hipEventCreate(&ea) != hipSuccess || hipEventCreate(&eb) != hipSuccess) return true;
+    if (hipEventCreate(&ea) != hipSuccess) return -1;
+    if (hipEventCreate(&eb) != hipSuccess) { (void)hipEventDestroy(ea); return -1; }
     (void)hipStreamSynchronize(a);
     (void)hipStreamSynchronize(b);
     hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, 20000L);   // 200 us
@@ -685,9 +667,29 @@ static bool probe_overlap(hipStream_t a, hipStream_t b) {
     (void)hipEventDestroy(ea);
     (void)hipEventDestroy(eb);
     (void)hipGetLastError();
-    return !ok || ms > 0.08f;   // the candidate's marker completed >= 80 us before the spin kernel's: another hardware queue
+    return !ok ? -1 : ms > 0.08f ? 1 : 0;
+}
+// majority of three samples (a busy GPU -- another context, a profiler -- can delay one marker); no usable sample: assume overlap
+static bool probe_overlap(hipStream_t a, hipStream_t b) {
+    int yes = 0, no = 0;
+    for (int k = 0; k < 3 && yes < 2 && no < 2; ++k) {
+        const int r = probe_overlap_once(a, b);
+        if (r > 0) ++yes; else if (r == 0) ++no;
+    }
+    return yes >= no;
+}
+static bool any_capturing(const hipStream_t* refs, int nrefs) {
+    for (int k = 0; k < nrefs; ++k) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (refs[k] != nullptr && hipStreamIsCapturing(refs[k], &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) return true;
+    }
+    (void)hipGetLastError();
+    return false;
 }
 }  // namespace
+// The library stream of `slot` that demonstrably runs beside every stream in refs.  Each distinct set of reference streams is probed ONCE per slot and its
+// answer remembered (a caller that alternates between two streams never re-probes), the probe synchronises the reference streams (never under stream
+// capture: then, and with may_sync false, an unprobed set gets candidate 0 until a later eager call probes it), HN_SIDE_PRIORITY 1 / 2 / 3 disables probing.
 int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, bool may_sync, hipStream_t* out) {
     auto& pk = ctx->picks[slot];
     int least = 0, greatest = 0;
@@ -698,28 +700,38 @@ int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, b
         return HN_OK;
     };
     int rc;
-    if (ctx->opt_side_priority != 0) {   // A/B: no probing
+    if (ctx->opt_side_priority != 0) {   // A/B, or a caller that must never be synchronised: no probing
         const int i = ctx->opt_side_priority == 1 ? 1 : ctx->opt_side_priority == 3 ? 2 : 0;
         if ((rc = cand(i)) != HN_OK) return rc;
         *out = pk.cand[i];
         return HN_OK;
     }
-    bool same = pk.nref == nrefs;
-    for (int k = 0; same && k < nrefs; ++k) same = pk.ref[k] == refs[k];
-    if (!same && may_sync) {
-        pk.chosen = 0;
+    hn_ctx::SidePick::Known* hit = nullptr;
+    for (auto& kn : pk.known) {
+        bool same = kn.nref == nrefs;
+        for (int k = 0; same && k < nrefs; ++k) same = kn.ref[k] == refs[k];
+        if (same) { hit = &kn; break; }
+    }
+    int chosen = hit ? hit->chosen : 0;
+    if (hit == nullptr && may_sync && nrefs <= 3 && !any_capturing(refs, nrefs)) {
         for (int i = 0; i < 4; ++i) {
             if ((rc = cand(i)) != HN_OK) return rc;
             bool ok = true;
             for (int k = 0; ok && k < nrefs; ++k) ok = probe_overlap(refs[k], pk.cand[i]);
-            if (ok) { pk.chosen = i; break; }
+            if (ok) { chosen = i; break; }
         }
-        pk.nref = nrefs;
-        for (int k = 0; k < nrefs; ++k) pk.ref[k] = refs[k];
-        if (getenv("HN_DEBUG_PICK")) fprintf(stderr, "[helmnet_hip] stream of slot %d beside %d other(s) (first %p): candidate %d (priority %d)\n", slot, nrefs, nrefs ? (void*)refs[0] : nullptr, pk.chosen, prio[pk.chosen]);
+        hn_ctx::SidePick::Known kn;
+        kn.nref = nrefs;
+        for (int k = 0; k < nrefs; ++k) kn.ref[k] = refs[k];
+        kn.chosen = chosen;
+        if (pk.known.size() >= 16) pk.known.erase(pk.known.begin());   // (streams come and go: bounded)
+        pk.known.push_back(kn);
+        ++ctx->probes_run;
+        if (getenv("HN_DEBUG_PICK")) fprintf(stderr, "[helmnet_hip] stream of slot %d beside %d other(s) (first %p): candidate %d (priority %d)\n", slot, nrefs, nrefs ? (void*)refs[0] : nullptr, chosen, prio[chosen]);
     }
-    if ((rc = cand(pk.chosen)) != HN_OK) return rc;
-    *out = pk.cand[pk.chosen];
+    if ((rc = cand(chosen)) != HN_OK) return rc;
+    pk.last_chosen = chosen;
+    *out = pk.cand[chosen];
     return HN_OK;
 }
 
@@ -753,7 +765,6 @@ int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, hipStream_t calle
             if (sl.done) continue;
             for (int d = 0; d < kMaxDepth; ++d) HN_HIP(ctx, hipEventCreateWithFlags(&sl.ev[d], hipEventDisableTiming));
             HN_HIP(ctx, hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-            HN_HIP(ctx, hipEventCreateWithFlags(&sl.pre_done, hipEventDisableTiming));
         }
     }
     return HN_OK;
@@ -872,8 +883,8 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     const size_t fb_all = sizeof(float) * (size_t)batch * 2 * plane, sb_all = sizeof(float) * (size_t)batch * kState * L;
     if (ns == 1) {
         // One lane: an iteration is a fixed kernel sequence over fixed buffers (the hidden states ping-pong between the
-        // caller's buffer and the library's).  By default (HN_OPT_GRAPH 0) every kernel is launched on the caller's stream:
-        // the host stays ahead of the GPU and in-order launches measured 4 % faster than graph replay.  With HN_OPT_GRAPH the
+        // caller's buffer and the library's).  By default (HN_EXP_GRAPH 0) every kernel is launched on the caller's stream:
+        // the host stays ahead of the GPU and in-order launches measured 4 % faster than graph replay.  With HN_EXP_GRAPH the
         // iteration is captured once per direction and replayed; iterations in which hn_profile_* brackets a kernel, and
         // everything when capture is unavailable, are still launched kernel by kernel -- the two forms are interchangeable
         // iteration by iteration (same kernels, same arguments, same order).

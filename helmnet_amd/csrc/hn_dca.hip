@@ -308,213 +308,6 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------------------------
-// Second form (r5): ONE round of blocks.  [measured, tools/dca_trace.py on the decoder] the 4-wave kernel above runs its 2048 blocks as two
-// rounds of 1024 (4 blocks per CU): a block lives 26 us of which 19 are conv1 at the FMA floor, but the first round runs in phase (every block
-// streams its input at once -- conv1 p95 29 us -- and then every block sits in its epilogue at once) and the second starts staggered over 20 us:
-// the kernel spans 68 us where 2 x 26 would be 53.  Here a block is TWO wavefronts -- wave h = mid rows 9h .. 9h+8 x all 8 mid channels over
-// ALL input channels (no exchange between waves at all) -- and needs half the LDS: chunks of one channel (ring of 3 x 6 KB), the mid tensor in two
-// halves of 4 channels (19 KB), conv2 accumulating over the first half while the second half's pre-activation sums wait in registers.  8 blocks
-// per CU = the same 4 wavefronts per SIMD, 2048 slots: every tile of a 256^2 x 32 launch is resident from the start and finishes once.
-// conv2: wave h = output rows 8h .. 8h+7 x 8 channels (10 mid rows read for 8 rows of FMAs instead of 6 for 4).
-// ------------------------------------------------------------------------------------------------------------------------------------
-constexpr int kChunk1 = 384 * 4;                           // one plane (360 float4) padded to 6 wave-instructions of 64 float4
-constexpr int kLds2Floats = cmax_(kNBuf * kChunk1, 4 * kMPlane);
-static_assert(kLds2Floats * 4 <= 20480, "8 blocks per CU");
-
-template <int CA, int CB, int CC, int EPI>
-__global__ __launch_bounds__(128, 4) void k_dc_asm2(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, const float* zero_page, int H, int W) {
-    constexpr int CIN = CA + CB + CC, NG = CIN;
-    __shared__ __attribute__((aligned(16))) float lds[kLds2Floats];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int h = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileId tl = xcd_tile();
-    const int b = tl.z;
-    const int x0 = tl.x * 64, y0 = tl.y * 16;
-#ifdef HN_ATRACE
-    const int tr_id = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191;
-    if (EPI == 1 && tid == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_dca_trace[tr_id][7] = hw; }
-#endif
-    HN_TR(0);
-
-    // ---- staging plan: wave-instruction k of a chunk writes float4s [64 k, 64 k + 64) of the chunk buffer; wave h issues k = h, 2 + h, 4 + h ----
-    unsigned goff[3];
-    bool gok[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int e = 64 * (h + 2 * i) + lane;
-        const int ir = e / 18, ic4 = e - 18 * ir;
-        const int y = y0 - 2 + ir, x = x0 - 4 + 4 * ic4;
-        gok[i] = e < kPlane4 && y >= 0 && y < H && x >= 0 && x < W;
-        goff[i] = gok[i] ? (unsigned)(y * W + x) * 4u : 0u;
-    }
-    const float* const base_a = sa.p + (long)b * sa.sb;
-    const float* const base_b = sb.p + (long)b * sb.sb;
-    const float* const base_c = sc.p + (long)b * sc.sb;
-    auto chan_ptr = [&](int c) -> const char* {   // c is wave-uniform: scalar selects
-        return reinterpret_cast<const char*>(c < CA ? base_a + (long)c * sa.sc
-                                                    : c < CA + CB ? base_b + (long)(c - CA) * sb.sc : base_c + (long)(c - CA - CB) * sc.sc);
-    };
-    auto issue = [&](int g, int buf) {
-        const char* const p0 = chan_ptr(g);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const char* src = gok[i] ? p0 + goff[i] : reinterpret_cast<const char*>(zero_page);
-            float* dst = lds + buf * kChunk1 + (h + 2 * i) * 256;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-    issue(0, 0);
-    if (NG > 1) issue(1, 1);
-
-    // ---- conv1 ----
-    f32x2 acc[9][4], acce[4];
-    {
-        const CwPtr bp = cw(w.b1);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x2 bv = bp[c];
-#pragma unroll
-            for (int r = 0; r < 9; ++r) acc[r][c] = bv;
-            acce[c] = bv;
-        }
-    }
-    const int el = lane < 18 ? lane : 17;                 // edge part: lane -> (mid row 9h + (el >> 1), mid column 64 + (el & 1))
-    const unsigned main0 = 4u * (unsigned)((9 * h) * kPI + lane + 2);
-    const unsigned edge0 = 4u * (unsigned)((9 * h + (el >> 1)) * kPI + 66 + (el & 1));
-    HN_TR(1);
-    {
-        int buf = 0;
-#pragma unroll 1
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) wait_vmcnt<3>(); else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (g + 2 < NG) issue(g + 2, buf == 0 ? 2 : buf - 1);
-            conv1_cin(acc, acce, main0 + 4u * (unsigned)(buf * kChunk1), edge0 + 4u * (unsigned)(buf * kChunk1), w.wa + (size_t)g * 72);
-            buf = buf == 2 ? 0 : buf + 1;
-        }
-    }
-    HN_TR(2);
-    __syncthreads();   // the staged input is dead: the first half of the mid tensor takes its place
-    HN_TR(3);
-
-    // ---- activation, zero padding of the MID tensor outside the image; one half (4 channels = pairs 2 hf, 2 hf + 1) at a time ----
-    const float slope = w.slope[0];
-    const float sel = slope <= 1.f ? __builtin_inff() : -__builtin_inff();
-    auto put = [&](f32x2 a, int cp, int mrow, int mcol, float mk) {   // cp: pair within the half; PReLU (architectures.py:32-33) as median(x, s x, +-inf)
-        float* m = lds + (2 * cp) * kMPlane + mrow * kPM + mcol;
-        const f32x2 am = a * (f32x2){mk, mk}, as = a * (f32x2){mk * slope, mk * slope};
-        m[0] = __builtin_amdgcn_fmed3f(am[0], as[0], sel);
-        m[kMPlane] = __builtin_amdgcn_fmed3f(am[1], as[1], sel);
-    };
-    const int xm = x0 - 1 + lane;
-    const bool xin = xm >= 0 && xm < W;
-    const int erow = 9 * h + (el >> 1), ecol = 64 + (el & 1);
-    const float emk = (y0 - 1 + erow >= 0 && y0 - 1 + erow < H && x0 - 1 + ecol < W) ? 1.f : 0.f;
-    auto put_half = [&](int hf) {
-#pragma unroll
-        for (int r = 0; r < 9; ++r) {
-            const int y = y0 - 1 + 9 * h + r;
-            const float mk = (xin && y >= 0 && y < H) ? 1.f : 0.f;
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) put(acc[r][2 * hf + cp], cp, 9 * h + r, lane, mk);
-        }
-        if (lane < 18) {
-#pragma unroll
-            for (int cp = 0; cp < 2; ++cp) put(acce[2 * hf + cp], cp, erow, ecol, emk);
-        }
-    };
-    // ---- conv2: output rows 8h .. 8h + 7, column x0 + lane ----
-    const int yb = y0 + 8 * h, ox = x0 + lane;
-    const long plane = (long)H * W;
-    const float* const mid = lds + (8 * h) * kPM + lane;
-    if constexpr (EPI == 1) {
-        const f32x2 bc = *cw(epi.b2c);
-        f32x2 acc2[8][1];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) acc2[r][0] = bc;
-        put_half(0);
-        __syncthreads();
-        HN_TR(4);
-#pragma unroll 1
-        for (int cm = 0; cm < 4; ++cm) conv_rows<8, 1>(acc2, mid + cm * kMPlane, kPM, cw(epi.w2c + cm * 18));
-        __syncthreads();
-        HN_TR(5);
-        put_half(1);
-        bool rok[8];
-        unsigned roff[8];
-        float wf_old[8][2];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            rok[r] = yb + r < H && ox < W;
-            roff[r] = rok[r] ? 4u * (unsigned)((yb + r) * W + ox) : 0u;
-            if (epi.wf != nullptr) {   // the wavefield read-modify-write is prefetched behind the second half of conv2
-                const char* base = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane);
-                wf_old[r][0] = *reinterpret_cast<const float*>(base + roff[r]);
-                wf_old[r][1] = *reinterpret_cast<const float*>(base + 4 * plane + roff[r]);
-            }
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int cm = 0; cm < 4; ++cm) conv_rows<8, 1>(acc2, mid + cm * kMPlane, kPM, cw(epi.w2c + (4 + cm) * 18));
-        HN_TR(6);
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            if (rok[r]) {
-                if (epi.d_out) {
-                    char* base = reinterpret_cast<char*>(epi.d_out + (long)b * 2 * plane);
-                    *reinterpret_cast<float*>(base + roff[r]) = acc2[r][0][0];
-                    *reinterpret_cast<float*>(base + 4 * plane + roff[r]) = acc2[r][0][1];
-                }
-                if (epi.wf) {  // wf <- d / 1e3 + wf (hybridnet.py:570)
-                    char* base = reinterpret_cast<char*>(epi.wf + (long)b * 2 * plane);
-                    *reinterpret_cast<float*>(base + roff[r]) = div1000(acc2[r][0][0]) + wf_old[r][0];
-                    *reinterpret_cast<float*>(base + 4 * plane + roff[r]) = div1000(acc2[r][0][1]) + wf_old[r][1];
-                }
-            }
-        }
-    } else {
-        f32x2 acc2[8][4];
-        {
-            const CwPtr bp = cw(w.b2);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x2 bv = bp[c];
-#pragma unroll
-                for (int r = 0; r < 8; ++r) acc2[r][c] = bv;
-            }
-        }
-        put_half(0);
-        __syncthreads();
-#pragma unroll 1
-        for (int cm = 0; cm < 4; ++cm) conv_rows<8, 4>(acc2, mid + cm * kMPlane, kPM, cw(w.w2 + cm * 72));
-        __syncthreads();
-        put_half(1);
-        __syncthreads();
-#pragma unroll 1
-        for (int cm = 0; cm < 4; ++cm) conv_rows<8, 4>(acc2, mid + cm * kMPlane, kPM, cw(w.w2 + (4 + cm) * 72));
-        if (ox < W) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                if (yb + r < H) {
-                    float* p = out.p + (long)b * out.sb + (long)(yb + r) * W + ox;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        p[(long)(2 * c) * out.sc] = acc2[r][c][0];
-                        p[(long)(2 * c + 1) * out.sc] = acc2[r][c][1];
-                    }
-                }
-            }
-        }
-    }
-}
-
-template <int CA, int CB, int CC, int EPI>
-void launch2(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, const float* zero_page, int H, int W, int batch, hipStream_t s) {
-    hipLaunchKernelGGL((k_dc_asm2<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(128), 0, s, a, b, c, out, w, e, zero_page, H, W);
-}
-
 template <int CA, int CB, int CC, int EPI>
 void launch(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, const float* zero_page, int H, int W, int batch, hipStream_t s) {
     hipLaunchKernelGGL((k_dc_asm<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, zero_page, H, W);
@@ -537,7 +330,7 @@ bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, i
     if (ctx->precision != HN_PREC_FP32 || ctx->opt_dc_valu < 3 || ctx->zero_page == nullptr) return false;
     if (act > HN_ACT_LEAKYRELU) return false;           // the smooth activations keep hn_dcv.hip's GEN instances
     if (kind == 2) return false;                         // (the bottleneck lives at the deepest level)
-    if ((ctx->opt_dc_valu == 3 || ctx->opt_dc_valu == 5) && kind == 1) return false;   // 3 / 5: inc + decoder here, conv_signal on the matrix core; 4 / 6: all three
+    if (ctx->opt_dc_valu == 3 && kind == 1) return false;   // 3: inc + decoder here, conv_signal on the matrix core; 4: all three
     // the input layer's weights carry the reference's 1e3 on the residual channels (hybridnet.py:566); any other scaling takes the other kernels
     const bool scales_ok = kind == 0 ? (a.scale == 1.f && b.scale == 1000.f && c.scale == 1.f) : (a.scale == 1.f && b.scale == 1.f && c.scale == 1.f);
     const bool off32 = 8.0 * (double)H * (double)W * 4.0 < 4.0e9;
@@ -552,16 +345,6 @@ bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, i
 void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H, int W,
                    int batch, hipStream_t s) {
     const VcEpi e{d_out, wf, ctx->v_dec0c, ctx->dec0c_b};
-    if (ctx->opt_dc_valu >= 5) {   // the two-wavefront blocks
-        switch (kind) {
-            case 0: launch2<2, 2, 2, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;
-            case 1: launch2<kFeat, kState, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;
-            default:
-                if (final_epi) launch2<kFeat, kFeat, 0, 1>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s);
-                else launch2<kFeat, kFeat, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s);
-        }
-        return;
-    }
     switch (kind) {
         case 0: launch<2, 2, 2, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;              // inc
         case 1: launch<kFeat, kState, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;      // conv_signal

@@ -49,10 +49,8 @@ struct VcCfg {
     static_assert(CIN % CK == 0, "whole chunks");
 };
 
-// PIN: conv1's accumulators start from `pin` ([B, 8, H, W]: bias + the share of the input channels that k_conv3_pre summed earlier, on the
-// side stream) instead of the bias; the kernel then walks the remaining CA + CB + CC channels only (decoder: the upsampled half).
-template <int CA, int CB, int CC, int EPI, bool GEN, bool PIN = false>
-__global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, int H, int W, Src pin) {
+template <int CA, int CB, int CC, int EPI, bool GEN>
+__global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, int H, int W) {
     using C = VcCfg<CA, CB, CC>;
     __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -120,30 +118,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
     const int el = lane < 18 ? lane : 17;                 // edge part: lane -> (mid row 9h + (el >> 1), mid column 64 + (el & 1))
     const int bse = (C::NR1 * h + (el >> 1)) * C::PI + 64 + (el & 1);
     f32x2 acc1[C::NR1][2], acce[2];
-    if constexpr (PIN) {
-        // mid position (row 9h + r, column lane) = image (y0 - 1 + 9h + r, x0 - 1 + lane); positions outside the image are masked to
-        // zero behind the activation, so they may start from any finite value: theirs is element 0 of the plane
-        const float* pb = pin.p + (long)b * pin.sb + (long)(4 * q) * pin.sc;
-        const int xm = x0 - 1 + lane;
-        const bool xin = xm >= 0 && xm < W;
-#pragma unroll
-        for (int r = 0; r < C::NR1; ++r) {
-            const int y = y0 - 1 + C::NR1 * h + r;
-            const unsigned o = (xin && y >= 0 && y < H) ? 4u * (unsigned)(y * W + xm) : 0u;
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                acc1[r][c][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pb + (long)(2 * c) * pin.sc) + o);
-                acc1[r][c][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pb + (long)(2 * c + 1) * pin.sc) + o);
-            }
-        }
-        const int ye = y0 - 1 + C::NR1 * h + (el >> 1), xe = x0 + 63 + (el & 1);
-        const unsigned oe = (ye >= 0 && ye < H && xe < W) ? 4u * (unsigned)(ye * W + xe) : 0u;
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-            acce[c][0] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pb + (long)(2 * c) * pin.sc) + oe);
-            acce[c][1] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(pb + (long)(2 * c + 1) * pin.sc) + oe);
-        }
-    } else {
+    {
         const CwPtr bp = cw(w.b1) + 2 * q;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -296,127 +271,12 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
     }
 }
 
-// ---- the skip half of a decoder's first convolution, ahead of time (r5) ----
-// decode_d's conv1 runs over cat[up_d(x), skip_d] (architectures.py:458-460).  It is linear in its input channels, and the skip half is
-// known as soon as conv_signal_d has run -- long before the decoder, which waits for the whole deep chain.  k_conv3_pre computes
-// P = b1 + W1[:, 8:16] * skip_d on the side stream, in the shadow of the small levels (where the main chain leaves most of the chip idle);
-// the decoder (k_dc_valu<..., PIN>) then starts its accumulators from P and walks the 8 upsampled channels only: half of conv1's FMAs,
-// none of its halo / edge-column overhead for the skip half (P is computed once per pixel: 16 x 64 output tiles, no mid halo).
-// Tile 16 x 64, 4 wavefronts; wave w owns output rows 4w .. 4w+3 x all 8 channels (conv2's shape: one LDS row read feeds up to 36 packed
-// FMAs); input staged with a halo of one row / two columns (8-byte aligned float2 loads), two channels per chunk, double buffered.
-template <int CIN>
-struct PreCfg {
-    static constexpr int TH = 16, TW = 64, CK = 2, NG = CIN / CK;
-    static constexpr int IR = TH + 2, PI = TW + 4, PLANE = IR * PI, NP2 = PLANE / 2, NL = cdiv_(NP2, 256);
-    static constexpr int PLANE_P = PLANE + 128;
-    static constexpr int LDS_FLOATS = 2 * CK * PLANE_P;
-};
-
-template <int CIN>
-__global__ __launch_bounds__(256, 4) void k_conv3_pre(Src sa, Dst out, const float* w9x8, const float* bias, int H, int W) {
-    using C = PreCfg<CIN>;
-    __shared__ __attribute__((aligned(16))) float lds[C::LDS_FLOATS];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileId tl = xcd_tile();
-    const int b = tl.z;
-    const int x0 = tl.x * C::TW, y0 = tl.y * C::TH;
-    unsigned gofb[C::NL];
-    int lofw[C::NL];
-#pragma unroll
-    for (int i = 0; i < C::NL; ++i) {
-        const int e = tid + i * 256;
-        const int ir = e / (C::PI / 2), ic = 2 * (e - ir * (C::PI / 2));
-        const int y = y0 - 1 + ir, x = x0 - 2 + ic;
-        const bool in = e < C::NP2;
-        const bool ok = in && y >= 0 && y < H && x >= 0 && x < W;
-        gofb[i] = ok ? (unsigned)(y * W + x) * 4u : 0u;
-        lofw[i] = (ok ? ir * C::PI + ic : C::PLANE + 2 * lane) >> 1;
-        if (in && !ok) {
-#pragma unroll
-            for (int pl = 0; pl < 2 * C::CK; ++pl) *reinterpret_cast<float2*>(&lds[pl * C::PLANE_P + ir * C::PI + ic]) = make_float2(0.f, 0.f);
-        }
-    }
-    const float* const base = sa.p + (long)b * sa.sb;
-    float2 stA[C::CK][C::NL], stB[C::CK][C::NL];
-    auto fetch = [&](int c0, float2 (&stage)[C::CK][C::NL]) {
-        unsigned off[C::NL];
-#pragma unroll
-        for (int i = 0; i < C::NL; ++i) {
-            off[i] = gofb[i];
-            asm volatile("" : "+v"(off[i]));
-        }
-#pragma unroll
-        for (int j = 0; j < C::CK; ++j) {
-            const float* p0 = base + (long)(c0 + j) * sa.sc;
-#pragma unroll
-            for (int i = 0; i < C::NL; ++i) stage[j][i] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(p0) + off[i]);
-        }
-    };
-    auto commit = [&](int buf, const float2 (&stage)[C::CK][C::NL]) {
-#pragma unroll
-        for (int j = 0; j < C::CK; ++j)
-#pragma unroll
-            for (int i = 0; i < C::NL; ++i) reinterpret_cast<float2*>(lds)[(buf * C::CK + j) * (C::PLANE_P / 2) + lofw[i]] = stage[j][i];
-    };
-    f32x2 acc[4][4];
-    {
-        const CwPtr bp = cw(bias);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x2 bv = bp[c];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[r][c] = bv;
-        }
-    }
-    const int bs = (4 * wave) * C::PI + lane + 1;   // output (y0 + 4 wave + r, x0 + lane): staged rows 4 wave + r + ky, columns lane + 1 + kx
-    auto step = [&](int g, int buf, float2 (&stage)[C::CK][C::NL]) {
-        commit(buf, stage);
-        __syncthreads();
-        if (g + 2 < C::NG) fetch((g + 2) * C::CK, stage);
-        const float* t = lds + buf * C::CK * C::PLANE_P;
-#pragma unroll
-        for (int j = 0; j < C::CK; ++j) conv_rows<4, 4>(acc, t + j * C::PLANE_P + bs, C::PI, cw(w9x8 + (size_t)(g * C::CK + j) * 72));
-    };
-    fetch(0, stA);
-    if (C::NG > 1) fetch(C::CK, stB);
-#pragma unroll 1
-    for (int g = 0; g + 1 < C::NG; g += 2) {
-        step(g, 0, stA);
-        step(g + 1, 1, stB);
-    }
-    if (C::NG & 1) step(C::NG - 1, 0, stA);
-    const int ox = x0 + lane, yb = y0 + 4 * wave;
-    if (ox < W) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            if (yb + r < H) {
-                float* p = out.p + (long)b * out.sb + (long)(yb + r) * W + ox;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    p[(long)(2 * c) * out.sc] = acc[r][c][0];
-                    p[(long)(2 * c + 1) * out.sc] = acc[r][c][1];
-                }
-            }
-        }
-    }
-}
-
 template <int CA, int CB, int CC, int EPI>
 void launch(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, int H, int W, int batch, hipStream_t s) {
     const dim3 g(cdiv_(W, 64), cdiv_(H, 16), batch);
-    const Src none{nullptr, 0, 0, 1.f};
-    if (w.act > HN_ACT_LEAKYRELU) hipLaunchKernelGGL((k_dc_valu<CA, CB, CC, EPI, true>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W, none);
-    else hipLaunchKernelGGL((k_dc_valu<CA, CB, CC, EPI, false>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W, none);
+    if (w.act > HN_ACT_LEAKYRELU) hipLaunchKernelGGL((k_dc_valu<CA, CB, CC, EPI, true>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
+    else hipLaunchKernelGGL((k_dc_valu<CA, CB, CC, EPI, false>), g, dim3(256), 0, s, a, b, c, out, w, e, H, W);
 }
-template <int EPI>
-void launch_pin(Src a, Src pin, Dst out, const DcW& w, const VcEpi& e, int H, int W, int batch, hipStream_t s) {
-    const dim3 g(cdiv_(W, 64), cdiv_(H, 16), batch);
-    const Src none{nullptr, 0, 0, 1.f};
-    if (w.act > HN_ACT_LEAKYRELU) hipLaunchKernelGGL((k_dc_valu<kFeat, 0, 0, EPI, true, true>), g, dim3(256), 0, s, a, none, none, out, w, e, H, W, pin);
-    else hipLaunchKernelGGL((k_dc_valu<kFeat, 0, 0, EPI, false, true>), g, dim3(256), 0, s, a, none, none, out, w, e, H, W, pin);
-}
-
 }  // namespace
 
 // conv2 [8][8][3][3] (+ bias) composed with the 1x1 out-conv [2][8] in float64 -> [8 cm][3][3][2] (the bias comes from
@@ -446,7 +306,7 @@ bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, 
     // pipe.  [measured on four boxes, 3 x 300 steps each] all-vector 1808 / 1987 / 1873 / 1929 it/s, all-matrix 1884 / 1902 / 1904 /
     // 1894, this mix 1887 / 1982 / 1925 / 1919: the packed-FMA kernels pull the shader clock down (median 2.22-2.30 GHz in the loop
     // instead of a held 2.40, tools/clock_probe.py) by an amount that depends on the box, and every other kernel pays for it.
-    if ((ctx->opt_dc_valu == 1 || ctx->opt_dc_valu == 3 || ctx->opt_dc_valu == 5) && kind == 1) return false;   // (3 / 4: hn_dca.hip takes what it can; the rest falls through to here)
+    if ((ctx->opt_dc_valu == 1 || ctx->opt_dc_valu == 3) && kind == 1) return false;   // (3 / 4: hn_dca.hip takes what it can; the rest falls through to here)
 #ifdef HN_EXP_MFMA_KINDS
     if ((HN_EXP_MFMA_KINDS >> kind) & 1) return false;   // A/B: these DoubleConv kinds stay on the matrix core
 #endif
@@ -457,13 +317,8 @@ bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, 
 }
 
 void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
-                    int W, int batch, hipStream_t s, const Src* pin) {
+                    int W, int batch, hipStream_t s) {
     const VcEpi e{d_out, wf, ctx->v_dec0c, ctx->dec0c_b};
-    if (pin != nullptr && kind == 3) {   // decoder whose skip half (b) was summed ahead of time into *pin (launch_skip_pre)
-        if (final_epi) launch_pin<1>(a, *pin, out, w, e, H, W, batch, s);
-        else launch_pin<0>(a, *pin, out, w, e, H, W, batch, s);
-        return;
-    }
     switch (kind) {
         case 0: launch<2, 2, 2, 0>(a, b, c, out, w, e, H, W, batch, s); break;              // inc
         case 1: launch<kFeat, kState, 0, 0>(a, b, c, out, w, e, H, W, batch, s); break;      // conv_signal
@@ -471,11 +326,6 @@ void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const D
             if (final_epi) launch<kFeat, kFeat, 0, 1>(a, b, c, out, w, e, H, W, batch, s);  // decoder (+ out-conv, wavefield update)
             else launch<kFeat, kFeat, 0, 0>(a, b, c, out, w, e, H, W, batch, s);
     }
-}
-
-// P = b1 + conv3x3(skip; W1[:, 8:16]) of decoder `w` (k_conv3_pre above); w.w1 is [16][9][8]
-void launch_skip_pre(Src skip, Dst p, const DcW& w, int H, int W, int batch, hipStream_t s) {
-    hipLaunchKernelGGL((k_conv3_pre<kFeat>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, skip, p, w.w1 + (size_t)kFeat * 72, w.b1, H, W);
 }
 
 }  // namespace hn

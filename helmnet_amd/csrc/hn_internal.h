@@ -41,7 +41,6 @@ struct DcW {
     int act;   // hn_act
     const float* w1q;   // conv1 again as [cin][2 channel halves][3][3][4] (8-channel DoubleConvs only; hn_dcv.hip)
     const float* wa;    // conv1 again as [cin][3 kx][3 ky][8] with the input scales folded in (8-channel DoubleConvs only; hn_dca.hip)
-    const float *u1, *u2;   // both convolutions in the Winograd F(2x2, 3x3) domain: [cin][2 halves][8 freq][8 cout] (hn_wino.hip)
 };
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each; MI355X_MICROARCH.md, "Workgroup
@@ -153,13 +152,8 @@ struct hn_ctx {
     bool cols_t_attr_set = false, cols512_attr_set = false;
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     int opt_dc_valu = 4;       // fp32 DoubleConvs of the big levels on the packed vector FMA: 0 none, 1 inc + decoder (hn_dcv.hip), 2 all three;
-                               // 3 / 4 (default): the same two / three on the hand-scheduled kernel (hn_dca.hip); 5 / 6: its two-wavefront form
-    int opt_skip_pre = 0;      // HN_OPT_SKIP_PRE: bit d (d = 0, 1): the skip half of decode_d's first convolution runs ahead of time on the side stream, in
-                               // the shadow of the small levels (hn_dcv.hip: k_conv3_pre); needs the side stream (policy 1) and the vector-pipe decoder.
-                               // bit 2 (A/B): ONE join in front of the first such decoder for everything on the side stream instead of an event of its own
-    int opt_dc_wino = 0;       // level-0 DoubleConvs as Winograd F(2x2, 3x3) on the vector FMA (hn_wino.hip): bit mask over the kinds
-                               // (1 inc, 2 conv_signal, 8 decoder), 0 none
-    const float* zero_page = nullptr;   // 256 zero bytes (out-of-image staging loads of hn_wino.hip)
+                               // 3 / 4 (default): the same two / three on the hand-scheduled kernel (hn_dca.hip)
+    const float* zero_page = nullptr;   // 256 zero bytes (out-of-image float4s of the LDS-direct staging loads, hn_dca.hip)
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
     // domain
@@ -171,13 +165,12 @@ struct hn_ctx {
     float* buf_a[hn::kMaxDepth + 1]{};  // x_d, later reused for the upsampled tensor u_d
     float* buf_o[hn::kMaxDepth]{};      // out_d (skip connections)
     float* buf_y[hn::kMaxDepth + 1]{};  // decoder outputs y_d
-    float* buf_p[2]{};                  // levels 0, 1: the skip half of the decoder's first convolution, summed ahead of time on the side stream (opt_skip_pre)
     float* st_tmp = nullptr;            // second flat state buffer for hn_step ping-pong
     // hn_step pipelines sub-batches on internal streams (samples are independent): while one
     // sub-batch walks the small, latency-bound UNet levels the other one keeps the CUs busy
     // conv_state kernels run on a side stream per pipeline lane (HN_SIDE_STREAM, hn_step only)
     struct SideLane {
-        hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr; hipEvent_t pre_done = nullptr;
+        hipStream_t stream = nullptr; hipEvent_t ev[hn::kMaxDepth]{}; hipEvent_t done = nullptr;
         bool pending = false;   // `done` has been recorded on the side stream and not been waited for yet (deferred join, hn_step)
     };
     SideLane side[8];          // (lane 0's stream belongs to picks[0]: side_stream_for)
@@ -186,7 +179,12 @@ struct hn_ctx {
     // 7.2 -> 21 ms) -- which streams share a queue depends on how many streams of which priority the PROCESS has created, not on anything the library controls
     // [measured, r4: profiles/r4_caller_stream.txt, r4_wg_prio.txt, r4_stream_probe.txt].  So per (slot, caller stream) the library PROBES its candidates once:
     // a 200 us spin kernel on the caller's stream, an empty one on the candidate -- did the second finish first? -- and keeps the first candidate that overlaps.
-    struct SidePick { hipStream_t cand[4]{}; hipStream_t ref[3]{}; int nref = -1; int chosen = 0; } picks[8];   // 0: hn_step's side stream; 1, 2: hn_train_grad lanes;
+    struct SidePick {
+        hipStream_t cand[4]{};
+        struct Known { hipStream_t ref[3]{}; int nref = 0; int chosen = 0; };
+        std::vector<Known> known;     // every reference-stream set probed so far and the candidate that overlapped with it
+        int last_chosen = 0;
+    } picks[8];   // 0: hn_step's side stream; 1, 2: hn_train_grad lanes;
                                                                                                                // 3 .. 6: two pipeline lanes (chain 0, chain 1, side 0, side 1: mutually overlapping)
     int n_streams = 0;         // internal streams created so far
     hipStream_t sub_stream[8]{};
@@ -202,7 +200,7 @@ struct hn_ctx {
     std::vector<StepGraph> graphs;
     long graph_clock = 0;
     hipStream_t cap_stream = nullptr;              // iterations are captured here (the caller's stream may be the legacy default stream)
-    long graph_replays = 0, eager_iterations = 0, graphs_captured = 0;  // diagnostics (hn_get_counter)
+    long graph_replays = 0, eager_iterations = 0, graphs_captured = 0, probes_run = 0, train_fwd_events = 0;  // diagnostics (hn_get_counter)
     // training workspace (hn_train.hip): activation tape of the unrolled iterations, gradient buffers, partial sums
     struct TrainWs {
         int batch = 0, n_unroll = 0, n = 0, depth = 0;
@@ -241,6 +239,7 @@ struct hn_ctx {
         hipEvent_t jobs_copied[kJobSets]{};   // recorded behind the last copy of the call that used the set
         bool jobs_in_flight[kJobSets]{};
         int jobs_set = 0, jobs_rows = 0;      // set of the current call; iterations per set
+        bool captured = false;       // a call using this workspace has been captured into a HIP graph: growing it needs an explicit hn_train_reserve
         int last_batch = 0;          // samples of the last hn_train_grad call in this workspace (hn_train_peek)
         int sumsq_batch = 0;         // samples per row of sumsq (lane 0 holds the whole batch's rows)
     } tr, tr_b;                      // tr_b: the second half of the batch when hn_train_grad runs as two lanes
@@ -296,8 +295,7 @@ enum KernelId : int {
     KID_SPEC_ROWS = 33,   // spectral row pass + residual terms (or the dense operator)
     KID_DEEP = 34,        // deepest level in one per-sample kernel: conv_signal, conv_state, down, bottleneck, up, decoder
     KID_SPEC_PAIR = 35,   // one bracket around both spectral passes (the HBM-bound part of the path as a whole)
-    KID_PRE0 = 36,        // + d (d = 0, 1): skip half of decode_d's conv1 ahead of time (side stream)
-    KID_COUNT = 38
+    KID_COUNT = 36
 };
 
 // RAII event pair around one launch when that kernel id is selected by hn_profile_enable.
@@ -352,7 +350,7 @@ void pack_frag_down_x16(const float* w_oihw, float* dst_split, float* dst_half);
 void pack_frag_up_x16(const float* w_iohw, float* dst_split, float* dst_half);
 // kind: 0 inc (2+2+2 ch), 1 conv_signal (8+2), 2 bottleneck (8), 3 decoder (8+8; final_epi adds outc + wf update)
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
-               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s, const Src* pin = nullptr);
+               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s);
 // training forward: the fused matrix-core DoubleConv with the pre-activation mid tensor stored to `z` ([B, 8, H, W]); fragments as pack_frag_3x3
 bool dc8_tape_applies(int H, int W);
 // Backward-data pass of an 8-channel DoubleConv (cin -> 8 -> 8) on the fp32 matrix core (hn_mfma.hip, k_dc_bwd_mfma_p): g_z = conv2^T(g) * act'(z),
@@ -393,21 +391,13 @@ void pack_valu_q(const float* w_oihw, int cin, float* dst);            // conv1 
 void pack_outc3x3_valu(const float* w2, const float* wo, float* dst);   // conv2 composed with the out-conv -> [8 cm][3][3][2]
 bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
 void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
-                    int W, int batch, hipStream_t s, const Src* pin = nullptr);
-// the skip half of decoder w's first convolution ahead of time: p = b1 + conv3x3(skip; W1[:, 8:16]); the decoder then takes it as `pin`
-void launch_skip_pre(Src skip, Dst p, const DcW& w, int H, int W, int batch, hipStream_t s);
+                    int W, int batch, hipStream_t s);
 
 // ---- the same with a hand-scheduled conv1 loop and LDS-direct staging (hn_dca.hip) ----
 void pack_dca(const float* w_oihw, int cin, const float* scale, float* dst);   // conv1 [8][cin][3][3] -> [cin][3 kx][3 ky][8]
 bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
 void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H, int W,
                    int batch, hipStream_t s);
-
-// ---- Winograd F(2x2, 3x3) DoubleConv of the big levels (hn_wino.hip) ----
-void pack_wino(const float* w_oihw, int cin, const float* scale, float* dst);   // [8][cin][3][3] -> [cin][2][8][8]
-bool dc_wino_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
-void launch_dc_wino(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
-                    int W, int batch, hipStream_t s);
 
 // ---- deep levels in one per-sample kernel (hn_deep.hip) ----
 void pack_frag_3x3_c2(const float* w_oihw, int cin, float* dst);  // 2 output channels -> [cin][3][64], rows 4..15 of M zero

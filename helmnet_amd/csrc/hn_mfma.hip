@@ -2564,15 +2564,7 @@ void pack_frag_up(const float* w, float* dst) {
 }
 
 int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, const float* frag1, const float* frag2,
-               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s, const Src* pin) {
-    if (pin != nullptr) {   // (unet_forward hands a pin only where skip_pre_applies said the vector-pipe decoder runs)
-        launch_dc_valu(ctx, kind, a, b, c, out, w, final_epi, d_out, wf, H, W, batch, s, pin);
-        return HN_OK;
-    }
-    if (dc_wino_applies(ctx, w.act, a, b, c, kind, H, W)) {
-        launch_dc_wino(ctx, kind, a, b, c, out, w, final_epi, d_out, wf, H, W, batch, s);
-        return HN_OK;
-    }
+               bool final_epi, float* d_out, float* wf, int H, int W, int batch, hipStream_t s) {
     if (dc_asm_applies(ctx, w.act, a, b, c, kind, H, W)) {
         launch_dc_asm(ctx, kind, a, b, c, out, w, final_epi, d_out, wf, H, W, batch, s);
         return HN_OK;

@@ -1601,9 +1601,14 @@ void train_free_ws(hn_ctx::TrainWs& W) {
 }
 
 // workspace W for `batch` samples x n_unroll iterations; sumsq rows of `sumsq_batch` samples (the first lane keeps the whole batch's)
-int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int sumsq_batch) {
+int train_reserve(hn_ctx* ctx, hn_ctx::TrainWs& W, int batch, int n_unroll, int sumsq_batch, bool allow_regrow_captured = false) {
     const int n = ctx->tab.n, depth = ctx->depth;
     if (W.tape != nullptr && W.n == n && W.depth == depth && batch <= W.batch && n_unroll <= W.n_unroll && sumsq_batch <= W.sumsq_batch) return HN_OK;
+    // a graph captured from hn_train_grad points into this workspace (tape, gradient buffers, the pinned job tables it re-copies on every replay): growing it
+    // would free that memory under the graph.  hn_train_reserve -- an explicit call -- is how the caller says the graph is gone
+    if (W.captured && !allow_regrow_captured)
+        return fail(ctx, HN_ERR_STATE, "hn_train_grad: a training step captured into a HIP graph uses this workspace and the call needs a larger one: destroy the "
+                                      "graph and call hn_train_reserve first");
     HN_HIP(ctx, hipDeviceSynchronize());
     const bool fresh = W.n != n || W.depth != depth;
     const int nb = fresh || batch > W.batch ? batch : W.batch;
@@ -1721,8 +1726,9 @@ int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll) {
     DeviceGuard guard(ctx);
     const int lanes = ctx->opt_train_lanes >= 2 && batch >= 2 ? 2 : 1;
     const int b0 = lanes == 2 ? (batch + 1) / 2 : batch;
-    rc = train_reserve(ctx, ctx->tr, b0, n_unroll, batch);
-    if (rc == HN_OK && lanes == 2) rc = train_reserve(ctx, ctx->tr_b, batch - b0, n_unroll, 1);
+    ctx->tr.captured = ctx->tr_b.captured = false;   // an explicit reserve is the caller's word that no captured training step is replayed any more
+    rc = train_reserve(ctx, ctx->tr, b0, n_unroll, batch, true);
+    if (rc == HN_OK && lanes == 2) rc = train_reserve(ctx, ctx->tr_b, batch - b0, n_unroll, 1, true);
     return rc;
 }
 
@@ -1781,7 +1787,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         auto& W = *ws[l];
         // set 0 of the pinned job tables belongs to CAPTURED calls (their graph copies the tables out of it at every replay, so eager calls
         // must never rewrite it); eager calls rotate over sets 1 .. kJobSets - 1
-        if (capturing) W.jobs_set = 0;
+        if (capturing) { W.jobs_set = 0; W.captured = true; }
         else W.jobs_set = W.jobs_set % (hn_ctx::TrainWs::kJobSets - 1) + 1;
         if (!capturing && W.jobs_in_flight[W.jobs_set]) {   // the tables of the call that last used this set have left the pinned buffer (normally long ago)
             HN_HIP(ctx, hipEventSynchronize(W.jobs_copied[W.jobs_set]));
@@ -1910,6 +1916,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         if (ctx->train_fwd_sumsq != nullptr)   // sum over (2, N, N) of res^2 per (iteration, sample): what the reference's refill rule thresholds (hybridnet.py:437-438)
             HN_HIP(ctx, hipMemcpyAsync(ctx->train_fwd_sumsq, ctx->tr.sumsq, sizeof(float) * (size_t)n_unroll * batch, hipMemcpyDeviceToHost, s));
         HN_HIP(ctx, hipEventRecord(ctx->train_fwd_event, s));
+        ++ctx->train_fwd_events;
     }
     // backward sweep
     int cur_wf[2] = {0, 0}, cur_st[2] = {0, 0};

@@ -462,29 +462,9 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     //      sequence is not being captured into a graph (an event record is a ~6 us bubble on the stream).
     //   3  all levels behind the deep kernel (beside the decoder's small levels)
     const int policy = side != nullptr ? ctx->opt_side_stream : 0;
-    // skip half of decode_d's first convolution ahead of time (hn_dcv.hip, k_conv3_pre): levels 0, 1 where the vector-pipe decoder runs,
-    // launched on the side stream in front of the hidden-state kernels (policy 1: beside the deep levels)
-    bool pre[2] = {false, false};
-    for (int d = 0; d < 2 && d < n_enc; ++d) {
-        const int m = n >> d;
-        pre[d] = policy == 1 && mfma && (ctx->opt_skip_pre >> d & 1) && ctx->buf_p[d] != nullptr &&
-                 dc_valu_applies(ctx, ctx->dec[d].act, featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none, 3, m, m) &&
-                 !dc_wino_applies(ctx, ctx->dec[d].act, featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none, 3, m, m);
-    }
-    const bool any_pre = pre[0] || pre[1], one_join = any_pre && (ctx->opt_skip_pre & 4) != 0;
-    bool joined_early = false;
     auto release_states = [&](int d0, int d1, hipEvent_t ev) -> int {
         HN_HIP(ctx, hipEventRecord(ev, s));
         HN_HIP(ctx, hipStreamWaitEvent(side, ev, 0));
-        if (any_pre) {
-            for (int e = 1; e >= 0; --e) {   // (level 1 first: its decoder comes first)
-                if (!pre[e]) continue;
-                const int me = n >> e;
-                ProfScope ps2(ctx, KID_PRE0 + e, side);
-                launch_skip_pre(featsrc(ctx->buf_o[e], e), feat(ctx->buf_p[e], e), ctx->dec[e], me, me, batch, side);
-            }
-            if (!one_join) HN_HIP(ctx, hipEventRecord(side_lane->pre_done, side));
-        }
         for (int e = d0; e < d1; ++e) {
 #ifdef HN_EXP_SKIP_STATE   // timing experiment only (tools/r4_skip_state.sh): environment bit e skips conv_state_e -- the results are WRONG
             static const int exp_skip = getenv("HN_EXP_SKIP_STATE") ? std::atoi(getenv("HN_EXP_SKIP_STATE")) : 0;
@@ -495,10 +475,6 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
             ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
             launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
-        }
-        if (one_join) {   // (A/B) everything on the side stream is waited for in front of the first decoder that takes a pin
-            HN_HIP(ctx, hipEventRecord(side_lane->done, side));
-            side_lane->pending = true;
         }
         return HN_OK;
     };
@@ -565,18 +541,11 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             else hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
                                     featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
         }
-        const bool pin_d = d < 2 && pre[d];
-        if (pin_d && !joined_early) {   // the first decoder that starts from a pin: the side stream's k_conv3_pre launches have to be through
-            if (one_join) { int rc = side_join(ctx, side_lane, s); if (rc != HN_OK) return rc; }
-            else HN_HIP(ctx, hipStreamWaitEvent(s, side_lane->pre_done, 0));
-            joined_early = true;
-        }
         ProfScope ps(ctx, KID_DEC0 + 2 * d, s);
         // x = decode[d](cat[x, skip_d])                                  (architectures.py:458-460)
         if (mfma) {
-            const Src pin = pin_d ? featsrc(ctx->buf_p[d], d) : none;
             launch_dc8(ctx, 3, featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none, d > 0 ? feat(ctx->buf_y[d], d) : Dst{nullptr, 0, 0},
-                       ctx->dec[d], ctx->f_dec[d][0], ctx->f_dec[d][1], d == 0, d_out, wf_update, m, m, batch, s, pin_d ? &pin : nullptr);
+                       ctx->dec[d], ctx->f_dec[d][0], ctx->f_dec[d][1], d == 0, d_out, wf_update, m, m, batch, s);
         } else if (d > 0) {
             launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none,
                                                         feat(ctx->buf_y[d], d), ctx->dec[d], noepi, m, m, batch, s);
@@ -587,7 +556,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                                         Dst{nullptr, 0, 0}, ctx->dec[0], e, m, m, batch, s);
         }
     }
-    if (policy != 0 && !one_join) {  // the next iteration's conv_signal reads the new states
+    if (policy != 0) {  // the next iteration's conv_signal reads the new states
         HN_HIP(ctx, hipEventRecord(side_lane->done, side));
         side_lane->pending = true;
         if (!defer_join) {

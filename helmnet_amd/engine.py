@@ -192,9 +192,9 @@ class Engine:
         return names[code]
 
     def set_option(self, name: str, value: int):
-        """Library tuning knobs (enum hn_option of include/helmnet_hip.h): 'lanes' 1..8, 'side_stream' 0..3, 'graph' 0, 1 or an even
-        number <= 64 of iterations per graph, 'deep' 0/1, 'spectral_pfa' 0/1, 'spectral_radix16' 0..2, 'dc_valu' 0..6,
-        'spectral_cols' 0..2, 'train_lanes' 1/2 (hn_train_grad: the halves of the batch as two chains of launches on two streams).
+        """Library tuning knobs (enum hn_option of include/helmnet_hip.h): 'lanes' 1..8, 'side_stream' 0..3, 'deep' 0/1, 'spectral_pfa' 0/1,
+        'spectral_radix16' 0..2, 'dc_valu' 0..4, 'spectral_cols' 0..2, 'train_fused', 'train_overlap'; laboratory knobs (HN_EXP_*): 'graph' 0, 1 or an even
+        number <= 64 of iterations per graph, 'train_lanes' 1/2 (hn_train_grad: the halves of the batch as two chains of launches on two streams).
         'spectral_pfa' is read when the spectral tables are built: changing it re-builds them."""
         if name not in _lib.HN_OPTION:
             raise ValueError(f"unknown option {name!r} (choose from {sorted(_lib.HN_OPTION)})")
@@ -454,7 +454,7 @@ class Engine:
         return out
 
     # ---- measurement hooks ---------------------------------------------------------------
-    KERNEL_IDS = 38
+    KERNEL_IDS = 36
 
     @staticmethod
     def kernel_name(kid: int) -> str:
@@ -466,7 +466,7 @@ class Engine:
             return "bottleneck"
         if 20 <= kid <= 31:
             return ("up", "decode")[(kid - 20) % 2] + str((kid - 20) // 2)
-        return {32: "spectral_cols", 33: "spectral_rows", 34: "deep", 35: "spectral_pair", 36: "skip_pre0", 37: "skip_pre1"}[kid]
+        return {32: "spectral_cols", 33: "spectral_rows", 34: "deep", 35: "spectral_pair"}[kid]
 
     def profile_enable(self, kernel_ids=None):
         """Bracket the selected kernels (None = all, [] = none) with HIP events on the launch stream."""

@@ -256,7 +256,13 @@ class Trainer:
         for k in ("weights", "exp_avg", "exp_avg_sq"):
             getattr(self, k).copy_(sd[k].to(self.weights.device))
         self.step_count, self.lr, self.current_epoch, self.global_step = int(sd["step"]), float(sd["lr"]), int(sd["epoch"]), int(sd["global_step"])
-        self.scheduler.load_state_dict(sd["scheduler"])
+        sched = sd["scheduler"]
+        if _world_size() > 1:   # a collective: EVERY rank must call load_state_dict.  Rank 0's file wins for everything the replicas must agree on -- not only
+            import torch.distributed as dist   # the tensors: the Adam step (bias correction), the learning rate, the epoch and the plateau scheduler's state
+            box = [(self.step_count, self.lr, self.current_epoch, self.global_step, sched)]
+            dist.broadcast_object_list(box, src=0)
+            self.step_count, self.lr, self.current_epoch, self.global_step, sched = box[0]
+        self.scheduler.load_state_dict(sched)
         self._lr_holder.param_groups[0]["lr"] = self.lr
         broadcast_from_rank0(self.weights, self.exp_avg, self.exp_avg_sq)
         self.sync_to_module()
@@ -323,7 +329,9 @@ class Trainer:
         s, hp = self.solver, self.solver.hparams
         maxiter = min([self.current_epoch * 20 + 1, hp.max_iterations])
         wavefields, h_states, k_sqs, residual, sources, timesteps, indices = self.replaybuffer.sample(hp.batch_size)
+        fwd_events = self.engine.counter("train_fwd_events")
         out = self.loss_and_grad(wavefields, h_states, k_sqs, residual, sources)
+        fwd_recorded = self.engine.counter("train_fwd_events") == fwd_events + 1 and getattr(self.engine, "_fwd_sumsq", None) is self._sumsq_host
         loss = out["loss"][0]
         T = out["residuals"].shape[0]
         iteration = np.random.choice(T)
@@ -332,8 +340,11 @@ class Trainer:
         # which sampled slots keep their (advanced) experience: bounded residual and young enough (:436-452).  The count of rejected slots decides how
         # many fresh maps Python's ``choice`` draws, as in the reference's loop, so the host needs the answer -- it waits for the FORWARD sweep only
         nb = wavefields.shape[0]
-        self._fwd_event.synchronize()
-        meansq = self._sumsq_host[: T * nb].view(T, nb)[iteration].numpy() / np.float32(res_it[0].numel())       # res.pow(2).mean() per sample, fp32
+        if fwd_recorded:
+            self._fwd_event.synchronize()
+            meansq = self._sumsq_host[: T * nb].view(T, nb)[iteration].numpy() / np.float32(res_it[0].numel())   # res.pow(2).mean() per sample, fp32
+        else:   # the library did not record the event for this call (a captured step, or another engine user replaced the registration): the reference's own reduction
+            meansq = res_it.pow(2).mean(dim=(1, 2, 3)).cpu().numpy()
         new_timesteps = np.asarray(timesteps, dtype=np.int64) + iteration + 1
         keep = (meansq < 1) & (new_timesteps < maxiter)
         fresh = np.nonzero(~keep)[0]

@@ -19,6 +19,15 @@
  *     who guarantees their lifetime until `stream` has been synchronised.
  *   - all work is enqueued asynchronously on the caller's `stream` (a hipStream_t passed as
  *     void*; NULL = the default stream).  A ctx is bound to one device and is NOT thread-safe.
+ *     ONE exception, "side streams": hn_step and hn_train_grad run part of their work on library streams beside the caller's, and HIP
+ *     deals streams onto a few hardware queues -- a library stream that shares the caller's queue silently serialises (inference -9 %,
+ *     the training step up to 3 x).  So the FIRST call that meets a new caller stream (per context and entry point) PROBES the library's
+ *     candidate streams against it: it synchronises that stream (hipStreamSynchronize), runs a 200 us spin kernel on it and an empty
+ *     kernel on a candidate, up to three times per candidate (majority), ~1 ms in all, and remembers the answer for that stream -- later
+ *     calls on any already-probed stream are asynchronous again.  The probe never runs while the caller's stream (or a stream it is
+ *     compared with) is being captured; a first call under capture uses candidate 0 unprobed.  A capture in global mode on ANOTHER thread
+ *     cannot be detected: make the first call before it, or disable probing.  HN_SIDE_PRIORITY=1 / 2 / 3 in the environment (lowest /
+ *     normal / highest priority candidate) disables probing altogether.  hn_get_counter(HN_CNT_STREAM_PROBES) counts the probes.
  *   - the library owns only its ctx: a re-packed copy of the weights, the spectral tables
  *     and the activation workspace (grown on demand by hn_reserve / the first call).
  */
@@ -62,15 +71,14 @@ enum hn_act { HN_ACT_PRELU = 0, HN_ACT_RELU = 1, HN_ACT_LEAKYRELU = 2, HN_ACT_CE
 enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_PREC_BF16X2 = 3, HN_PREC_FP32_VALU = 4 };
 
 /* Tuning knobs (hn_set_option).  Bit-exact ones -- the same kernels and summation order, only launched differently: LANES,
- * SIDE_STREAM, GRAPH, SPECTRAL_COLS (same butterflies, other memory access).  The others select a different kernel for the same
+ * SIDE_STREAM, SPECTRAL_COLS (same butterflies, other memory access).  The others select a different kernel for the same
  * fp32 arithmetic and agree to fp32 rounding, like two fp32 implementations of the reference do: DEEP (other summation order,
- * 2e-6 * max), SPECTRAL_PFA (FFT instead of the dense operator), SPECTRAL_RADIX16 (other butterfly order), DC_VALU, DC_WINO. */
+ * 2e-6 * max), SPECTRAL_PFA (FFT instead of the dense operator), SPECTRAL_RADIX16 (other butterfly order), DC_VALU. */
 enum hn_option {
-    HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1)                      */
+    HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1; [measured] 2 loses 3 % at 256^2 x 32 and
+                              * wins where a lane is a full batch of 32: 256^2 x 64 as two chains +19 % samples/s)              */
     HN_OPT_SIDE_STREAM = 1,  /* conv_state kernels: 0 in line; on a library side stream released 1 after the last `down`,
                               * 2 level by level behind conv_signal, 3 behind the fused deep level               */
-    HN_OPT_GRAPH = 2,        /* 0: launch every kernel (default; measured faster); 1: replay one captured iteration per HIP graph
-                              * launch; even n <= 64: n iterations per graph                                          */
     HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
     HN_OPT_SPECTRAL_PFA = 4, /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k, 7 * 2^k instead of the dense n x n operator (default 1;
                               * read by the next hn_set_domain)                                                     */
@@ -78,48 +86,42 @@ enum hn_option {
     HN_OPT_DC_VALU = 6,      /* fp32 DoubleConvs of the largest level (W >= 256) on the packed vector FMA (every FMA useful, same peak as the
                               * fp32 MFMA, whose 3x3 packing fills 75 % of its slots): 0 none (matrix core); 1 inc and the decoder, 2 all three on the
                               * compiler-scheduled kernel (hn_dcv.hip); 3 inc and the decoder, 4 (default) all three on the hand-scheduled kernel
-                              * (hn_dca.hip: all 8 mid channels per wavefront, LDS-direct staging; [measured, r5] +3 % it/s over 1); 5 / 6 its
-                              * two-wavefront form (one round of blocks; measured behind 4) */
+                              * (hn_dca.hip: all 8 mid channels per wavefront, LDS-direct staging; [measured, r5] +1 .. 3 % it/s over 1).  Smooth
+                              * activations and unaligned tensors always take hn_dcv.hip                                          */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
-    HN_OPT_TRAIN_LANES = 8,  /* hn_train_grad: 1 (default) the whole batch as one chain of launches; 2: the two halves of the batch as
-                              * two chains on two streams (samples are independent).  Same gradient up to the order of the final
-                              * sum over the halves.  Measured equal to 1: two overlapping chains of 16 samples take as long as
-                              * one chain of 32                                                            */
-    HN_OPT_DC_WINO = 9,      /* fp32 DoubleConvs of the largest level (W >= 256) as Winograd F(2x2, 3x3) on the packed vector FMA (2.25 x fewer
-                              * multiplies; weights G g G^T composed in float64 at hn_load_weights): sum of 1 (inc), 2 (conv_signal),
-                              * 8 (decoder), 16 / 32 (conv_signal / decoder one level down, W >= 128); default 0 = the direct kernels
-                              * HN_OPT_DC_VALU selects ([measured] the Winograd kernels are at parity with them, not ahead: DESIGN.md 4.2d).
-                              * Same fp32 sums in another order: agrees with the direct kernels to fp32 rounding                */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
                               * the inference path, which also store the pre-activation mid tensor to the tape; same tape within fp32
                               * rounding), 2 (backward pass: both backward-data convolutions of a big level's DoubleConv as one tiled
                               * launch; bit-identical gradients), 4 (the hidden-state DoubleConvs of all levels as one launch per
-                              * direction instead of two; bit-identical), 8 (experiment: the small levels' backward DoubleConvs on the tiled kernel) and
-                              * 16 (the backward-data pass of every 8-channel DoubleConv on the fp32 matrix core, k_dc_bwd_mfma_p: one launch, the g_z tile in
-                              * LDS; the f32 matrix instruction is an exact fmaf chain in the vector kernels' order: bit-identical gradients at the
-                              * training sizes) and 32 (with 4 and 16: conv_state's backward-data pass rides in the decoder's launch of the same level,
-                              * k_dc_bwd_mfma_aux; d loss / d out is added up in one accumulator: fp32 rounding); default 55, 0: every convolution as its own
-                              * launch (round 3)                                                                                         */
-    HN_OPT_SKIP_PRE = 12,    /* hn_step: the skip half of a decoder's first convolution (decode_d's conv1 runs over cat[up(x), skip_d],
-                              * architectures.py:458-460, and is linear in its input channels) summed ahead of time on the library side stream,
-                              * beside the small levels of the main chain; the decoder then starts from that sum and walks the upsampled half
-                              * only.  Sum of 1 (level 0), 2 (level 1; both only where the vector-pipe decoder runs, HN_OPT_DC_VALU >= 1 and
-                              * W >= 256, and with HN_OPT_SIDE_STREAM 1), 4 (A/B: one join for everything on the side stream); default 0: [measured, r5] the
-                              * decoder gains 17 us and the small levels beside the longer side stream lose as much (1905-1933 vs 1920-1941 it/s).
-                              * The same fp32 products summed skip half first: agrees with 0 to fp32 rounding                    */
-    HN_OPT_TRAIN_OVERLAP = 11 /* hn_train_grad, backward pass: where the three weight-gradient launches of unrolled iteration t run.  0: in line on the
-                              * caller's stream.  1: on a library stream beside the backward chain of iteration t - 1 (two sets of gradient buffers), the
-                              * same launches: bit-identical gradients, and measured equal (their blocks hold the CUs' LDS; the chain slows down by what the
-                              * overlap gains).  2 (default): on the library stream AND, where the chain is latency-bound (200 k .. 1 M pixels per call), with at
-                              * most ~2 of their blocks per CU -- each walks more tiles, the chain keeps half of every CU: 9.13 -> 8.77 ms at 96^2 x 32 -- and the forward
-                              * sweep's hidden-state launch on that stream beside the decoder.  The cap
-                              * changes how many partial sums a weight gradient is added up from: a fixed order (reproducible), not mode 0's  */
+                              * direction instead of two; bit-identical), 16 (the backward-data pass of every 8-channel DoubleConv on the fp32 matrix
+                              * core, k_dc_bwd_mfma_p: one launch, the g_z tile in LDS; the f32 matrix instruction is an exact fmaf chain in the vector
+                              * kernels' order: bit-identical gradients at the training sizes) and 32 (with 4 and 16: conv_state's backward-data pass
+                              * rides in the decoder's launch of the same level, k_dc_bwd_mfma_aux; d loss / d out is added up in one accumulator: fp32
+                              * rounding); default 55, 0: every convolution as its own launch (round 3).  (Value 8 is a lab setting: the small
+                              * levels' backward DoubleConvs on the tiled kernel; measured slower.)                                       */
+    HN_OPT_TRAIN_OVERLAP = 11, /* hn_train_grad, backward pass: where the three weight-gradient launches of unrolled iteration t run.  0: in line on the
+                              * caller's stream.  2 (default): on a library stream beside the backward chain of iteration t - 1 (two sets of gradient
+                              * buffers) AND, where the chain is latency-bound (200 k .. 1 M pixels per call), with at most ~2 of their blocks per CU --
+                              * each walks more tiles, the chain keeps half of every CU: 9.13 -> 8.77 ms at 96^2 x 32 -- and the forward sweep's
+                              * hidden-state launch on that stream beside the decoder.  The cap changes how many partial sums a weight gradient is added
+                              * up from: a fixed order (reproducible), not mode 0's.  (Value 1 is a lab setting: the side stream without
+                              * the cap; bit-identical to 0 and measured equal to it.)                                                    */
+    /* ---- laboratory knobs (same setter): implemented, tested bit-identical / equal within rounding, and MEASURED NOT TO HELP; they stay for A/B runs
+     * and are not part of the supported surface (DESIGN_NOTEBOOK.md has the measurements) ---- */
+    HN_EXP_GRAPH = 100,      /* 0: launch every kernel (default; measured 4 % faster); 1: replay one captured iteration per HIP graph
+                              * launch; even n <= 64: n iterations per graph.  Bit-identical                              */
+    HN_EXP_TRAIN_LANES = 101 /* hn_train_grad: 1 (default) the whole batch as one chain of launches; 2: the two halves of the batch as
+                              * two chains on two streams.  Same gradient up to the order of the final sum over the halves; measured equal to 1 */
 };
 /* Diagnostics counters (hn_get_counter). */
-enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2 };
+enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2,
+                  HN_CNT_STREAM_PROBES = 3,     /* reference-stream sets probed so far (see "side streams" in the conventions above) */
+                  HN_CNT_SIDE_CANDIDATE = 4,    /* candidate (0 .. 3) hn_step's side stream was last picked from; -1 before the first pick */
+                  HN_CNT_TRAIN_FWD_EVENTS = 5 };/* times hn_train_grad recorded the registered forward event (hn_train_set_forward_event): a caller compares the
+                                                 * counter before and after a call to know whether event and table are valid for it (not under capture) */
 
-#define HN_ABI_VERSION 5
+#define HN_ABI_VERSION 6
 int hn_abi_version(void);
 
 /* Create / destroy a context on HIP device `device_id`. */
@@ -249,7 +251,9 @@ int hn_train_reserve(hn_ctx* ctx, int batch, int n_unroll);
  * Stream capture (a caller recording the step into a HIP graph): supported with the workspace in place -- call hn_train_reserve (or run
  * one eager hn_train_grad of the same shape) first; a captured call whose workspace would have to grow returns HN_ERR_STATE instead of
  * breaking the capture.  The launch tables of a captured call live in a pinned buffer of their own that eager calls never rewrite; capturing a
- * SECOND graph on the same context rewrites it (one captured training step per context at a time). */
+ * SECOND graph on the same context rewrites it (one captured training step per context at a time).  Once a call has been captured, an eager call that
+ * needs a LARGER workspace (bigger batch, more unrolled iterations, another domain) returns HN_ERR_STATE instead of freeing memory the graph points into:
+ * destroy the graph and call hn_train_reserve (the caller's word that no captured step is replayed any more; it may re-allocate). */
 int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const float* res, const float* states, const float* k_sq,
                   const float* src, int src_batch, int batch, int n_unroll, float loss_scale, float* wf_hist, float* res_hist,
                   float* st_hist, float* loss, float* grad, float* grad_wf0, float* grad_res0, float* grad_st0, void* stream);
@@ -306,11 +310,10 @@ int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_
  *   20+2d up(d) | 21+2d decoder(d) (d=0 includes outc + wavefield update) |
  *   32 spectral column pass | 33 spectral row pass (or the dense operator) |
  *   34 the fused deepest level (conv_signal, conv_state, down, bottleneck, up, decoder of level depth-1 in one kernel;
- *      those six ids then do not occur) | 35 both spectral passes under ONE event pair
- *      | 36 + d (d = 0, 1) the skip half of decode_d's first convolution ahead of time (side stream, HN_OPT_SKIP_PRE).
+ *      those six ids then do not occur) | 35 both spectral passes under ONE event pair.
  * hn_profile_collect synchronises the recorded events, returns per-id total milliseconds and
  * launch counts for ids [0, n_ids) and resets the accumulators. */
-#define HN_KERNEL_IDS 38
+#define HN_KERNEL_IDS 36
 int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
 /* Bracket only every `every_nth` launch of a selected kernel (default 1), starting every_nth / 2 launches in.  An event pair
  * costs a few microseconds of stream gap, so timed runs sample instead of bracketing every launch. */

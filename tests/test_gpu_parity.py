@@ -44,7 +44,7 @@ def _err(name, got, g, n):
 def test_library_is_the_hip_build():
     from helmnet_amd import _lib
     lib = _lib.load()
-    assert lib.hn_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.hn_abi_version() == _lib.ABI_VERSION == 6
     assert torch.cuda.is_available()
 
 
@@ -449,10 +449,9 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
     ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=777).items()}
     src = SRC.get(n, [n // 3, n // 2])
     outs = {}
-    for valu in (6, 5, 4, 3, 2, 1, 0):   # all three level-0 DoubleConvs / inc + decoder on the hand-scheduled kernels (two-wave blocks: 6 / 5; four-wave: 4 / 3); the same on hn_dcv.hip; none
+    for valu in (4, 3, 2, 1, 0):   # all three level-0 DoubleConvs / inc + decoder on the hand-scheduled kernel (hn_dca.hip); the same on hn_dcv.hip; none
         s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
         s.set_domain_size(n, source_location=src)
-        s.engine().set_option("dc_wino", 0)   # (the Winograd kernels would take the level-0 DoubleConvs whatever dc_valu says)
         s.engine().set_option("dc_valu", valu)
         g = {k: v.to(DEV) for k, v in ti.items()}
         k_sq, _ = s.get_initials(g["sos"])
@@ -463,92 +462,19 @@ def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weight
     k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
     want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, src, 10.0), t)
     want = (want[0], want[1], O.flatten_states(want[2]))
-    for valu in (6, 5, 4, 3, 2, 1):
+    for valu in (4, 3, 2, 1):
         for a, bb, w in zip(outs[valu], outs[0], want):
             scale = w.abs().max().item()
             assert (a - bb).abs().max().item() <= 4e-6 * scale, (valu, (a - bb).abs().max().item() / scale)
             assert (a - w).abs().max().item() <= 1e-5 * scale, (valu, (a - w).abs().max().item() / scale)
     for a, w in zip(outs[0], want):
         assert (a - w).abs().max().item() <= 1e-5 * w.abs().max().item()
-    wfs = [outs[v][0] for v in (6, 5, 4, 3, 2, 1, 0)]
-    assert all(not torch.equal(wfs[i], wfs[j]) for i in range(7) for j in range(i))   # seven different kernel sets did run
-
-
-@pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])
-def test_winograd_doubleconvs_match_the_direct_ones_and_the_oracle(weights, n, b):
-    """hn_wino.hip (level-0 DoubleConvs as Winograd F(2x2, 3x3) on v_pk_fma_f32, the default at W >= 256) against the direct vector /
-    matrix-core kernels (HN_OPT_DC_WINO = 0) and against the oracle, for every subset of kinds the option can select: the same fp32
-    sums in another order, so every variant sits within 1e-5 * max of the oracle and within 4e-6 * max of the direct kernels.  320 has
-    a partial tile row / odd tile counts (no XCD remap); at 512 level 1 (W = 256) takes the kernels too."""
-    from helmnet_amd import IterativeSolver
-    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=4242).items()}
-    src = SRC.get(n, [n // 3, n // 2])
-    outs = {}
-    for mask in (0, 11, 1, 2, 8):
-        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
-        s.set_domain_size(n, source_location=src)
-        s.engine().set_option("dc_wino", mask)
-        g = {k: v.to(DEV) for k, v in ti.items()}
-        k_sq, _ = s.get_initials(g["sos"])
-        s.f.set_states(g["states"], flatten=True)
-        wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
-        outs[mask] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
-    t = O.SpectralTables(n, 8, 2, 1.0)
-    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
-    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, src, 10.0), t)
-    want = (want[0], want[1], O.flatten_states(want[2]))
-    for mask in (11, 1, 2, 8):
-        for a, d, w in zip(outs[mask], outs[0], want):
-            scale = w.abs().max().item()
-            assert (a - d).abs().max().item() <= 4e-6 * scale, (mask, (a - d).abs().max().item() / scale)
-            assert (a - w).abs().max().item() <= 1e-5 * scale, (mask, (a - w).abs().max().item() / scale)
-        assert not torch.equal(outs[mask][0], outs[0][0])   # another kernel did run
-
-
-@pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])
-def test_skip_half_of_the_decoder_ahead_of_time_matches_the_plain_decoder_and_the_oracle(weights, n, b):
-    """HN_OPT_SKIP_PRE (hn_dcv.hip: k_conv3_pre on the side stream + k_dc_valu<..., PIN>): decode_d's first convolution over cat[up(x), skip]
-    (architectures.py:458-460) with the skip half summed ahead of time, against the one-kernel decoder (option 0) and the oracle.  The same
-    fp32 products summed skip half first: within 4e-6 * max of the plain decoder and 1e-5 * max of the oracle.  At 512 level 1 (W = 256)
-    takes the path too (masks 1, 2, 3); mask 7 joins the side stream once; 320 has partial tiles; several iterations through hn_step, so
-    that the side stream's buffers are reused across iterations."""
-    from helmnet_amd import IterativeSolver
-    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=31337).items()}
-    src = SRC.get(n, [n // 3, n // 2])
-    outs, runs = {}, {}
-    for mask in (0, 3, 1, 2, 7):
-        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
-        s.set_domain_size(n, source_location=src)
-        s.engine().set_option("dc_valu", 1)
-        s.engine().set_option("skip_pre", mask)
-        g = {k: v.to(DEV) for k, v in ti.items()}
-        k_sq, _ = s.get_initials(g["sos"])
-        s.f.set_states(g["states"], flatten=True)
-        wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
-        outs[mask] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
-        o = s.forward(g["sos"], num_iterations=12)
-        runs[mask] = (o["wavefields"][0].cpu(), o["residuals"][-1].cpu())
-    t = O.SpectralTables(n, 8, 2, 1.0)
-    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
-    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, src, 10.0), t)
-    want = (want[0], want[1], O.flatten_states(want[2]))
-    for mask in (3, 1, 2, 7):
-        for a, d, w in zip(outs[mask], outs[0], want):
-            scale = w.abs().max().item()
-            assert (a - d).abs().max().item() <= 4e-6 * scale, (mask, (a - d).abs().max().item() / scale)
-            assert (a - w).abs().max().item() <= 1e-5 * scale, (mask, (a - w).abs().max().item() / scale)
-        for a, d in zip(runs[mask], runs[0]):   # 12 free-running iterations: rounding differences grow, slowly
-            assert (a - d).abs().max().item() <= 1e-4 * d.abs().max().item(), (mask, (a - d).abs().max().item() / d.abs().max().item())
-    assert not torch.equal(outs[1][0], outs[0][0])                       # the pin decoder did run at level 0
-    assert torch.equal(outs[7][0], outs[3][0])                           # the join policy changes no bit
-    if n >= 512:
-        assert not torch.equal(outs[2][0], outs[0][0]) and not torch.equal(outs[3][0], outs[1][0])   # ... and at level 1
-    else:
-        assert torch.equal(outs[2][0], outs[0][0])                       # W = 128 stays on the matrix core: mask 2 is a no-op at 256 / 320
+    wfs = [outs[v][0] for v in (4, 3, 2, 1, 0)]
+    assert all(not torch.equal(wfs[i], wfs[j]) for i in range(5) for j in range(i))   # five different kernel sets did run
 
 
 def test_graph_replay_is_bit_identical_to_kernel_by_kernel_launches(solver):
-    """HN_OPT_GRAPH: one captured iteration per graph, and 4 iterations per graph, against the default launches -- the
+    """HN_EXP_GRAPH: one captured iteration per graph, and 4 iterations per graph, against the default launches -- the
     same kernels with the same arguments in the same order, so every output bit agrees (the RMSE history goes through
     the device-side iteration counter in all three)."""
     n, b, K = 128, 3, 21
@@ -570,3 +496,63 @@ def test_graph_replay_is_bit_identical_to_kernel_by_kernel_launches(solver):
                 assert torch.allclose(a, bb, rtol=1e-5)
             else:
                 assert torch.equal(a, bb)
+
+
+def test_side_stream_pick_is_probed_once_per_caller_stream_and_stable_under_load():
+    """hn_step's side stream is PROBED against the caller's stream (include/helmnet_hip.h, "side streams"): once per caller stream and context --
+    a caller alternating between two streams never re-probes --, never under stream capture, and with the same answer in ten fresh
+    contexts while a second context keeps the GPU busy on its own stream (three samples per candidate, majority; VERDICT r4 #6b)."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import ring_sos_batch
+
+    def fresh(n=128, b=2):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=[20, n // 2])
+        sos = torch.from_numpy(ring_sos_batch(n, b, seed=3)).to(DEV)
+        k_sq, wf = s.get_initials(sos)
+        s.f.clear_states(wf)
+        res = s.get_residual(wf, k_sq)
+        st = s.f.get_states(flatten=True).contiguous()
+        return s, (wf, res, st, k_sq.contiguous(), s.source.detach().contiguous())
+
+    # a busy neighbour: a 256^2 x 16 solve running on a stream of its own in another context
+    busy, bargs = fresh(256, 16)
+    busy_stream = torch.cuda.Stream()
+    with torch.cuda.stream(busy_stream):
+        busy.engine().step(*bargs, 3)
+    torch.cuda.synchronize()
+    picks = []
+    for i in range(10):
+        with torch.cuda.stream(busy_stream):
+            busy.engine().step(*bargs, 40)          # ~25 ms of kernels beside the probes below
+        s, args = fresh()
+        eng = s.engine()
+        assert eng.counter("stream_probes") == 0 and eng.counter("side_candidate") == -1
+        eng.step(*args, 2)
+        assert eng.counter("stream_probes") == 1
+        picks.append(eng.counter("side_candidate"))
+        other = torch.cuda.Stream()
+        for _ in range(3):                          # alternate between two caller streams: one more probe, then none
+            with torch.cuda.stream(other):
+                eng.step(*args, 1)
+            eng.step(*args, 1)
+        assert eng.counter("stream_probes") == 2, eng.counter("stream_probes")
+        torch.cuda.synchronize()
+    assert len(set(picks)) == 1, picks
+    # a caller stream first met UNDER CAPTURE is not probed (the probe would synchronise it): candidate 0 until an eager call meets that stream
+    s, args = fresh()
+    ref = [a.clone() for a in args]
+    eng = s.engine()
+    eng.step(*args, 2)                              # eager, default stream: allocations and the one probe happen here
+    torch.cuda.synchronize()
+    assert eng.counter("stream_probes") == 1
+    g = torch.cuda.CUDAGraph()
+    cap = torch.cuda.Stream()
+    with torch.cuda.stream(cap):
+        with torch.cuda.graph(g, stream=cap):
+            eng.step(*args, 2)
+    assert eng.counter("stream_probes") == 1
+    g.replay(); torch.cuda.synchronize()
+    s2, _ = fresh()
+    s2.engine().step(*ref, 2); s2.engine().step(*ref, 2); torch.cuda.synchronize()
+    assert torch.equal(args[0], ref[0]) and torch.equal(args[1], ref[1])

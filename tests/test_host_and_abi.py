@@ -22,7 +22,7 @@ def test_header_symbols_all_exported():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.hn_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.hn_abi_version() == _lib.ABI_VERSION == 6
     assert lib.hn_weight_count(8, 4, 2) == 48160
     assert lib.hn_weight_count(16, 4, 2) == 0
     # no GPU here: creating a context must fail cleanly with a message, not crash
@@ -37,7 +37,9 @@ def test_python_enum_tables_match_the_header():
     from helmnet_amd import _lib
     hdr = open(os.path.join(REPO, "include", "helmnet_hip.h")).read()
     enums = {name: int(val) for name, val in re.findall(r"\b(HN_[A-Z0-9_]+)\s*=\s*(-?\d+)", hdr)}
-    for table, prefix, rename in ((_lib.HN_OPTION, "HN_OPT_", {}), (_lib.HN_ACT, "HN_ACT_", {}),
+    opt = {k: v for k, v in _lib.HN_OPTION.items() if v < 100}      # supported knobs: HN_OPT_*; laboratory knobs (>= 100): HN_EXP_*
+    exp = {k: v for k, v in _lib.HN_OPTION.items() if v >= 100}
+    for table, prefix, rename in ((opt, "HN_OPT_", {}), (exp, "HN_EXP_", {}), (_lib.HN_ACT, "HN_ACT_", {}),
                                   (_lib.HN_PRECISION, "HN_PREC_", {"valu": "FP32_VALU"}), (_lib.HN_COUNTER, "HN_CNT_", {})):
         in_header = {k: v for k, v in enums.items() if k.startswith(prefix)}
         mine = {prefix + rename.get(k, k).upper(): v for k, v in table.items()}

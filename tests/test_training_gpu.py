@@ -584,6 +584,17 @@ def test_training_step_can_be_captured_in_a_hip_graph(solver, weights, n, b):
     again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
     torch.cuda.synchronize()
     assert torch.equal(g, want) and abs(float(again["loss"]) - float(want_loss)) <= 1e-6 * float(want_loss)
+    # ... but an eager call that would have to GROW the workspace is refused while a captured step may still be replayed (its graph points into the
+    # workspace), until hn_train_reserve says the graph is gone
+    with pytest.raises(Exception, match="captured"):
+        eng.train_grad(blob, *args, 25, 1e4, grad=g)
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(g, want)
+    del graph
+    eng.train_reserve(b, 25)
+    more = eng.train_grad(blob, *args, 25, 1e4, grad=g)
+    torch.cuda.synchronize()
+    assert torch.isfinite(more["grad"]).all()
 
 
 def test_adam_three_steps_match_the_reference_optimiser(solver, weights, g_train):
