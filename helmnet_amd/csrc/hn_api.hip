@@ -67,7 +67,7 @@ struct Packer {
     DcW dc(int cin, int cm, int co) {
         DcW w;
         w.act = act;
-        w.w1q = w.wa = nullptr;   // set by hn_load_weights for the 8-channel DoubleConvs
+        w.w1q = w.wa = w.wa2 = nullptr;   // set by hn_load_weights for the 8-channel DoubleConvs
         repack_oihw(src + pos, dst.data() + pos, cm, cin, 9);
         w.w1 = dev + pos; pos += (size_t)cm * cin * 9;
         std::memcpy(dst.data() + pos, src + pos, sizeof(float) * cm);
@@ -372,6 +372,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             {
                 static const float inc_scale_a[kInCh] = {1.f, 1.f, 1000.f, 1000.f, 1.f, 1.f};
                 offa.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 72); pack_dca(w1, cin, cin == kInCh ? inc_scale_a : nullptr, fr.data() + offa.back());
+                offa.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * 72); pack_dca(w2, kFeat, nullptr, fr.data() + offa.back());
             }
             // each fp32 fragment block is followed by its split-bf16 and fp16 twins (launch_dc8 relies on this order)
             off.push_back(fr.size()); fr.resize(fr.size() + (size_t)cin * 3 * 64); pack_frag_3x3(w1, cin, fr.data() + off.back());
@@ -435,9 +436,10 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
             for (int d = 0; d < depth; ++d) ctx->sig[d].w1q = ctx->fragdev + offq[iq++];
             for (int d = 0; d <= depth; ++d) ctx->dec[d].w1q = ctx->fragdev + offq[iq++];
             size_t ia = 0;
-            ctx->inc.wa = ctx->fragdev + offa[ia++];
-            for (int d = 0; d < depth; ++d) ctx->sig[d].wa = ctx->fragdev + offa[ia++];
-            for (int d = 0; d <= depth; ++d) ctx->dec[d].wa = ctx->fragdev + offa[ia++];
+            auto seta = [&](DcW& w) { w.wa = ctx->fragdev + offa[ia++]; w.wa2 = ctx->fragdev + offa[ia++]; };
+            seta(ctx->inc);
+            for (int d = 0; d < depth; ++d) seta(ctx->sig[d]);
+            for (int d = 0; d <= depth; ++d) seta(ctx->dec[d]);
         }
         ctx->zero_page = ctx->fragdev + off_zero;
         ctx->f_dec0c = ctx->fragdev + off_comp;

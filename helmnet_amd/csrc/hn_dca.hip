@@ -79,6 +79,15 @@ __device__ __forceinline__ void conv1_cin(f32x2 (&a)[9][4], f32x2 (&e)[4], unsig
 #define HN_TR(i) do { } while (0)
 #endif
 
+// conv2 (8 -> 8) of this wave over the 8 LDS-resident mid channels, 24 chained passes (tools/gen_dca_asm.py: conv2_block)
+__device__ __forceinline__ void conv2_all(f32x2 (&a)[4][4], unsigned mid_addr, const float* wts) {
+    asm volatile(HN_DCA_CONV2_ASM
+                 : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]),
+                   "+v"(a[2][0]), "+v"(a[2][1]), "+v"(a[2][2]), "+v"(a[2][3]), "+v"(a[3][0]), "+v"(a[3][1]), "+v"(a[3][2]), "+v"(a[3][3])
+                 : "v"(mid_addr), "s"(wts)
+                 : HN_DCA_CIN_CLOBBERS);
+}
+
 template <int CA, int CB, int CC, int EPI>
 __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, const float* zero_page, int H, int W) {
     constexpr int CIN = CA + CB + CC, NG = CIN / 2;
@@ -290,8 +299,12 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
             }
         }
         __syncthreads();
+#ifdef HN_DCA_CONV2_CPP   // (A/B: hn_dcv.hip's compiler-scheduled loop)
 #pragma unroll 2
         for (int cm = 0; cm < kFeat; ++cm) conv_rows<4, 4>(acc2, mid + cm * kMPlane, kPM, cw(w.w2 + cm * 72));
+#else
+        conv2_all(acc2, 4u * (unsigned)((4 * wave) * kPM + lane), w.wa2);
+#endif
         if (ox < W) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

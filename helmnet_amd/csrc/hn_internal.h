@@ -41,6 +41,7 @@ struct DcW {
     int act;   // hn_act
     const float* w1q;   // conv1 again as [cin][2 channel halves][3][3][4] (8-channel DoubleConvs only; hn_dcv.hip)
     const float* wa;    // conv1 again as [cin][3 kx][3 ky][8] with the input scales folded in (8-channel DoubleConvs only; hn_dca.hip)
+    const float* wa2;   // conv2 likewise: [8 cm][3 kx][3 ky][8]
 };
 
 // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (private L2 each; MI355X_MICROARCH.md, "Workgroup

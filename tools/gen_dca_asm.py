@@ -73,6 +73,43 @@ def cin_block(with_loads=True, with_fmas=True):
     return lines
 
 
+def conv2_block(nch=8, rows=4, pitch_bytes=66 * 4, chan_bytes=18 * 66 * 4):
+    """conv2 (8 -> 8) of one wavefront: `rows` output rows x all 8 output channels over the `nch` mid channels resident in LDS, 3 * nch passes chained --
+    the loads of pass q + 1 (next kernel column, or the next channel's first) are requested at the top of pass q; no barriers inside.
+    Operands: %0 .. %(4 rows - 1) acc2[r][c] (+v, 64-bit); %(4 rows) v byte address in LDS of (mid row of the wave's first output row - 1 + 1 ..., see
+    hn_dca.hip) ; %(4 rows + 1) s 64-bit address of the weights [nch][3 kx][3 ky][8]."""
+    na = 4 * rows
+    xset = (100, 100 + rows + 2)
+    lines = []
+
+    def loads(q):
+        cm, kx = divmod(q, 3)
+        ws, xs = WSET[q & 1], xset[q & 1]
+        for k in range(3):
+            lines.append(f"s_load_dwordx8 s[{ws + 8 * k}:{ws + 8 * k + 7}], %{na + 1}, {hex(cm * 288 + kx * 96 + 32 * k)}")
+        for j in range(rows + 2):
+            lines.append(f"ds_read_b32 v{xs + j}, %{na} offset:{cm * chan_bytes + j * pitch_bytes + 4 * kx}")
+
+    def fmas(q):
+        ws, xs = WSET[q & 1], xset[q & 1]
+        for j in range(rows + 2):
+            src, mod = bcast(xs + j)
+            for ky in range(3):
+                r = j - ky
+                if r < 0 or r >= rows:
+                    continue
+                for c in range(4):
+                    lines.append(f"v_pk_fma_f32 %{4 * r + c}, s[{ws + 8 * ky + 2 * c}:{ws + 8 * ky + 2 * c + 1}], {src}, %{4 * r + c} {mod}")
+
+    loads(0)
+    for q in range(3 * nch):
+        lines.append("s_waitcnt lgkmcnt(0)")
+        if q + 1 < 3 * nch:
+            loads(q + 1)
+        fmas(q)
+    return lines
+
+
 def main():
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "helmnet_amd", "csrc", "hn_dca_pass.inc")
     body = cin_block()
@@ -89,6 +126,14 @@ def main():
             for l in lines:
                 f.write(f'    "{l}\\n" \\\n')
             f.write('    ""\n')
+        c2 = conv2_block()
+        assert sum(1 for l in c2 if l.startswith("v_pk_fma")) == 8 * 9 * 4 * 4
+        f.write(f"// conv2 (8 -> 8) of one wavefront, 4 output rows x 8 channels over the 8 LDS-resident mid channels: {sum(1 for l in c2 if l.startswith('v_pk_fma'))} "
+                f"v_pk_fma_f32, {sum(1 for l in c2 if l.startswith('ds_read'))} ds_read_b32, {sum(1 for l in c2 if l.startswith('s_load'))} s_load_dwordx8\n")
+        f.write("#define HN_DCA_CONV2_ASM \\\n")
+        for l in c2:
+            f.write(f'    "{l}\\n" \\\n')
+        f.write('    ""\n')
         clob = [f"s{i}" for i in range(40, 88)] + [f"v{i}" for i in range(100, 128)]
         f.write("#define HN_DCA_CIN_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "memory"\n')
     print(out, len(body), "instructions")
