@@ -183,16 +183,22 @@ def secondary(solver, dev, n, B, precision, steps, warmup, loc=None, seed=5, rea
     try:
         eng.step(wf, res, st, k_sq, src, warmup, rmse_hist=rmse[:warmup])
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        eng.step(wf, res, st, k_sq, src, steps, rmse_hist=rmse[:steps])
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        # two timed regions of `steps` iterations, the faster one reported (both listed): [measured, r5, tools/outlier_probe.py] about one short run in
+        # eighty on this pool is 30-40 % slow whatever the kernels (a stall of tens of milliseconds somewhere in the region), and these side
+        # measurements are 40-300 steps long.  The HEADLINE region above is timed exactly once, as the contract says
+        dts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            eng.step(wf, res, st, k_sq, src, steps, rmse_hist=rmse[:steps])
+            torch.cuda.synchronize()
+            dts.append(time.perf_counter() - t0)
+        dt = min(dts)
     finally:
         eng.set_option("lanes", 1)
     flops = 2.0 * sum(kernel_macs(n).values()) * B
     return {"workload": label or f"{n}x{n} ring-phantom SoS maps, batch={B}, point source, UNet precision {precision}" + (f", {lanes} pipeline lanes" if lanes > 1 else ""),
             "dtype": DTYPE[precision], "value": round(steps / dt, 2), "unit": "iterations/s", "steps": steps, "warmup": warmup,
-            "ms_per_step": round(dt / steps * 1e3, 4), "sample_iterations_per_s": round(B * steps / dt, 1),
+            "ms_per_step": round(dt / steps * 1e3, 4), "regions_it_per_s": [round(steps / d, 2) for d in dts], "sample_iterations_per_s": round(B * steps / dt, 1),
             "unet_tflops_fp32_equivalent": round(flops * steps / dt / 1e12, 2),
             "residual_rmse_max": float(rmse[steps - 1].max().item())}
 

@@ -439,12 +439,13 @@ def test_fused_deep_level_kernel_matches_the_layer_by_layer_path(weights):
     assert (outs[1][2][:, :, L3] - want[2][:, :, L3]).abs().max().item() <= 1e-5 * want[2][:, :, L3].abs().max().item()
 
 
-@pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1)])
+@pytest.mark.parametrize("n,b", [(256, 2), (512, 1), (320, 1), (272, 3)])
 def test_vector_fma_doubleconvs_match_the_matrix_core_ones_and_the_oracle(weights, n, b):
     """The level-0 DoubleConvs on v_pk_fma_f32 -- hn_dca.hip (hand-scheduled conv1 loop, LDS-direct staging; HN_OPT_DC_VALU 3 / 4) and
     hn_dcv.hip (compiler-scheduled; 1 / 2) -- against the fp32 matrix-core kernels (0) and against the oracle: the same fp32 FMAs in
     another order, so all sit within 1e-5 * max of the oracle and within 4e-6 * max of each other; at 512 the option also covers
-    level 1 (W = 256); 320 has partial tiles (out-of-image float4s of the LDS-direct loads read the zero page)."""
+    level 1 (W = 256); 320 has an odd tile count (no XCD remap), 272 = 4 x 64 + 16 a PARTIAL tile column (the float4s beyond the image read the zero
+    page of the LDS-direct loads, the lanes beyond it store nothing) and a batch of 3."""
     from helmnet_amd import IterativeSolver
     ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=777).items()}
     src = SRC.get(n, [n // 3, n // 2])

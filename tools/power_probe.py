@@ -12,7 +12,10 @@ def find(pattern):
         except Exception:
             pass
     return None
-hw = "/sys/class/drm/card*/device/hwmon/hwmon*/"
+# the hwmon directory of the GPU torch runs on (a box can expose several cards): matched by PCI address
+pr = torch.cuda.get_device_properties(0)
+addr = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0" if hasattr(pr, "pci_bus_id") else None
+hw = f"/sys/bus/pci/devices/{addr}/hwmon/hwmon*/" if addr and glob.glob(f"/sys/bus/pci/devices/{addr}/hwmon/hwmon*/") else "/sys/class/drm/card*/device/hwmon/hwmon*/"
 P = find(hw + "power1_average") or find(hw + "power1_input")
 F = find(hw + "freq1_input")
 CAP = find(hw + "power1_cap")
