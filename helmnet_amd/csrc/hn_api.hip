@@ -114,6 +114,7 @@ void free_workspace(hn_ctx* c) {
         if (d < kMaxDepth) { (void)hipFree(c->buf_o[d]); c->buf_o[d] = nullptr; }
     }
     (void)hipFree(c->st_tmp); c->st_tmp = nullptr;
+    (void)hipFree(c->pair_flags); c->pair_flags = nullptr; c->pair_flags_cap = 0;
     c->cap_batch = 0;
 }
 
@@ -188,7 +189,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_EXP_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}};
+                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 3 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -240,6 +241,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_DC_VALU:
             if (value < 0 || value > 4) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_VALU must be 0 .. 4 (got %d)", value);
             ctx->opt_dc_valu = value;
+            break;
+        case HN_OPT_DC_PAIR:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_PAIR must be 0 or 1 (got %d)", value);
+            ctx->opt_dc_pair = value;
             break;
         case HN_OPT_SPECTRAL_RADIX16:
             if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_SPECTRAL_RADIX16 must be 0, 1 or 2 (got %d)", value);
@@ -498,6 +503,9 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
         if (d > 0) HN_HIP(ctx, hipMalloc((void**)&ctx->buf_y[d], bytes));
     }
     HN_HIP(ctx, hipMalloc((void**)&ctx->st_tmp, sizeof(float) * (size_t)max_batch * kState * ctx->state_len));
+    ctx->pair_flags_cap = (long)((n + 63) / 64) * ((n + 15) / 16) * max_batch;   // one flag word per level-0 tile (k_dc_asm_pair); epochs start at 1
+    HN_HIP(ctx, hipMalloc((void**)&ctx->pair_flags, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
+    HN_HIP(ctx, hipMemset(ctx->pair_flags, 0, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
     ctx->cap_batch = max_batch;
     return HN_OK;
 }

@@ -88,22 +88,39 @@ __device__ __forceinline__ void conv2_all(f32x2 (&a)[4][4], unsigned mid_addr, c
                  : HN_DCA_CIN_CLOBBERS);
 }
 
-template <int CA, int CB, int CC, int EPI>
-__global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, const float* zero_page, int H, int W) {
+// ROLE 0: a launch of its own.  ROLE 1 / 2: the producer / consumer half of a two-phase launch (k_dc_asm_pair below): the producer writes its output tile
+// through (sc1 stores), drains them and publishes flags[tile] = epoch; the consumer first waits for the flags of the (up to nine) producer tiles its input
+// window touches and stages with sc1 LDS-direct loads.
+struct PairSync { unsigned* flags; unsigned epoch; int tile, tx, ty, gx, gy; };
+
+template <int CA, int CB, int CC, int EPI, int ROLE>
+__device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, Dst out, const DcW& w, const VcEpi& epi, const float* zero_page, int H, int W,
+                                            int b, int x0, int y0, int tr_id, PairSync ps) {
     constexpr int CIN = CA + CB + CC, NG = CIN / 2;
     static_assert(CIN % 2 == 0 && CA % 2 == 0 && CB % 2 == 0, "a chunk is two channels of one source");
-    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = wave >> 1, s = wave & 1;
-    const TileId tl = xcd_tile();
-    const int b = tl.z;
-    const int x0 = tl.x * 64, y0 = tl.y * 16;
 #ifdef HN_ATRACE
-    const int tr_id = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191;
     if (EPI == 1 && tid == 0) { unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_dca_trace[tr_id][7] = hw; }
 #endif
     HN_TR(0);
+    __shared__ int s_ok;
+    if (ROLE == 2) {   // the producer tiles this tile's window touches: rows y0 - 2 .. y0 + 17, columns x0 - 4 .. x0 + 67
+        if (wave == 0) {
+            const int dy = lane / 3 - 1, dx = lane % 3 - 1;
+            const bool need = lane < 9 && ps.ty + dy >= 0 && ps.ty + dy < ps.gy && ps.tx + dx >= 0 && ps.tx + dx < ps.gx;
+            const unsigned* f = ps.flags + (need ? ps.tile + dy * ps.gx + dx : ps.tile);
+            bool got = !need;
+            for (int spin = 0; spin < 2000000; ++spin) {   // bounded: a block that gives up poisons its output instead of hanging the GPU
+                if (!got) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ps.epoch;
+                if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (lane == 0) s_ok = __builtin_amdgcn_ballot_w64(!got) == 0 ? 1 : 0;
+        }
+        __syncthreads();
+    }
 
     // ---- staging plan: wave-instruction k of a chunk writes float4s [64 k, 64 k + 64) of the chunk buffer; wave w issues k = w, 4 + w, 8 + w ----
     unsigned goff[3];
@@ -133,7 +150,8 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
         for (int i = 0; i < 3; ++i) {
             const char* src = gsel[i] == 2 ? reinterpret_cast<const char*>(zero_page) : (gsel[i] ? p1 : p0) + goff[i];
             float* dst = lds + buf * kChunk + (wave + 4 * i) * 256;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            // (ROLE 2: sc1 -- the first channel group is what producer blocks of THIS launch wrote through; harmless for the other tensors)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, ROLE == 2 ? 16 : 0);
         }
     };
 
@@ -305,6 +323,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
 #else
         conv2_all(acc2, 4u * (unsigned)((4 * wave) * kPM + lane), w.wa2);
 #endif
+        const float poison = ROLE == 2 && !s_ok ? __builtin_nanf("") : 0.f;   // (a consumer whose inputs never arrived: loud, not silent)
         if (ox < W) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -312,14 +331,63 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
                     float* p = out.p + (long)b * out.sb + (long)(yb + r) * W + ox;
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        p[(long)(2 * c) * out.sc] = acc2[r][c][0];
-                        p[(long)(2 * c + 1) * out.sc] = acc2[r][c][1];
+                        if (ROLE == 1) {   // write-through: the tile must have left this CU before its flag says so
+                            __hip_atomic_store(p + (long)(2 * c) * out.sc, acc2[r][c][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(p + (long)(2 * c + 1) * out.sc, acc2[r][c][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } else {
+                            p[(long)(2 * c) * out.sc] = acc2[r][c][0] + poison;
+                            p[(long)(2 * c + 1) * out.sc] = acc2[r][c][1] + poison;
+                        }
                     }
                 }
             }
         }
+        if (ROLE == 1) {   // publish: every store of the block has left (vmcnt), then the flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(ps.flags + ps.tile, ps.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
+
+template <int CA, int CB, int CC, int EPI>
+__global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, const float* zero_page, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    const TileId tl = xcd_tile();
+    const int tr_id = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191;
+    dc_asm_body<CA, CB, CC, EPI, 0>(lds, sa, sb, sc, out, w, epi, zero_page, H, W, tl.z, tl.x * 64, tl.y * 16, tr_id, PairSync{nullptr, 0u, 0, 0, 0, 0, 0});
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// inc and conv_signal_0 as ONE launch (r5).  Nothing of kernel k + 1 can start before the LAST block of kernel k has finished, and every big kernel of
+// the chain loses ~20 % of its span to an in-phase first round and a ragged tail.  conv_signal_0 reads inc's output tile by tile (a
+// 16 x 64 tile needs the 3 x 3 tiles around it), so the two run as 2 T blocks of one grid: block t < T is inc on tile t, block T + t is conv_signal_0 on
+// tile t and first waits for the (up to nine) inc tiles it reads -- one flag word per tile, written with the launch's epoch.  [measured,
+// tools/ubench_dataflow.hip] two dependent 75 us phases: 146-150 us as two launches, 124-125 us as one.
+//   * no deadlock: workgroups are dispatched in order, so by the time any conv_signal block holds a slot every inc block is resident or done; the poll
+//     is bounded all the same (a block that gives up poisons its output with NaN instead of hanging the GPU);
+//   * visibility without fences (a device-scope release / acquire pair is a whole-L2 write-back here: +60 us in the micro-benchmark): inc's output
+//     stores are write-through (sc1), drained (s_waitcnt vmcnt(0)) before the flag is published with an agent-scope store; conv_signal polls with
+//     agent-scope loads and stages that tensor with sc1 LDS-direct loads (what an agent-scope relaxed atomic access compiles to on gfx950);
+//   * used by hn_step's single-lane eager path only (the epoch travels in the kernel arguments: not under capture); anything else launches the two
+//     kernels as before.  Same arithmetic in the same order as the separate launches: results are bit-identical.
+// ------------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, Dst x0_out, DcW w_inc, Src b0, Src b1, Dst out0, DcW w_sig, const float* zero_page,
+                                                         int H, int W, int gx, int gy, int T, unsigned* flags, unsigned epoch) {
+    __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+    const bool second = __builtin_amdgcn_readfirstlane((int)blockIdx.x) >= T;   // wave-uniform
+    int tile = second ? (int)blockIdx.x - T : (int)blockIdx.x;
+#ifndef HN_NO_XCD
+    if ((T & 7) == 0) tile = (tile & 7) * (T >> 3) + (tile >> 3);   // xcd_tile(): block i and block T + i share an XCD, and so do a tile's neighbours
+#endif
+    const int tq = tile / gx, tx = tile - tq * gx, b = tq / gy, ty = tq - b * gy;
+    const PairSync ps{flags, epoch, tile, tx, ty, gx, gy};
+    const VcEpi noepi{nullptr, nullptr, nullptr, nullptr};
+    const Src none{nullptr, 0, 0, 1.f};
+    if (second) dc_asm_body<kFeat, kState, 0, 0, 2>(lds, b0, b1, none, out0, w_sig, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps);
+    else dc_asm_body<2, 2, 2, 0, 1>(lds, a0, a1, a2, x0_out, w_inc, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps);
+}
+
 
 template <int CA, int CB, int CC, int EPI>
 void launch(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, const float* zero_page, int H, int W, int batch, hipStream_t s) {
@@ -365,6 +433,21 @@ void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const Dc
             if (final_epi) launch<kFeat, kFeat, 0, 1>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s);  // decoder (+ out-conv, wavefield update)
             else launch<kFeat, kFeat, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s);
     }
+}
+
+// inc + conv_signal_0 as one launch (k_dc_asm_pair): both must be what launch_dc_asm would run with tile order and sizes in common
+bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch) {
+    if (!ctx->opt_dc_pair || ctx->pair_flags == nullptr) return false;
+    const Src none{nullptr, 0, 0, 1.f};
+    if (!dc_asm_applies(ctx, ctx->inc.act, wf, res, sig, 0, H, W) || !dc_asm_applies(ctx, ctx->sig[0].act, x0, st, none, 1, H, W)) return false;
+    return (long)cdiv_(W, 64) * cdiv_(H, 16) * batch <= ctx->pair_flags_cap;
+}
+
+void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, hipStream_t s) {
+    const int gx = cdiv_(W, 64), gy = cdiv_(H, 16), T = gx * gy * batch;
+    const unsigned epoch = ++ctx->pair_epoch;
+    hipLaunchKernelGGL(k_dc_asm_pair, dim3(2 * T), dim3(256), 0, s, wf, res, sig, x0_out, ctx->inc, x0, st, out0, ctx->sig[0], ctx->zero_page, H, W, gx, gy, T,
+                       ctx->pair_flags, epoch);
 }
 
 }  // namespace hn

@@ -154,6 +154,10 @@ struct hn_ctx {
     int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
     int opt_dc_valu = 4;       // fp32 DoubleConvs of the big levels on the packed vector FMA: 0 none, 1 inc + decoder (hn_dcv.hip), 2 all three;
                                // 3 / 4 (default): the same two / three on the hand-scheduled kernel (hn_dca.hip)
+    int opt_dc_pair = 1;       // HN_OPT_DC_PAIR: inc and conv_signal_0 as one launch with per-tile flags (hn_dca.hip, k_dc_asm_pair); hn_step's single-lane eager path
+    unsigned* pair_flags = nullptr;   // one word per level-0 tile of the reserved batch: the epoch of the launch whose inc block wrote that tile
+    long pair_flags_cap = 0;
+    unsigned pair_epoch = 0;
     const float* zero_page = nullptr;   // 256 zero bytes (out-of-image float4s of the LDS-direct staging loads, hn_dca.hip)
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
@@ -296,7 +300,8 @@ enum KernelId : int {
     KID_SPEC_ROWS = 33,   // spectral row pass + residual terms (or the dense operator)
     KID_DEEP = 34,        // deepest level in one per-sample kernel: conv_signal, conv_state, down, bottleneck, up, decoder
     KID_SPEC_PAIR = 35,   // one bracket around both spectral passes (the HBM-bound part of the path as a whole)
-    KID_COUNT = 36
+    KID_INC_SIG0 = 36,    // inc and conv_signal_0 as one launch (hn_dca.hip, k_dc_asm_pair); KID_INC and KID_SIG0 then do not occur
+    KID_COUNT = 37
 };
 
 // RAII event pair around one launch when that kernel id is selected by hn_profile_enable.
@@ -399,6 +404,9 @@ void pack_dca(const float* w_oihw, int cin, const float* scale, float* dst);   /
 bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
 void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H, int W,
                    int batch, hipStream_t s);
+// inc and conv_signal_0 as ONE launch with a flag per tile (k_dc_asm_pair): x0_out / x0 are the same tensor as inc's output and conv_signal's input
+bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch);
+void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, hipStream_t s);
 
 // ---- deep levels in one per-sample kernel (hn_deep.hip) ----
 void pack_frag_3x3_c2(const float* w_oihw, int cin, float* dst);  // 2 output channels -> [cin][3][64], rows 4..15 of M zero

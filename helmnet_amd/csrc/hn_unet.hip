@@ -438,8 +438,25 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     auto feat = [&](float* p, int d) { return Dst{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d)}; };
     auto featsrc = [&](const float* p, int d) { return Src{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d), 1.f}; };
 
+    // inc and conv_signal_0 as ONE launch with a flag per tile (hn_dca.hip, k_dc_asm_pair) where both run on the hand-scheduled kernel: hn_step's
+    // single-lane path, not under stream capture (the launch's epoch travels in the kernel arguments)
+    bool pair = false;
+    if (mfma && ws_off == 0 && ctx->opt_lanes == 1 && side_lane != nullptr) {
+        const Src st0{states_in + ctx->state_off[0], 2 * L, L, 1.f};
+        if (dc_asm_pair_applies(ctx, in_wf, in_res, in_sig, featsrc(ctx->buf_a[0], 0), st0, n, n, batch)) {
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            pair = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+            (void)hipGetLastError();
+        }
+    }
+    if (pair) {
+        int rc = side_join(ctx, side_lane, s);   // (deferred join: conv_signal_0 reads the new states)
+        if (rc != HN_OK) return rc;
+        const Src st0{states_in + ctx->state_off[0], 2 * L, L, 1.f};
+        ProfScope ps(ctx, KID_INC_SIG0, s);
+        launch_dc_asm_pair(ctx, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), featsrc(ctx->buf_a[0], 0), st0, feat(ctx->buf_o[0], 0), n, n, batch, s);
+    } else {
     // inc: DoubleConv(6 -> 8 -> 8) on [wf, 1e3*res, sigmas]  (architectures.py:442, hybridnet.py:566)
-    {
     ProfScope ps(ctx, KID_INC, s);
     if (mfma) launch_dc8(ctx, 0, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, ctx->f_inc[0], ctx->f_inc[1], false, nullptr, nullptr, n, n, batch, s);
     else launch_dc<2, 2, 2, kFeat, kFeat, 0>(in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), ctx->inc, noepi, n, n, batch, s);
@@ -483,7 +500,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         const Src st_old{states_in + ctx->state_off[d], 2 * L, L, 1.f};
         const Dst st_new{states_out + ctx->state_off[d], 2 * L, L};
         // out = conv_signal(cat[x, state])                               (architectures.py:246-247)
-        {
+        if (!(pair && d == 0)) {
             ProfScope ps(ctx, KID_SIG0 + 3 * d, s);
             if (mfma) launch_dc8(ctx, 1, featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d), ctx->sig[d], ctx->f_sig[d][0],
                                  ctx->f_sig[d][1], false, nullptr, nullptr, m, m, batch, s);

@@ -454,7 +454,7 @@ class Engine:
         return out
 
     # ---- measurement hooks ---------------------------------------------------------------
-    KERNEL_IDS = 36
+    KERNEL_IDS = 37
 
     @staticmethod
     def kernel_name(kid: int) -> str:
@@ -466,7 +466,7 @@ class Engine:
             return "bottleneck"
         if 20 <= kid <= 31:
             return ("up", "decode")[(kid - 20) % 2] + str((kid - 20) // 2)
-        return {32: "spectral_cols", 33: "spectral_rows", 34: "deep", 35: "spectral_pair"}[kid]
+        return {32: "spectral_cols", 33: "spectral_rows", 34: "deep", 35: "spectral_pair", 36: "inc_conv_signal0"}[kid]
 
     def profile_enable(self, kernel_ids=None):
         """Bracket the selected kernels (None = all, [] = none) with HIP events on the launch stream."""

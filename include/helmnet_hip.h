@@ -88,6 +88,9 @@ enum hn_option {
                               * compiler-scheduled kernel (hn_dcv.hip); 3 inc and the decoder, 4 (default) all three on the hand-scheduled kernel
                               * (hn_dca.hip: all 8 mid channels per wavefront, LDS-direct staging; [measured, r5] +1 .. 3 % it/s over 1).  Smooth
                               * activations and unaligned tensors always take hn_dcv.hip                                          */
+    HN_OPT_DC_PAIR = 12,     /* 0/1 (default 1): where inc and conv_signal_0 both run on hn_dca.hip they are ONE launch -- conv_signal's blocks wait, tile by
+                              * tile, on a flag the inc blocks of the tiles they read publish (write-through stores, agent-scope flag).  hn_step's
+                              * single-lane eager path only (not under capture, not with HN_OPT_LANES > 1).  Bit-identical to the two launches      */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
@@ -310,10 +313,11 @@ int64_t hn_train_peek(hn_ctx* ctx, int kind, int level, float* out, int64_t max_
  *   20+2d up(d) | 21+2d decoder(d) (d=0 includes outc + wavefield update) |
  *   32 spectral column pass | 33 spectral row pass (or the dense operator) |
  *   34 the fused deepest level (conv_signal, conv_state, down, bottleneck, up, decoder of level depth-1 in one kernel;
- *      those six ids then do not occur) | 35 both spectral passes under ONE event pair.
+ *      those six ids then do not occur) | 35 both spectral passes under ONE event pair
+ *      | 36 inc and conv_signal_0 as one launch (HN_OPT_DC_PAIR; ids 0 and 1 then do not occur).
  * hn_profile_collect synchronises the recorded events, returns per-id total milliseconds and
  * launch counts for ids [0, n_ids) and resets the accumulators. */
-#define HN_KERNEL_IDS 36
+#define HN_KERNEL_IDS 37
 int hn_profile_enable(hn_ctx* ctx, uint64_t kernel_mask);
 /* Bracket only every `every_nth` launch of a selected kernel (default 1), starting every_nth / 2 launches in.  An event pair
  * costs a few microseconds of stream gap, so timed runs sample instead of bracketing every launch. */

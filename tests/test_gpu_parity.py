@@ -557,3 +557,24 @@ def test_side_stream_pick_is_probed_once_per_caller_stream_and_stable_under_load
     s2, _ = fresh()
     s2.engine().step(*ref, 2); s2.engine().step(*ref, 2); torch.cuda.synchronize()
     assert torch.equal(args[0], ref[0]) and torch.equal(args[1], ref[1])
+
+
+@pytest.mark.parametrize("n,b", [(256, 8), (256, 3), (512, 2), (272, 1)])
+def test_inc_and_conv_signal_as_one_launch_is_bit_identical_to_two(n, b):
+    """HN_OPT_DC_PAIR (hn_dca.hip, k_dc_asm_pair): inc and conv_signal_0 as ONE launch in which conv_signal's blocks wait, tile by tile, for the inc
+    tiles they read (a flag word per tile carrying the launch's epoch; write-through stores, agent-scope flag, sc1 loads).  The same kernels' arithmetic in the same
+    order: every output bit equals the two-launch path over 25 free-running iterations (each iteration is a new epoch on the same flag words) -- with the
+    XCD-aware tile order (batch 8), without it (3 maps at 256^2: 192 tiles per map, T % 8 == 0 still; 272: odd tile counts, partial tile column)."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import ring_sos_batch
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=11)).to(DEV)
+    outs = {}
+    for pair in (1, 0):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=SRC.get(n, [n // 3, n // 2]))
+        s.engine().set_option("dc_pair", pair)
+        o = s.forward(sos, num_iterations=25, residuals="norms")
+        outs[pair] = (o["wavefields"][0].clone(), o["last_residual"].clone(), s.f.get_states(flatten=True).clone())
+        assert torch.isfinite(outs[pair][0]).all()
+    for a, c in zip(outs[1], outs[0]):
+        assert torch.equal(a, c)
