@@ -47,17 +47,25 @@ def kernel_macs(n: int, depth: int = 4) -> dict:
         m[f"up{d}"] = 16 * 8 * 8 * nd * nd
         m[f"decode{d}"] = dc(16, 8, 8, nd * nd) + (16 * nd * nd if d == 0 else 0)
     m["bottleneck"] = dc(8, 8, 8, (n >> depth) ** 2)
+    m["inc_conv_signal0"] = m["inc"] + m["conv_signal0"]   # the two as ONE launch (HN_OPT_DC_PAIR, hn_dca.hip: k_dc_asm_pair); never summed with its parts
     return m
 
 
 def kernel_macs_executed(n: int, name: str):
     """MACs the vector-pipe DoubleConv kernels of level 0 actually execute per SAMPLE per launch (hn_dca.hip / hn_dcv.hip: 16 x 64 output tiles,
     conv1 on the 18 x 66 mid tile incl. its halo, decode0's conv2 composed with the out-conv into a 2-channel 3x3), or None for other kernels."""
+    if name == "inc_conv_signal0":
+        return kernel_macs_executed(n, "inc") + kernel_macs_executed(n, "conv_signal0")
     cin = {"inc": 6, "conv_signal0": 10, "decode0": 16}.get(name)
     if cin is None:
         return None
     tiles = -(-n // 64) * -(-n // 16)
     return tiles * (18 * 66 * 8 * cin * 9 + 16 * 64 * (2 if name == "decode0" else 8) * 8 * 9)
+
+
+def unet_macs(n: int) -> int:
+    """MACs of one HybridNet evaluation per sample (every reference layer once)."""
+    return sum(v for k, v in kernel_macs(n).items() if k != "inc_conv_signal0")
 
 
 def kernel_bytes(n: int, depth: int = 4) -> dict:
@@ -71,6 +79,7 @@ def kernel_bytes(n: int, depth: int = 4) -> dict:
         b[f"up{d}"] = 4 * (px // 4) * 8 + 4 * px * 8
         b[f"decode{d}"] = 4 * px * (16 + (4 if d == 0 else 8))   # d = 0: read-modify-write of the wavefield, no 8-ch output
     b["bottleneck"] = 4 * ((n >> depth) ** 2) * 16
+    b["inc_conv_signal0"] = b["inc"] + b["conv_signal0"]
     return b
 
 
@@ -78,6 +87,7 @@ def kernel_bytes(n: int, depth: int = 4) -> dict:
 # HBM traffic up in profiles/*_traffic.json (FETCH_SIZE + WRITE_SIZE of the same command, tools/summarize_profiles.py)
 ROCPROF_NAME = {"decode0": ("k_dc_asm<8, 8, 0, 1>", "k_dc_valu<8, 8, 0, 1, false, false>", "k_dc_valu<8, 8, 0, 1, false>", "k_dc_mfma_s<8, 8, 0, 1, false>", "k_dc_mfma_s<8, 8, 0, 1>"),
                 "inc": ("k_dc_asm<2, 2, 2, 0>", "k_dc_valu<2, 2, 2, 0, false, false>", "k_dc_valu<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0>"),
+                "inc_conv_signal0": ("k_dc_asm_pair",),
                 "conv_signal0": ("k_dc_asm<8, 2, 0, 0>", "k_dc_valu<8, 2, 0, 0, false, false>", "k_dc_mfma_s<8, 2, 0, 0, false>"),
                 "spectral_rows": ("k_spec8_rows", "k_spec_rows<256>"), "spectral_cols": ("k_spec16_cols_t<16>", "k_spec16_cols_t<32>", "k_spec16_cols", "k_spec_cols<256, 16>")}
 
@@ -195,7 +205,7 @@ def secondary(solver, dev, n, B, precision, steps, warmup, loc=None, seed=5, rea
         dt = min(dts)
     finally:
         eng.set_option("lanes", 1)
-    flops = 2.0 * sum(kernel_macs(n).values()) * B
+    flops = 2.0 * unet_macs(n) * B
     return {"workload": label or f"{n}x{n} ring-phantom SoS maps, batch={B}, point source, UNet precision {precision}" + (f", {lanes} pipeline lanes" if lanes > 1 else ""),
             "dtype": DTYPE[precision], "value": round(steps / dt, 2), "unit": "iterations/s", "steps": steps, "warmup": warmup,
             "ms_per_step": round(dt / steps * 1e3, 4), "regions_it_per_s": [round(steps / d, 2) for d in dts], "sample_iterations_per_s": round(B * steps / dt, 1),
@@ -227,7 +237,7 @@ def secondary_train_step(solver, dev, n=96, B=32, unroll=10, steps=8, warmup=3):
         o = step(warmup + i)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    fwd_flop = 2.0 * sum(kernel_macs(n).values()) * B * unroll
+    fwd_flop = 2.0 * unet_macs(n) * B * unroll
     return {"workload": f"training step: {n}x{n}, batch={B}, {unroll} unrolled iterations, forward + backward + Adam (SURVEY 8 f4)",
             "dtype": "f32", "value": round(dt * 1e3, 3), "unit": "ms per training step", "higher_is_better": False, "steps": steps,
             "warmup": warmup, "sample_iterations_per_s": round(B * unroll / dt, 1),
@@ -285,7 +295,7 @@ def train_main(args, rank, world, dev, dist):
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         same = bool(flag.item() == 1.0)
     if rank == 0:
-        fwd_flop = 2.0 * sum(kernel_macs(n).values()) * B * unroll
+        fwd_flop = 2.0 * unet_macs(n) * B * unroll
         print(json.dumps({
             "metric": f"training sample-iterations/sec (whole node), {n}^2 domain, batch={B} per GPU x {unroll} unrolled iterations",
             "value": round(world * B * unroll * K / dt, 1), "unit": "sample-iterations/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -430,7 +440,7 @@ def main():
 
     if rank == 0:
         macs, byts_k = kernel_macs(n), kernel_bytes(n)
-        total_flops = 2.0 * sum(macs.values()) * B
+        total_flops = 2.0 * unet_macs(n) * B
         per_step = max(1, args.lanes if B >= 2 * args.lanes else 1)   # hn_step may split the batch over pipeline lanes
         dc_valu = int(dict(kv.split("=", 1) for kv in args.opt).get("dc_valu", "4")) if prec == "fp32" and n >= 256 else 0
         peak = PEAK_TFLOPS[prec]
@@ -451,7 +461,7 @@ def main():
                  "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
                  "samples_per_launch": B // per_step, "flops_per_launch": flops, "flops_credited_per_launch": flops, "product_terms_per_flop": TERMS[prec],
                  "hbm_view": {"bytes_per_launch": hbm, "achieved": round(ach_b, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach_b / HBM_PEAK_GBS, 4)}}
-            on_vector_pipe = (name in ("decode0", "inc") and dc_valu >= 1) or (name == "conv_signal0" and dc_valu in (2, 4, 6))
+            on_vector_pipe = (name in ("decode0", "inc") and dc_valu >= 1) or (name == "conv_signal0" and dc_valu in (2, 4)) or name == "inc_conv_signal0"
             if on_vector_pipe:
                 # hn_dca.hip / hn_dcv.hip: the level-0 DoubleConvs run on the packed fp32 VECTOR FMA, whose peak on gfx950 equals the fp32
                 # matrix peak (157.3 TFLOP/s, 64 FLOP / clk / SIMD); "bound" keeps the schema's compute label
@@ -521,7 +531,7 @@ def main():
         line["level0_kernels_note"] = ("shortest launch per kernel in the warm-up pass in which EVERY kernel is bracketed by an event pair; each figure carries ~5-8 us of "
                                        "event overhead (compare roofline.avg_launch_us, sampled in the timed region); rocprofv3 durations: profiles/r5_kernel_stats.csv")
         line["level0_kernels"] = [{"kernel": k, "bracketed_us": round(pmin[k] * 1e3, 2), "gflop_credited": round(2.0 * macs[k] * B / per_step / 1e9, 3)}
-                                  for k in ("inc", "conv_signal0", "down0", "up0", "decode0") if k in pmin and k in macs and pmin[k] > 0]
+                                  for k in ("inc", "conv_signal0", "inc_conv_signal0", "down0", "up0", "decode0") if k in pmin and k in macs and pmin[k] > 0]
         # secondary line for the HBM-bound part of the path (north_star: "achieved HBM GB/s for the FFT path"):
         # compulsory bytes of get_residual (5 planes per sample) over the shortest bracketed launches of the two
         # spectral kernels in the fully bracketed warm-up pass
