@@ -481,7 +481,11 @@ def main():
         roof = None
         if sampled:
             roof = kernel_roof(*sampled[0])
-            roof["selection"] = ("the longer (timed-region average) of the two longest main-chain kernels of the fully bracketed warm-up pass: " + ", ".join(cand))
+            roof["selection"] = ("the longer (timed-region average) of the two longest main-chain launches of the fully bracketed warm-up pass: " + ", ".join(cand))
+            if roof["kernel"] == "inc_conv_signal0":
+                roof["merged_launch_note"] = ("this launch is TWO reference layers -- inc and conv_signal_0 as one grid whose second half waits, tile by tile, on flags the first "
+                                              "half publishes (HN_OPT_DC_PAIR, DESIGN.md 4.1a); launched separately (--opt dc_pair=0) they take 52 + 66 us (0.51 / 0.53 of peak, "
+                                              "profiles/r5_kernel_stats.csv history in DESIGN.md 4); the longest SINGLE-layer kernel is the runner_up, decode0")
             if len(sampled) > 1:
                 other = kernel_roof(*sampled[1])
                 roof["runner_up"] = other                       # always reported; "tie" says whether it is within 5 % of the longest
