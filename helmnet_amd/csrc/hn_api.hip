@@ -189,7 +189,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_EXP_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}};
+                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}};
     if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 3 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -245,6 +245,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_DC_PAIR:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_PAIR must be 0 or 1 (got %d)", value);
             ctx->opt_dc_pair = value;
+            break;
+        case HN_OPT_SIDE_SYNC:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_SIDE_SYNC must be 0 or 1 (got %d)", value);
+            ctx->opt_side_sync = value;
             break;
         case HN_OPT_SPECTRAL_RADIX16:
             if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_SPECTRAL_RADIX16 must be 0, 1 or 2 (got %d)", value);
@@ -303,6 +307,8 @@ void hn_destroy(hn_ctx* ctx) {
         (void)hipEventDestroy(ctx->ev_stagger[j]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    (void)hipFree(ctx->sync_flags);
+    if (ctx->sync_err) (void)hipHostFree(ctx->sync_err);
     for (int j = 0; j < 8; ++j) {
         auto& sl = ctx->side[j];
         if (!sl.done) continue;
@@ -506,6 +512,13 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
     ctx->pair_flags_cap = (long)((n + 63) / 64) * ((n + 15) / 16) * max_batch;   // one flag word per level-0 tile (k_dc_asm_pair); epochs start at 1
     HN_HIP(ctx, hipMalloc((void**)&ctx->pair_flags, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
     HN_HIP(ctx, hipMemset(ctx->pair_flags, 0, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
+    if (ctx->sync_flags == nullptr) {   // flag sync (hn_internal.h): two device words and a host-visible error word, for the context's lifetime
+        HN_HIP(ctx, hipMalloc((void**)&ctx->sync_flags, sizeof(unsigned) * 64));
+        HN_HIP(ctx, hipMemset(ctx->sync_flags, 0, sizeof(unsigned) * 64));
+        HN_HIP(ctx, hipHostMalloc((void**)&ctx->sync_err, sizeof(int), hipHostMallocMapped));
+        *ctx->sync_err = 0;
+        HN_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->sync_err_dev, ctx->sync_err, 0));
+    }
     ctx->cap_batch = max_batch;
     return HN_OK;
 }
@@ -877,6 +890,9 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     DeviceGuard guard(ctx);
     if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
     if (n_iter == 0) return HN_OK;
+    if (ctx->sync_err != nullptr && *ctx->sync_err != 0)
+        return fail(ctx, HN_ERR_STATE, "hn_step: a device-side wait of an earlier call gave up after 10 s (side-stream flag never arrived): the hidden states of that "
+                                       "call are incomplete; destroy the context (HN_SIDE_SYNC=0 selects event packets instead of device flags)");
     hipStream_t s = (hipStream_t)stream;
     const long plane = (long)ctx->tab.n * ctx->tab.n;
     const long L = ctx->state_len;
@@ -904,6 +920,14 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
         const int per_graph = ctx->opt_graph > 1 ? ctx->opt_graph : 1;
         const bool hist = res_hist || wf_hist || st_hist;
         if (ctx->opt_graph && n_iter >= 4 * per_graph && !caller_capturing && !(per_graph > 1 && (hist || ctx->prof_mask))) g = step_graph(ctx, a);
+        // flag sync (hn_internal.h: sync_flags): between the iterations of this call the side stream is released and joined through device words instead
+        // of event packets.  Its gate kernel spins from the moment the side stream is free, so the side stream first waits for the caller's stream to get
+        // here (one event per CALL), and the last iteration joins with an event as before (the caller's stream must own the final states).
+        const bool flag_sync = g == nullptr && n_iter > 1 && !st_hist && side_flags_apply(ctx, s);
+        if (flag_sync) {
+            HN_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+            HN_HIP(ctx, hipStreamWaitEvent(ctx->side[0].stream, ctx->ev_fork, 0));
+        }
         for (int it = 0; it < n_iter; ++it) {
             if (g != nullptr && per_graph > 1 && (it & 1) == 0 && it + per_graph <= n_iter) {   // several iterations per replay
                 HN_HIP(ctx, hipGraphLaunch(g->exec[0], s));
@@ -924,7 +948,7 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
             } else {
                 // the new hidden states are first needed by the next iteration's conv_signal_0: the side-stream join moves there,
                 // unless something reads them right away (a state history) or this is the last iteration
-                const bool defer = ctx->opt_defer_join && ctx->opt_side_stream && !st_hist && it + 1 < n_iter && g == nullptr;
+                const bool defer = (ctx->opt_defer_join || flag_sync) && ctx->opt_side_stream && !st_hist && it + 1 < n_iter && g == nullptr;
                 if ((rc = one_iteration(ctx, a, it & 1, 0, batch, 0, s, nullptr, defer)) != HN_OK) return rc;
                 ++ctx->eager_iterations;
             }

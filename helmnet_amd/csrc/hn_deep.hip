@@ -251,8 +251,9 @@ __device__ __forceinline__ void zero_fill(float* p, int count, int tid) {  // co
 template <bool GEN>
 __global__ __launch_bounds__(512) void k_deep32(const float* __restrict__ x_in, long x_sb, const float* __restrict__ st_in,
                                                 float* __restrict__ st_out, long st_sb, long st_sc, float* __restrict__ y_out, long y_sb,
-                                                DeepW w) {
+                                                DeepW w, SyncHook hook) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    sync_hook_begin(hook);   // (flag sync: releases the hidden-state kernels of the larger levels on the side stream, hn_internal.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -483,7 +484,7 @@ bool deep_applies(const hn_ctx* ctx) {
 }
 
 int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, float* st_out, long st_sb, long st_sc, float* y_out,
-                long y_sb, int batch, hipStream_t s) {
+                long y_sb, int batch, hipStream_t s, SyncHook hook) {
     const int d = ctx->depth - 1;
     DeepW w;
     w.sig1 = ctx->f_sig[d][0]; w.sig1_b = ctx->sig[d].b1; w.sig_slope = ctx->sig[d].slope; w.sig2 = ctx->f_sig[d][1]; w.sig2_b = ctx->sig[d].b2;
@@ -499,9 +500,9 @@ int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, f
         ctx->deep_attr_set = true;
     }
     if (w.act > HN_ACT_LEAKYRELU)
-        hipLaunchKernelGGL(k_deep32<true>, dim3(batch), dim3(512), LDS_FLOATS * sizeof(float), s, x_in, x_sb, st_in, st_out, st_sb, st_sc, y_out, y_sb, w);
+        hipLaunchKernelGGL(k_deep32<true>, dim3(batch), dim3(512), LDS_FLOATS * sizeof(float), s, x_in, x_sb, st_in, st_out, st_sb, st_sc, y_out, y_sb, w, hook);
     else
-        hipLaunchKernelGGL(k_deep32<false>, dim3(batch), dim3(512), LDS_FLOATS * sizeof(float), s, x_in, x_sb, st_in, st_out, st_sb, st_sc, y_out, y_sb, w);
+        hipLaunchKernelGGL(k_deep32<false>, dim3(batch), dim3(512), LDS_FLOATS * sizeof(float), s, x_in, x_sb, st_in, st_out, st_sb, st_sc, y_out, y_sb, w, hook);
     return HN_OK;
 }
 

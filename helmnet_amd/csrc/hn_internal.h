@@ -29,6 +29,28 @@ struct Dst {
     long sb;
     long sc;
 };
+// flag sync (hn_ctx::sync_flags): what a main-chain kernel does for the side stream on the way -- thread 0 of block 0 stores `store_epoch` to *store (signal
+// memory the side stream's command processor waits on) when the kernel starts, i.e. when everything launched before it on its stream is complete, and / or,
+// after its own work, waits until *wait has reached wait_epoch
+struct SyncHook {
+    unsigned* store = nullptr; unsigned store_epoch = 0;
+    const unsigned* wait = nullptr; unsigned wait_epoch = 0;
+    int* err = nullptr;   // host-mapped: a wait that gave up
+};
+__device__ __forceinline__ void sync_hook_begin(const SyncHook& h) {
+    if (h.store != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)
+        __hip_atomic_store(h.store, h.store_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void sync_wait_ge(const unsigned* flag, unsigned epoch, int* err) {   // wrap-around safe; bounded by 10 s of the 100 MHz counter
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+        __builtin_amdgcn_s_sleep(16);
+    }
+}
+__device__ __forceinline__ void sync_hook_end(const SyncHook& h) {
+    if (h.wait != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0) sync_wait_ge(h.wait, h.wait_epoch, h.err);
+}
 
 // Weights of one DoubleConv, re-packed for scalar (SGPR) broadcast loads:
 //   w1 [cin][3][3][cmid], b1 [cmid], slope (1 float), w2 [cmid][3][3][cout], b2 [cout]
@@ -158,6 +180,22 @@ struct hn_ctx {
     unsigned* pair_flags = nullptr;   // one word per level-0 tile of the reserved batch: the epoch of the launch whose inc block wrote that tile
     long pair_flags_cap = 0;
     unsigned pair_epoch = 0;
+    // Side stream <-> main stream without event packets ("flag sync", hn_unet.hip).  An event record holds the recording stream for ~7 us, a stream-wait for ~6,
+    // and so does ANY extra kernel, however small [measured, r5: profiles/r5_side_sync.txt].  So between the iterations of one hn_step call the hand-overs
+    // ride on kernels the main chain launches anyway (SyncHook):
+    //   join     a one-thread kernel behind the hidden-state kernels stores the epoch to word 32; ONE thread of up_0 polls it after its own work (one
+    //            spinning thread cannot keep the side stream's kernels off the CUs; a grid of polling conv_signal blocks could);
+    //   release  (where the deep kernel exists) its first thread stores the epoch to word 0 -- everything before it on the main stream is complete --
+    //            and a one-wave gate kernel in front of the hidden-state kernels polls it.  The gate is resident from the end of one iteration's
+    //            hidden-state kernels to the next release and costs the level-0 kernels a block slot (decode_0 70 -> 74 us: half of what the missing
+    //            event packet saves); hipStreamWaitValue64 is itself a spinning kernel here and slower.
+    // Every store is enqueued before the kernel that waits for it (a tool that runs one kernel at a time in submission order cannot deadlock), every wait is
+    // bounded (10 s, then hn_step fails).
+    int opt_side_sync = 1;     // HN_OPT_SIDE_SYNC: 1 device words between the iterations of one hn_step call, 0 events everywhere
+    unsigned* sync_flags = nullptr;   // device, 64 words
+    unsigned sync_epoch = 0;   // (compared wrap-around safe)
+    int* sync_err = nullptr;          // host-mapped: a bounded device-side wait that gave up stores its code here (sticky; checked by hn_step)
+    int* sync_err_dev = nullptr;
     const float* zero_page = nullptr;   // 256 zero bytes (out-of-image float4s of the LDS-direct staging loads, hn_dca.hip)
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
@@ -390,7 +428,8 @@ int launch_dc8_bwd(hn_ctx* ctx, const McBwd& a, int cin, int H, int W, int batch
 int launch_dc8_tape(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const float* frag1, const float* b1, const float* slope, const float* frag2,
                     const float* b2, int act, float* z, int H, int W, int batch, hipStream_t s);
 void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
-void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate = false);
+void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate = false,
+               SyncHook hook = SyncHook{});   // hook: fp32 matrix-core kernels only (k_up_mfma)
 
 // ---- vector-pipe DoubleConv of the big levels (hn_dcv.hip) ----
 void pack_valu_q(const float* w_oihw, int cin, float* dst);            // conv1 [8][cin][3][3] -> [cin][2][9][4]
@@ -412,7 +451,7 @@ void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x
 void pack_frag_3x3_c2(const float* w_oihw, int cin, float* dst);  // 2 output channels -> [cin][3][64], rows 4..15 of M zero
 bool deep_applies(const hn_ctx* ctx);
 int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, float* st_out, long st_sb, long st_sc, float* y_out,
-                long y_sb, int batch, hipStream_t s);
+                long y_sb, int batch, hipStream_t s, SyncHook hook = SyncHook{});
 
 // ---- unet (hn_unet.hip) ----
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the
@@ -422,6 +461,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                  hn_ctx::SideLane* side_lane = nullptr, bool defer_join = false);
 // make stream s wait for the hidden-state kernels of the previous unet_forward(..., defer_join = true) on this lane
 int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
+bool side_flags_apply(hn_ctx* ctx, hipStream_t s);   // would unet_forward(defer_join = true) on hn_step's single lane use the device flags?
 int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, bool may_sync, hipStream_t* out);   // a stream that overlaps with every stream in refs
 
 // standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv): fp32 vector kernels of hn_unet.hip on packed device weights

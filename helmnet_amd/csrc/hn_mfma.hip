@@ -2014,9 +2014,10 @@ struct UpCfg2 {
 // Staging follows k_down_mfma: zero the out-of-image positions once, no predicates in the (unrolled) loop.
 template <int WX, int R_, bool ALL, bool ACC = false>   // ACC: out += (the training step's backward pass adds `down`'s input gradient to the skip gradient)
 __global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][2][4][64]*/,
-                                                  const float* __restrict__ bias, int Hin, int Win) {
+                                                  const float* __restrict__ bias, int Hin, int Win, SyncHook hook) {
     using C = UpCfg2<WX, R_>;
     __shared__ float lds[(ALL ? kFeat : 4) * C::PLANE_P];  // ALL: every channel at once; else 2 buffers x 2 channels
+    sync_hook_begin(hook);   // (flag sync: the side stream's hand-overs ride on this kernel, hn_internal.h)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 15, q = lane >> 4;
@@ -2149,6 +2150,7 @@ __global__ __launch_bounds__(256, 3) void k_up_mfma(Src in, Dst out, const float
             }
         }
     }
+    sync_hook_end(hook);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2680,7 +2682,7 @@ void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const fl
     }
 }
 
-void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate) {
+void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate, SyncHook hook) {
     // window rows -1 .. Hin-1
     if (const int mode = ctx->precision; mode >= HN_PREC_BF16X3 && mode <= HN_PREC_BF16X2 && Win >= 64) {
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
@@ -2697,12 +2699,12 @@ void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const floa
     // round of 3 resident blocks per CU at 256^2 x 32 (16-row blocks: 1152 = 1.5 rounds)
     if (Win > up_small) {
         const dim3 g(cdiv_(Win, 32), cdiv_(Hin + 1, 22), batch);
-        if (accumulate) hipLaunchKernelGGL((k_up_mfma<2, 11, false, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
-        else hipLaunchKernelGGL((k_up_mfma<2, 11, false>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+        if (accumulate) hipLaunchKernelGGL((k_up_mfma<2, 11, false, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win, hook);
+        else hipLaunchKernelGGL((k_up_mfma<2, 11, false>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win, hook);
     } else {
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
-        if (accumulate) hipLaunchKernelGGL((k_up_mfma<1, 5, true, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
-        else hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+        if (accumulate) hipLaunchKernelGGL((k_up_mfma<1, 5, true, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win, hook);
+        else hipLaunchKernelGGL((k_up_mfma<1, 5, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win, hook);
     }
 }
 

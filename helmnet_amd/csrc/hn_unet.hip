@@ -422,6 +422,17 @@ __global__ __launch_bounds__(UpCfg::NT) void k_up8x8(Src in, Dst out, K8W w, int
         }
 }
 
+
+// ---- flag sync (hn_internal.h: sync_flags): the side stream's two small kernels (the main chain's halves ride on k_deep32 / k_up_mfma: SyncHook) ----
+__global__ void k_sync_signal(unsigned* flag, unsigned epoch) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Holds its stream until *flag has reached epoch.  The store it waits for is always enqueued BEFORE this kernel (a tool that runs one kernel at a time in
+// submission order cannot deadlock it), and the wait is bounded: after 10 s it gives up loudly (sticky error word read by hn_step).
+__global__ void k_sync_gate(const unsigned* flag, unsigned epoch, int* err) {
+    if (threadIdx.x == 0) sync_wait_ge(flag, epoch, err);
+}
+
 }  // namespace
 
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
@@ -440,14 +451,13 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
 
     // inc and conv_signal_0 as ONE launch with a flag per tile (hn_dca.hip, k_dc_asm_pair) where both run on the hand-scheduled kernel: hn_step's
     // single-lane path, not under stream capture (the launch's epoch travels in the kernel arguments)
-    bool pair = false;
-    if (mfma && ws_off == 0 && ctx->opt_lanes == 1 && side_lane != nullptr) {
+    bool pair = false, eager = false;
+    if (ws_off == 0 && ctx->opt_lanes == 1 && side_lane != nullptr) {   // hn_step's single lane, launched kernel by kernel
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        eager = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+        (void)hipGetLastError();
         const Src st0{states_in + ctx->state_off[0], 2 * L, L, 1.f};
-        if (dc_asm_pair_applies(ctx, in_wf, in_res, in_sig, featsrc(ctx->buf_a[0], 0), st0, n, n, batch)) {
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            pair = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-            (void)hipGetLastError();
-        }
+        pair = eager && mfma && dc_asm_pair_applies(ctx, in_wf, in_res, in_sig, featsrc(ctx->buf_a[0], 0), st0, n, n, batch);
     }
     if (pair) {
         int rc = side_join(ctx, side_lane, s);   // (deferred join: conv_signal_0 reads the new states)
@@ -479,9 +489,19 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     //      sequence is not being captured into a graph (an event record is a ~6 us bubble on the stream).
     //   3  all levels behind the deep kernel (beside the decoder's small levels)
     const int policy = side != nullptr ? ctx->opt_side_stream : 0;
+    // flag sync (hn_internal.h: sync_flags): in an iteration whose join may be deferred (all but the last of an hn_step call) the join is one thread of
+    // up_0 polling a word, and, where the deep kernel exists to carry the store, the release is a word too: no event packet touches the main stream
+    const bool flags = eager && defer_join && policy == 1 && ctx->opt_side_sync == 1 && ctx->sync_flags != nullptr && ctx->precision == HN_PREC_FP32 &&
+                       n_enc >= 1;
+    const bool rel_flag = flags && deep;   // otherwise the release stays an event record (no other kernel sits where the store belongs)
+    const unsigned sync_epoch = flags ? ++ctx->sync_epoch : 0u;
     auto release_states = [&](int d0, int d1, hipEvent_t ev) -> int {
-        HN_HIP(ctx, hipEventRecord(ev, s));
-        HN_HIP(ctx, hipStreamWaitEvent(side, ev, 0));
+        if (rel_flag) {   // (the kernel that stores the release word has been enqueued)
+            hipLaunchKernelGGL(k_sync_gate, dim3(1), dim3(64), 0, side, ctx->sync_flags, sync_epoch, ctx->sync_err_dev);
+        } else {
+            HN_HIP(ctx, hipEventRecord(ev, s));
+            HN_HIP(ctx, hipStreamWaitEvent(side, ev, 0));
+        }
         for (int e = d0; e < d1; ++e) {
 #ifdef HN_EXP_SKIP_STATE   // timing experiment only (tools/r4_skip_state.sh): environment bit e skips conv_state_e -- the results are WRONG
             static const int exp_skip = getenv("HN_EXP_SKIP_STATE") ? std::atoi(getenv("HN_EXP_SKIP_STATE")) : 0;
@@ -493,8 +513,12 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
             launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
         }
+        if (flags) hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, side, ctx->sync_flags + 32, sync_epoch);   // (... before up_0, which waits for it)
         return HN_OK;
     };
+    SyncHook rel_hook, join_hook;
+    if (rel_flag) { rel_hook.store = ctx->sync_flags; rel_hook.store_epoch = sync_epoch; }
+    if (flags) { join_hook.wait = ctx->sync_flags + 32; join_hook.wait_epoch = sync_epoch; join_hook.err = ctx->sync_err_dev; }
     for (int d = 0; d < n_enc; ++d) {
         const int m = n >> d;
         const Src st_old{states_in + ctx->state_off[d], 2 * L, L, 1.f};
@@ -525,17 +549,23 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                     ctx->down[d], m, m);
         }
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
-        if (policy == 1 && d == n_enc - 1) {
+        if (policy == 1 && d == n_enc - 1 && !rel_flag) {
             int rc = release_states(0, n_enc, side_lane->ev[0]);
             if (rc != HN_OK) return rc;
         }
     }
     if (deep) {
         const int d = depth - 1;
-        ProfScope ps(ctx, KID_DEEP, s);
-        int rc = launch_deep(ctx, ctx->buf_a[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), states_in + ctx->state_off[d],
-                             states_out + ctx->state_off[d], 2 * L, L, ctx->buf_y[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), batch, s);
-        if (rc != HN_OK) return rc;
+        {
+            ProfScope ps(ctx, KID_DEEP, s);
+            int rc = launch_deep(ctx, ctx->buf_a[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), states_in + ctx->state_off[d],
+                                 states_out + ctx->state_off[d], 2 * L, L, ctx->buf_y[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), batch, s, rel_hook);
+            if (rc != HN_OK) return rc;
+        }
+        if (rel_flag) {
+            int rc = release_states(0, n_enc, nullptr);
+            if (rc != HN_OK) return rc;
+        }
     }
     if (policy == 3) {
         int rc = release_states(0, n_enc, side_lane->ev[0]);
@@ -554,7 +584,8 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // x = up[d](x)                                                   (architectures.py:456)
         {
             ProfScope ps(ctx, KID_UP0 + 2 * d, s);
-            if (mfma) launch_up(ctx, featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->f_up[d], ctx->up[d].b, m / 2, m / 2, batch, s);
+            if (mfma) launch_up(ctx, featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->f_up[d], ctx->up[d].b, m / 2, m / 2, batch, s, false,
+                                d == 0 ? join_hook : SyncHook{});
             else hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
                                     featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->up[d], m / 2, m / 2);
         }
@@ -574,11 +605,13 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         }
     }
     if (policy != 0) {  // the next iteration's conv_signal reads the new states
-        HN_HIP(ctx, hipEventRecord(side_lane->done, side));
-        side_lane->pending = true;
-        if (!defer_join) {
-            int rc = side_join(ctx, side_lane, s);
-            if (rc != HN_OK) return rc;
+        if (!flags) {   // (flag sync: up_0 has waited for the join word)
+            HN_HIP(ctx, hipEventRecord(side_lane->done, side));
+            side_lane->pending = true;
+            if (!defer_join) {
+                int rc = side_join(ctx, side_lane, s);
+                if (rc != HN_OK) return rc;
+            }
         }
     }
     HN_HIP(ctx, hipGetLastError());
@@ -591,6 +624,15 @@ int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s) {
         side_lane->pending = false;
     }
     return HN_OK;
+}
+
+bool side_flags_apply(hn_ctx* ctx, hipStream_t s) {
+    if (ctx->opt_lanes != 1 || ctx->opt_side_stream != 1 || ctx->opt_side_sync == 0 || ctx->sync_flags == nullptr) return false;
+    if (ctx->precision != HN_PREC_FP32) return false;   // (the hooks live in k_deep32 / k_up_mfma)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool eager = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+    return eager;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -91,6 +91,11 @@ enum hn_option {
     HN_OPT_DC_PAIR = 12,     /* 0/1 (default 1): where inc and conv_signal_0 both run on hn_dca.hip they are ONE launch -- conv_signal's blocks wait, tile by
                               * tile, on a flag the inc blocks of the tiles they read publish (write-through stores, agent-scope flag).  hn_step's
                               * single-lane eager path only (not under capture, not with HN_OPT_LANES > 1).  Bit-identical to the two launches      */
+    HN_OPT_SIDE_SYNC = 13,   /* 0/1 (default 1): between the iterations of ONE hn_step call the side stream is joined -- and, at 256^2, released -- through
+                              * device words that kernels of the main chain store / poll on their way (one thread each) instead of event packets,
+                              * each of which holds the main stream for ~7 us; the first release and the last join of a call stay events.
+                              * hn_step's single-lane eager path, fp32, HN_OPT_SIDE_STREAM 1; waits are bounded (10 s, then hn_step fails).
+                              * Same kernels, same results; [measured, r5] +1 % it/s at 256^2 x 32, +8 % at batch 8                        */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of

@@ -578,3 +578,27 @@ def test_inc_and_conv_signal_as_one_launch_is_bit_identical_to_two(n, b):
         assert torch.isfinite(outs[pair][0]).all()
     for a, c in zip(outs[1], outs[0]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.parametrize("n,b", [(256, 8), (128, 4), (96, 5), (512, 2)])
+def test_side_stream_synchronised_by_device_flags_is_bit_identical_to_events(n, b):
+    """HN_OPT_SIDE_SYNC (hn_unet.hip): between the iterations of one hn_step call the hidden-state kernels on the side stream are released by a word the
+    main chain stores and joined through a word the next iteration's gate kernel polls, instead of event packets.  Ordering only: the same kernels on the same
+    data, so 40 free-running iterations (the ping-pong of the hidden-state buffers makes a late or early conv_state visible as different bits), a second call on
+    the same solver (epochs continue), per-call history (which keeps the event path) and an odd iteration count all equal the event-synchronised run
+    bit for bit -- at a size with the merged level-0 launch (256), without it (128), with the reference's 96 and at 512."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import ring_sos_batch
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=13)).to(DEV)
+    outs = {}
+    for sync in (1, 0):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=SRC.get(n, [n // 3, n // 2]))
+        s.engine().set_option("side_sync", sync)
+        o = s.forward(sos, num_iterations=40, residuals="norms")
+        first = (o["wavefields"][0].clone(), o["last_residual"].clone(), s.f.get_states(flatten=True).clone())
+        o = s.forward(sos, num_iterations=7, residuals="norms")
+        outs[sync] = first + (o["wavefields"][0].clone(), o["last_residual"].clone(), s.f.get_states(flatten=True).clone())
+        assert all(torch.isfinite(t).all() for t in outs[sync])
+    for a, c in zip(outs[1], outs[0]):
+        assert torch.equal(a, c)
