@@ -809,8 +809,10 @@ int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, in
                           stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr, defer_join);
     if (rc != HN_OK) return rc;
     const float* src_j = a.src_batch == 1 ? a.src : a.src + (size_t)b0 * 2 * plane;
-    return spec_apply(ctx, wf_j, res_j, a.k_sq + (size_t)b0 * plane, src_j, a.src_batch == 1 ? 1 : nb, nb,
-                      a.rmse_hist ? a.rmse_hist + b0 : nullptr, sj, a.rmse_hist ? ctx->it_counter + lane : nullptr, a.batch);
+    HN_REP(KID_SPEC_PAIR)
+    rc = spec_apply(ctx, wf_j, res_j, a.k_sq + (size_t)b0 * plane, src_j, a.src_batch == 1 ? 1 : nb, nb,
+                    a.rmse_hist ? a.rmse_hist + b0 : nullptr, sj, a.rmse_hist ? ctx->it_counter + lane : nullptr, a.batch);
+    return rc;
 }
 
 void destroy_graph_entry(hn_ctx::StepGraph& g) {
@@ -998,3 +1000,11 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
 }
 
 }  // extern "C"
+
+#ifdef HN_EXP_REPEAT   // tools/energy_probe.py (hn_internal.h: HN_REP)
+namespace hn {
+int g_exp_repeat[64] = {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+                        1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1};
+}
+extern "C" void hn_debug_set_repeat(int kid, int count) { if (kid >= 0 && kid < 64) hn::g_exp_repeat[kid] = count; }
+#endif

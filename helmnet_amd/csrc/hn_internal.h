@@ -356,6 +356,14 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
+// Energy / time experiment only (tools/energy_probe.py; -DHN_EXP_REPEAT builds): launch the kernel(s) of one id `count` times instead of once -- the
+// difference to the plain loop in time and in board energy is what one launch costs.  count 0 skips the kernel.  The results of such a run are not the solver's.
+#ifdef HN_EXP_REPEAT
+extern int g_exp_repeat[64];
+#define HN_REP(kid) for (int r_ = g_exp_repeat[kid]; r_ > 0; --r_)
+#else
+#define HN_REP(kid)
+#endif
 struct ProfScope {
     hn_ctx* c;
     hipStream_t s;

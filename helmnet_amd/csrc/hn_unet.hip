@@ -464,7 +464,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         if (rc != HN_OK) return rc;
         const Src st0{states_in + ctx->state_off[0], 2 * L, L, 1.f};
         ProfScope ps(ctx, KID_INC_SIG0, s);
-        launch_dc_asm_pair(ctx, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), featsrc(ctx->buf_a[0], 0), st0, feat(ctx->buf_o[0], 0), n, n, batch, s);
+        HN_REP(KID_INC_SIG0) launch_dc_asm_pair(ctx, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), featsrc(ctx->buf_a[0], 0), st0, feat(ctx->buf_o[0], 0), n, n, batch, s);
     } else {
     // inc: DoubleConv(6 -> 8 -> 8) on [wf, 1e3*res, sigmas]  (architectures.py:442, hybridnet.py:566)
     ProfScope ps(ctx, KID_INC, s);
@@ -511,7 +511,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
             const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
             ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
-            launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
+            HN_REP(KID_STATE0 + 3 * e) launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
         }
         if (flags) hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, side, ctx->sync_flags + 32, sync_epoch);   // (... before up_0, which waits for it)
         return HN_OK;
@@ -526,6 +526,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // out = conv_signal(cat[x, state])                               (architectures.py:246-247)
         if (!(pair && d == 0)) {
             ProfScope ps(ctx, KID_SIG0 + 3 * d, s);
+            HN_REP(KID_SIG0 + 3 * d)
             if (mfma) launch_dc8(ctx, 1, featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d), ctx->sig[d], ctx->f_sig[d][0],
                                  ctx->f_sig[d][1], false, nullptr, nullptr, m, m, batch, s);
             else launch_dc<kFeat, kState, 0, kFeat, kFeat, 0>(featsrc(ctx->buf_a[d], d), st_old, none, feat(ctx->buf_o[d], d),
@@ -543,6 +544,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // x = down(out)                                                  (architectures.py:252)
         {
             ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
+            HN_REP(KID_DOWN0 + 3 * d)
             if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
             else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
                                     dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
@@ -558,7 +560,8 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         const int d = depth - 1;
         {
             ProfScope ps(ctx, KID_DEEP, s);
-            int rc = launch_deep(ctx, ctx->buf_a[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), states_in + ctx->state_off[d],
+            int rc = HN_OK;
+            HN_REP(KID_DEEP) rc = launch_deep(ctx, ctx->buf_a[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), states_in + ctx->state_off[d],
                                  states_out + ctx->state_off[d], 2 * L, L, ctx->buf_y[d] + (long)ws_off * kFeat * plane(d), kFeat * plane(d), batch, s, rel_hook);
             if (rc != HN_OK) return rc;
         }
@@ -584,6 +587,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // x = up[d](x)                                                   (architectures.py:456)
         {
             ProfScope ps(ctx, KID_UP0 + 2 * d, s);
+            HN_REP(KID_UP0 + 2 * d)
             if (mfma) launch_up(ctx, featsrc(ctx->buf_y[d + 1], d + 1), feat(ctx->buf_a[d], d), ctx->f_up[d], ctx->up[d].b, m / 2, m / 2, batch, s, false,
                                 d == 0 ? join_hook : SyncHook{});
             else hipLaunchKernelGGL(k_up8x8, dim3(cdiv(m / 2, UpCfg::TW), cdiv(m / 2, UpCfg::TH), batch), dim3(UpCfg::NT), 0, s,
@@ -591,6 +595,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         }
         ProfScope ps(ctx, KID_DEC0 + 2 * d, s);
         // x = decode[d](cat[x, skip_d])                                  (architectures.py:458-460)
+        HN_REP(KID_DEC0 + 2 * d)
         if (mfma) {
             launch_dc8(ctx, 3, featsrc(ctx->buf_a[d], d), featsrc(ctx->buf_o[d], d), none, d > 0 ? feat(ctx->buf_y[d], d) : Dst{nullptr, 0, 0},
                        ctx->dec[d], ctx->f_dec[d][0], ctx->f_dec[d][1], d == 0, d_out, wf_update, m, m, batch, s);
