@@ -626,7 +626,7 @@ def main():
                                  secondary(solver, dev, 512, 16, "fp32", 40, 10),
                                  secondary(solver, dev, 256, 32, "bf16x3", 60, 10),
                                  secondary(solver, dev, 512, 16, "fp16", 40, 10),
-                                 secondary(solver, dev, 256, 64, "fp32", 60, 10, lanes=2),   # throughput beyond the headline batch: the halves of a 64-map batch as two chains
+                                 secondary(solver, dev, 256, 64, "fp32", 60, 10),   # throughput beyond the headline batch (one chain: since r5 faster than two lanes at 64, tools/ab_inproc.py lanes 1,2 --batch 64)
                                  secondary_train_step(solver, dev)]
             hw0 = line["secondary"][0].get("hwmon")
             if hw0 and hw0.get("sclk_mhz_median"):

@@ -190,6 +190,12 @@ int hn_create(hn_ctx** out, int device_id) {
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_EXP_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
                                                             {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}};
+    // Counter collection (rocprofv3 --pmc, rocprof -i / ROCP_METRICS) runs ONE kernel at a time across all queues, in an order of the tool's choosing: a kernel that
+    // waits for a word another queue's kernel stores may then be the one that runs -- the bounded wait gives up after 2 s and hn_step fails [seen, r5].  Under such
+    // a tool the hand-overs stay event packets unless HN_SIDE_SYNC says otherwise (the merged level-0 launch is ONE kernel and is not affected).
+    for (const char* name : {"ROCPROF_COUNTER_COLLECTION", "ROCPROF_COUNTERS", "ROCP_METRICS"})
+        if (const char* v = getenv(name))
+            if (v[0] != '\0' && std::strcmp(v, "0") != 0 && std::strcmp(v, "False") != 0 && std::strcmp(v, "false") != 0) c->opt_side_sync = 0;
     if (const char* v = getenv("HN_SIDE_PRIORITY")) { const int p = std::atoi(v); c->opt_side_priority = p < 0 || p > 3 ? 0 : p; }
     if (const char* v = getenv("HN_DEFER_JOIN")) c->opt_defer_join = std::atoi(v) != 0;
     for (const auto& k : knobs)
@@ -893,7 +899,7 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
     if (n_iter == 0) return HN_OK;
     if (ctx->sync_err != nullptr && *ctx->sync_err != 0)
-        return fail(ctx, HN_ERR_STATE, "hn_step: a device-side wait of an earlier call gave up after 10 s (side-stream flag never arrived): the hidden states of that "
+        return fail(ctx, HN_ERR_STATE, "hn_step: a device-side wait of an earlier call gave up after 2 s (side-stream flag never arrived): the hidden states of that "
                                        "call are incomplete; destroy the context (HN_SIDE_SYNC=0 selects event packets instead of device flags)");
     hipStream_t s = (hipStream_t)stream;
     const long plane = (long)ctx->tab.n * ctx->tab.n;

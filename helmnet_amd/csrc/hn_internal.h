@@ -41,10 +41,10 @@ __device__ __forceinline__ void sync_hook_begin(const SyncHook& h) {
     if (h.store != nullptr && (blockIdx.x | blockIdx.y | blockIdx.z | threadIdx.x) == 0)
         __hip_atomic_store(h.store, h.store_epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ void sync_wait_ge(const unsigned* flag, unsigned epoch, int* err) {   // wrap-around safe; bounded by 10 s of the 100 MHz counter
+__device__ __forceinline__ void sync_wait_ge(const unsigned* flag, unsigned epoch, int* err) {   // wrap-around safe; bounded by 2 s of the 100 MHz counter
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
     while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - epoch) < 0) {
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 1000000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
         __builtin_amdgcn_s_sleep(16);
     }
 }
@@ -190,7 +190,7 @@ struct hn_ctx {
     //            hidden-state kernels to the next release and costs the level-0 kernels a block slot (decode_0 70 -> 74 us: half of what the missing
     //            event packet saves); hipStreamWaitValue64 is itself a spinning kernel here and slower.
     // Every store is enqueued before the kernel that waits for it (a tool that runs one kernel at a time in submission order cannot deadlock), every wait is
-    // bounded (10 s, then hn_step fails).
+    // bounded (2 s, then hn_step fails).
     int opt_side_sync = 1;     // HN_OPT_SIDE_SYNC: 1 device words between the iterations of one hn_step call, 0 events everywhere
     unsigned* sync_flags = nullptr;   // device, 64 words
     unsigned sync_epoch = 0;   // (compared wrap-around safe)

@@ -428,7 +428,7 @@ __global__ void k_sync_signal(unsigned* flag, unsigned epoch) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Holds its stream until *flag has reached epoch.  The store it waits for is always enqueued BEFORE this kernel (a tool that runs one kernel at a time in
-// submission order cannot deadlock it), and the wait is bounded: after 10 s it gives up loudly (sticky error word read by hn_step).
+// submission order cannot deadlock it), and the wait is bounded: after 2 s it gives up loudly (sticky error word read by hn_step).
 __global__ void k_sync_gate(const unsigned* flag, unsigned epoch, int* err) {
     if (threadIdx.x == 0) sync_wait_ge(flag, epoch, err);
 }

@@ -93,9 +93,12 @@ enum hn_option {
                               * single-lane eager path only (not under capture, not with HN_OPT_LANES > 1).  Bit-identical to the two launches      */
     HN_OPT_SIDE_SYNC = 13,   /* 0/1 (default 1): between the iterations of ONE hn_step call the side stream is joined -- and, at 256^2, released -- through
                               * device words that kernels of the main chain store / poll on their way (one thread each) instead of event packets,
-                              * each of which holds the main stream for ~7 us; the first release and the last join of a call stay events.
-                              * hn_step's single-lane eager path, fp32, HN_OPT_SIDE_STREAM 1; waits are bounded (10 s, then hn_step fails).
-                              * Same kernels, same results; [measured, r5] +1 % it/s at 256^2 x 32, +8 % at batch 8                        */
+                              * each of which holds the main stream for ~7 us; a call forks the side stream with one event and its LAST iteration uses events.
+                              * hn_step's single-lane eager path, fp32, HN_OPT_SIDE_STREAM 1; waits are bounded (2 s, then hn_step fails).
+                              * Same kernels, same results; [measured, r5] +1 % it/s at 256^2 x 32, +8 % at batch 8.  A tool that runs ONE kernel at
+                              * a time across all queues (counter collection: rocprofv3 --pmc) can starve such a wait: hn_create then defaults
+                              * to 0 (ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS / ROCP_METRICS in the environment); any other such tool gets
+                              * HN_ERR_STATE from hn_step after 2 s and must set HN_SIDE_SYNC=0                                              */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
