@@ -389,9 +389,10 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, 
 }
 
 
+// lds_pad: bytes of (unused) dynamic LDS on top of the static 38 KB -- 7 KB make it 3 blocks per CU instead of 4 (launch_dc_asm)
 template <int CA, int CB, int CC, int EPI>
-void launch(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, const float* zero_page, int H, int W, int batch, hipStream_t s) {
-    hipLaunchKernelGGL((k_dc_asm<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), 0, s, a, b, c, out, w, e, zero_page, H, W);
+void launch(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, const float* zero_page, int H, int W, int batch, hipStream_t s, int lds_pad = 0) {
+    hipLaunchKernelGGL((k_dc_asm<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), lds_pad, s, a, b, c, out, w, e, zero_page, H, W);
 }
 
 }  // namespace
@@ -430,7 +431,10 @@ void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const Dc
         case 0: launch<2, 2, 2, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;              // inc
         case 1: launch<kFeat, kState, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;      // conv_signal
         default:
-            if (final_epi) launch<kFeat, kFeat, 0, 1>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s);  // decoder (+ out-conv, wavefield update)
+            // decoder (+ out-conv, wavefield update).  With the side stream's gate wave resident (flag sync, hn_internal.h) the kernel runs at 3 blocks per CU:
+            // at 4 (every VGPR of every SIMD) the gate's wave costs one CU a block slot and the kernel a ragged third round (70 -> 74 us); at 3 the decoder is as
+            // fast as at 4 [measured, r5: DESIGN_NOTEBOOK Part I] and the gate fits beside it: +0.9 .. 1.1 % it/s at 256^2 x 32 (-0.5 % at 512^2, where no gate exists)
+            if (final_epi) launch<kFeat, kFeat, 0, 1>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s, ctx->dca_dec_pad);
             else launch<kFeat, kFeat, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s);
     }
 }

@@ -194,6 +194,7 @@ struct hn_ctx {
     int opt_side_sync = 1;     // HN_OPT_SIDE_SYNC: 1 device words between the iterations of one hn_step call, 0 events everywhere
     unsigned* sync_flags = nullptr;   // device, 64 words
     unsigned sync_epoch = 0;   // (compared wrap-around safe)
+    int dca_dec_pad = 0;       // dynamic LDS of the next decode_0 launch on hn_dca.hip: 7168 (3 blocks per CU) while the gate kernel is resident, else 0
     int* sync_err = nullptr;          // host-mapped: a bounded device-side wait that gave up stores its code here (sticky; checked by hn_step)
     int* sync_err_dev = nullptr;
     const float* zero_page = nullptr;   // 256 zero bytes (out-of-image float4s of the LDS-direct staging loads, hn_dca.hip)

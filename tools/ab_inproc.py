@@ -8,7 +8,7 @@ temperature.  Prints median / quartiles of ms per iteration per value and the ra
 import argparse, glob, os, sys, threading, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from helmnet_amd import IterativeSolver
+from helmnet_amd import _lib, IterativeSolver
 from helmnet_amd.phantoms import ring_sos_batch
 
 ap = argparse.ArgumentParser()
@@ -16,8 +16,11 @@ ap.add_argument("option"); ap.add_argument("values")
 ap.add_argument("--size", type=int, default=256); ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--steps", type=int, default=300); ap.add_argument("--reps", type=int, default=15)
 ap.add_argument("--clock", action="store_true")
+ap.add_argument("--lib", default=None, help="an alternative build of the library (tools/build_variant.sh)")
 a = ap.parse_args()
 vals = [int(v) for v in a.values.split(",")]
+if a.lib:
+    _lib._LIB_PATH = os.path.abspath(a.lib)
 
 def find(pattern):
     for p in sorted(glob.glob(pattern)):
