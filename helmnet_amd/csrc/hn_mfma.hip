@@ -1944,7 +1944,10 @@ __global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const flo
 #pragma unroll
     for (int ci = 0; ci < kFeat; ++ci) {
         float* t = lds + (ALL ? ci : (ci & 1)) * C::PLANE_P;
-        if (!ALL) {
+#ifndef HN_DN_ABL   // timing ablations only (tools/exp_down.sh): 1 no global loads after the first two channels, 2 no LDS commits after them, 4 no barriers after them
+#define HN_DN_ABL 0
+#endif
+        if (!ALL && !((HN_DN_ABL & 2) && ci >= 2)) {
 #pragma unroll
             for (int i = 0; i < C::NL; ++i) t[lofw[i]] = stage[i];
         }
@@ -1952,8 +1955,8 @@ __global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const flo
 #pragma unroll
         for (int kx = 0; kx < 8; ++kx) afrag[kx] = afrag_next[kx];
         if (!ALL) {
-            __syncthreads();
-            if (ci + 1 < kFeat) fetch(ci + 1);
+            if (!((HN_DN_ABL & 4) && ci >= 2)) __syncthreads();
+            if (ci + 1 < kFeat && !((HN_DN_ABL & 1) && ci >= 1)) fetch(ci + 1);
         } else if (ci + 1 < kFeat) {
 #pragma unroll
             for (int kx = 0; kx < 8; ++kx) afrag_next[kx] = afr[((ci + 1) * 8 + kx) * 64 + lane];
