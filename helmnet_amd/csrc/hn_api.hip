@@ -290,6 +290,7 @@ int64_t hn_get_counter(const hn_ctx* ctx, int counter) {
         case HN_CNT_GRAPHS_CAPTURED: return ctx->graphs_captured;
         case HN_CNT_STREAM_PROBES: return ctx->probes_run;
         case HN_CNT_TRAIN_FWD_EVENTS: return ctx->train_fwd_events;
+        case HN_CNT_FLAG_SYNC_ITERATIONS: return ctx->flag_sync_iterations;
         case HN_CNT_SIDE_CANDIDATE: return ctx->picks[0].known.empty() ? -1 : ctx->picks[0].last_chosen;
         default: return -1;
     }

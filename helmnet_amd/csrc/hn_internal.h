@@ -244,7 +244,7 @@ struct hn_ctx {
     std::vector<StepGraph> graphs;
     long graph_clock = 0;
     hipStream_t cap_stream = nullptr;              // iterations are captured here (the caller's stream may be the legacy default stream)
-    long graph_replays = 0, eager_iterations = 0, graphs_captured = 0, probes_run = 0, train_fwd_events = 0;  // diagnostics (hn_get_counter)
+    long graph_replays = 0, eager_iterations = 0, graphs_captured = 0, probes_run = 0, train_fwd_events = 0, flag_sync_iterations = 0;  // diagnostics (hn_get_counter)
     // training workspace (hn_train.hip): activation tape of the unrolled iterations, gradient buffers, partial sums
     struct TrainWs {
         int batch = 0, n_unroll = 0, n = 0, depth = 0;

@@ -517,6 +517,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         return HN_OK;
     };
     SyncHook rel_hook, join_hook;
+    if (flags) ++ctx->flag_sync_iterations;
     ctx->dca_dec_pad = rel_flag ? 7168 : 0;   // (the gate wave is resident while decode_0 runs: hn_dca.hip, launch_dc_asm)
     if (rel_flag) { rel_hook.store = ctx->sync_flags; rel_hook.store_epoch = sync_epoch; }
     if (flags) { join_hook.wait = ctx->sync_flags + 32; join_hook.wait_epoch = sync_epoch; join_hook.err = ctx->sync_err_dev; }

@@ -129,8 +129,10 @@ enum hn_option {
 enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_GRAPHS_CAPTURED = 2,
                   HN_CNT_STREAM_PROBES = 3,     /* reference-stream sets probed so far (see "side streams" in the conventions above) */
                   HN_CNT_SIDE_CANDIDATE = 4,    /* candidate (0 .. 3) hn_step's side stream was last picked from; -1 before the first pick */
-                  HN_CNT_TRAIN_FWD_EVENTS = 5 };/* times hn_train_grad recorded the registered forward event (hn_train_set_forward_event): a caller compares the
+                  HN_CNT_TRAIN_FWD_EVENTS = 5,  /* times hn_train_grad recorded the registered forward event (hn_train_set_forward_event): a caller compares the
                                                  * counter before and after a call to know whether event and table are valid for it (not under capture) */
+                  HN_CNT_FLAG_SYNC_ITERATIONS = 6 };/* hn_step iterations whose side-stream hand-overs went through device words (HN_OPT_SIDE_SYNC): n_iter - 1 per
+                                                 * eligible call, 0 with the option off, under stream capture, under counter collection, with several lanes */
 
 #define HN_ABI_VERSION 6
 int hn_abi_version(void);

@@ -5,6 +5,8 @@ Tolerances (fp32):
   * teacher-forced single operators: L_inf <= 1e-5 * max|golden|
   * free runs <= 300 iterations: L_inf(wavefield) <= 1e-4 absolute, RMSE trace within 2 %
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -17,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 SRC = {96: [82, 48], 256: [30, 128], 512: [450, 256]}
 DEV = "cuda:0"
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -602,3 +605,34 @@ def test_side_stream_synchronised_by_device_flags_is_bit_identical_to_events(n, 
         assert all(torch.isfinite(t).all() for t in outs[sync])
     for a, c in zip(outs[1], outs[0]):
         assert torch.equal(a, c)
+
+
+def test_flag_sync_is_counted_and_stands_down_under_counter_collection():
+    """hn_get_counter(HN_CNT_FLAG_SYNC_ITERATIONS): a 12-iteration hn_step call hands over through device words in 11 iterations (its last one joins with an
+    event), none with HN_OPT_SIDE_SYNC 0 -- and none by default in a process whose environment announces counter collection (rocprofv3 --pmc runs one kernel at a
+    time across queues and would starve a kernel that waits for another queue's: hn_create then defaults to events), where the solver still produces the same
+    wavefield."""
+    import subprocess, sys
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import ring_sos_batch
+    sos = torch.from_numpy(ring_sos_batch(256, 4, seed=14)).to(DEV)
+    s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+    s.set_domain_size(256, source_location=SRC[256])
+    eng = s.engine()
+    c0 = eng.counter("flag_sync_iterations")
+    ref = s.forward(sos, num_iterations=12, residuals="norms")["wavefields"][0].clone()
+    assert eng.counter("flag_sync_iterations") - c0 == 11
+    eng.set_option("side_sync", 0)
+    c1 = eng.counter("flag_sync_iterations")
+    s.forward(sos, num_iterations=12, residuals="norms")
+    assert eng.counter("flag_sync_iterations") == c1
+    code = ("import torch, sys; sys.path.insert(0, %r); from helmnet_amd import IterativeSolver; from helmnet_amd.phantoms import ring_sos_batch; "
+            "s = IterativeSolver.from_exported_weights(); s.freeze(); s.to('cuda:0'); s.set_domain_size(256, source_location=%r); "
+            "sos = torch.from_numpy(ring_sos_batch(256, 4, seed=14)).to('cuda:0'); wf = s.forward(sos, num_iterations=12, residuals='norms')['wavefields'][0]; "
+            "print('COUNT', s.engine().counter('flag_sync_iterations'), 'SUM', float(wf.double().abs().sum()))") % (REPO, SRC[256])
+    env = dict(os.environ, ROCPROF_COUNTER_COLLECTION="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("COUNT")][-1].split()
+    assert int(line[1]) == 0
+    assert abs(float(line[3]) - float(ref.double().abs().sum())) <= 1e-12 * float(ref.double().abs().sum())   # (same kernels, same order: the same bits)
