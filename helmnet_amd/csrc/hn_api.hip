@@ -189,7 +189,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_EXP_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}};
+                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}, {"HN_STATE_KERNEL", HN_OPT_STATE_KERNEL}};
     // Counter collection (rocprofv3 --pmc, rocprof -i / ROCP_METRICS) runs ONE kernel at a time across all queues, in an order of the tool's choosing: a kernel that
     // waits for a word another queue's kernel stores may then be the one that runs -- the bounded wait gives up after 2 s and hn_step fails [seen, r5].  Under such
     // a tool the hand-overs stay event packets unless HN_SIDE_SYNC says otherwise (the merged level-0 launch is ONE kernel and is not affected).
@@ -251,6 +251,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_DC_PAIR:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_DC_PAIR must be 0 or 1 (got %d)", value);
             ctx->opt_dc_pair = value;
+            break;
+        case HN_OPT_STATE_KERNEL:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_STATE_KERNEL must be 0 or 1 (got %d)", value);
+            ctx->opt_state_kernel = value;
             break;
         case HN_OPT_SIDE_SYNC:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_SIDE_SYNC must be 0 or 1 (got %d)", value);

@@ -1,0 +1,191 @@
+// conv_state: the hidden-state DoubleConv 10 -> 2 -> 2 of every level (architectures.py:248, new_state = conv_state(cat[out, state])) as a streaming kernel.
+//
+// Nothing of the running iteration reads the new states, so these launches sit on a library side stream -- but "hidden" is not free: at 512^2 x 16, where no
+// per-sample deep kernel leaves CUs idle, they cost the main chain 75 us per iteration (8 %: skipping them, tools/cs_skip_probe.py), 45 of them the level-0 launch,
+// whatever their priority, launch order or blocks per CU [measured, r5: DESIGN_NOTEBOOK Part I].  What shrinks that is less of them: the layer is 216 MACs per pixel
+// on 48 bytes, i.e. a stream, and the general kernel (k_double_conv: 4-byte loads through registers, a commit pass and a barrier per channel pair) moves it at 3.3 TB/s.
+//
+// This kernel: tile = 16 x 64 outputs, 256 threads, four blocks per CU.  The window of the tile (rows y0 - 2 .. y0 + 17, columns x0 - 4 .. x0 + 67: 20 x 72 floats per
+// channel, in a slot of six 1 KB wave-instructions) streams through a ring of three two-channel buffers with LDS-direct 16-byte loads (out-of-image float4s from
+// the zero page, no staging registers), two chunks in flight beyond the one being consumed, behind counted vmcnt waits -- the staging of hn_dca.hip.  The three
+// buffers are three arrays, so that the compiler's wait-count insertion knows that reading one does not depend on the loads in flight into the others.
+// conv1 (1 x 6 strips, 198 threads), activation and zero padding of the mid tensor, conv2 (1 x 4 strips, 256 threads) follow the general kernel's arithmetic
+// operation by operation (same fused multiply-adds in the same order per accumulator): the results are bit-identical to k_double_conv<8, 2, 0, 2, 2, 64> (tested).
+#include "hn_internal.h"
+
+namespace hn {
+namespace {
+
+using f32x2 = float __attribute__((ext_vector_type(2)));
+
+constexpr int kPI = 72, kIR = 20, kPlane4 = kIR * kPI / 4;   // the window of one channel: 1440 floats = 360 float4 ...
+constexpr int kSlot = 6 * 256;                                // ... in a slot of six wave-instructions of 64 float4 (the sixth fills 40 lanes)
+constexpr int kChunk = 2 * kSlot;                             // two channels: 12 wave-instructions, three per wave
+constexpr int kCin = kFeat + kState, kNG = kCin / 2;          // 10 channels = 5 chunks
+constexpr int kMR = 18, kPM = 68;                             // mid tensor [2][18][68] (66 columns used), aliased onto the first ring buffer
+static_assert(3 * kChunk * 4 <= 40960 && 2 * kMR * kPM <= kChunk, "four blocks per CU; the mid tensor fits a buffer");
+
+// (the weights come as const __restrict__ kernel arguments of their own: loads through them are invariant, i.e. scalar loads, whatever the LDS-direct loads and the
+// hand-placed waits in between look like to the alias analysis)
+__global__ __launch_bounds__(256, 4) void k_conv_state(Src sa, Src sb, Dst out, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ slope_p, const float* __restrict__ w2, const float* __restrict__ b2,
+                                                       const float* __restrict__ zero_page, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float ring0[kChunk];
+    __shared__ __attribute__((aligned(16))) float ring1[kChunk];
+    __shared__ __attribute__((aligned(16))) float ring2[kChunk];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const TileId tl = xcd_tile();
+    const int b = tl.z, x0 = tl.x * 64, y0 = tl.y * 16;
+    const float* const base_a = sa.p + (long)b * sa.sb;
+    const float* const base_b = sb.p + (long)b * sb.sb;
+
+    // ---- staging plan: of a chunk's 12 wave-instructions (k = 6 * channel-in-chunk + j) wave w issues k = w, w + 4, w + 8: the same three for every chunk ----
+    long goff[3];
+    bool gok[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int k = wave + 4 * i, j = k % 6;
+        const int p = 64 * j + lane;
+        const int ir = p / 18, ic4 = p - 18 * ir;
+        const int y = y0 - 2 + ir, x = x0 - 4 + 4 * ic4;
+        gok[i] = p < kPlane4 && y >= 0 && y < H && x >= 0 && x < W;
+        goff[i] = gok[i] ? (long)y * W + x : 0;
+    }
+    auto chan_ptr = [&](int c) -> const float* { return c < kFeat ? base_a + (long)c * sa.sc : base_b + (long)(c - kFeat) * sb.sc; };   // (c is wave-uniform)
+    auto issue = [&](int g, float* ring) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int k = wave + 4 * i;
+            const float* src = gok[i] ? chan_ptr(2 * g + k / 6) + goff[i] : zero_page;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)(ring + k * 256), 16, 0, 0);
+        }
+    };
+
+    // ---- conv1 over the 18 x 66 mid region: thread = (mid row, strip of 6 columns); window column of mid column mc, tap dx: mc + dx + 2 ----
+    const int mr = tid / 11, s6 = tid - 11 * mr;
+    const bool act1 = tid < 11 * kMR;
+    f32x2 acc1[6];
+#pragma unroll
+    for (int p = 0; p < 6; ++p) acc1[p] = (f32x2){0.f, 0.f};
+    auto conv1 = [&](const float* ring, int g) {
+        if (!act1) return;
+        const unsigned t_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)ring + 4u * (unsigned)(mr * kPI + 6 * s6 + 2);   // LDS byte address
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const float* __restrict__ wc = w1 + (2 * g + cc) * 18;   // [cin][3][3][2]
+            // (the 3 x 8 window values of the channel through inline assembly, all twelve reads in flight at once: LDS reads the compiler can see make its wait-count
+            // insertion wait for EVERY LDS-direct load in flight -- it cannot see the counted waits below -- which is the prefetch this ring exists for)
+            f32x2 r[3][4];
+            asm volatile("ds_read_b64 %0, %12 offset:%13\n\tds_read_b64 %1, %12 offset:%14\n\tds_read_b64 %2, %12 offset:%15\n\tds_read_b64 %3, %12 offset:%16\n\t"
+                         "ds_read_b64 %4, %12 offset:%17\n\tds_read_b64 %5, %12 offset:%18\n\tds_read_b64 %6, %12 offset:%19\n\tds_read_b64 %7, %12 offset:%20\n\t"
+                         "ds_read_b64 %8, %12 offset:%21\n\tds_read_b64 %9, %12 offset:%22\n\tds_read_b64 %10, %12 offset:%23\n\tds_read_b64 %11, %12 offset:%24\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[0][3]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]), "=&v"(r[1][3]),
+                           "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[2][2]), "=&v"(r[2][3])
+                         : "v"(t_addr), "n"(4 * (cc * kSlot)), "n"(4 * (cc * kSlot + 2)), "n"(4 * (cc * kSlot + 4)), "n"(4 * (cc * kSlot + 6)),
+                           "n"(4 * (cc * kSlot + kPI)), "n"(4 * (cc * kSlot + kPI + 2)), "n"(4 * (cc * kSlot + kPI + 4)), "n"(4 * (cc * kSlot + kPI + 6)),
+                           "n"(4 * (cc * kSlot + 2 * kPI)), "n"(4 * (cc * kSlot + 2 * kPI + 2)), "n"(4 * (cc * kSlot + 2 * kPI + 4)), "n"(4 * (cc * kSlot + 2 * kPI + 6))
+                         : "memory");
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const float v[8] = {r[dy][0][0], r[dy][0][1], r[dy][1][0], r[dy][1][1], r[dy][2][0], r[dy][2][1], r[dy][3][0], r[dy][3][1]};
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const f32x2 wv = {wc[(dy * 3 + dx) * 2], wc[(dy * 3 + dx) * 2 + 1]};
+#pragma unroll
+                    for (int p = 0; p < 6; ++p) acc1[p] = __builtin_elementwise_fma(wv, (f32x2){v[p + dx], v[p + dx]}, acc1[p]);
+                }
+            }
+        }
+    };
+    // chunk g has landed once at most the three loads of the chunk behind it are outstanding (vmcnt counts in issue order); the barrier says the same of the other
+    // waves' shares AND that chunk g - 1 has been consumed: its buffer takes chunk g + 2.  (Bare s_barrier: __syncthreads() would wait for every outstanding load.)
+#define HN_CS_STEP(g, cur, nxt2)                                                      \
+    if ((g) + 1 < kNG) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                              \
+    __builtin_amdgcn_s_barrier();                                                      \
+    asm volatile("" ::: "memory");                                                     \
+    if ((g) + 2 < kNG) issue((g) + 2, nxt2);                                           \
+    conv1(cur, g);
+    issue(0, ring0);
+    issue(1, ring1);
+    HN_CS_STEP(0, ring0, ring2)
+    HN_CS_STEP(1, ring1, ring0)
+    HN_CS_STEP(2, ring2, ring1)
+    HN_CS_STEP(3, ring0, ring2)
+    HN_CS_STEP(4, ring1, ring0)
+#undef HN_CS_STEP
+    __syncthreads();   // the staged input is dead: the mid tensor takes ring0
+    float* const lds = ring0;
+
+    if (act1) {
+        const float slope = slope_p[0];
+        const int y = y0 - 1 + mr;
+        const bool yin = y >= 0 && y < H;
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const float bias = b1[m];
+            float o[6];
+#pragma unroll
+            for (int p = 0; p < 6; ++p) {
+                const int x = x0 - 1 + 6 * s6 + p;
+                float v = acc1[p][m] + bias;
+                v = v > 0.f ? v : slope * v;   // PReLU / ReLU / LeakyReLU: one scalar slope (architectures.py:32-33)
+                o[p] = (yin && x >= 0 && x < W) ? v : 0.f;   // conv2 zero-pads the MID tensor
+            }
+            float* mp = lds + (m * kMR + mr) * kPM + 6 * s6;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) *reinterpret_cast<float2*>(mp + 2 * j) = make_float2(o[2 * j], o[2 * j + 1]);
+        }
+    }
+    __syncthreads();
+
+    // ---- conv2 over the 16 x 64 output tile: thread = (row, strip of 4) ----
+    const int oy = tid >> 4, s2 = tid & 15;
+    f32x2 acc2[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc2[p] = (f32x2){0.f, 0.f};
+#pragma unroll
+    for (int cm = 0; cm < 2; ++cm) {
+        const float* t = lds + (cm * kMR + oy) * kPM + 4 * s2;
+        const float* __restrict__ wc = w2 + cm * 18;   // [cmid][3][3][2]
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const float4 lo = *reinterpret_cast<const float4*>(t + dy * kPM);
+            const float2 hi = *reinterpret_cast<const float2*>(t + dy * kPM + 4);
+            const float v[6] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y};
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const f32x2 wv = {wc[(dy * 3 + dx) * 2], wc[(dy * 3 + dx) * 2 + 1]};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) acc2[p] = __builtin_elementwise_fma(wv, (f32x2){v[p + dx], v[p + dx]}, acc2[p]);
+            }
+        }
+    }
+    const int y = y0 + oy, x = x0 + 4 * s2;
+    if (y >= H || x >= W) return;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float bias = b2[m];
+        float* po = out.p + (long)b * out.sb + (long)m * out.sc + (long)y * W + x;
+        *reinterpret_cast<float4*>(po) = make_float4(acc2[0][m] + bias, acc2[1][m] + bias, acc2[2][m] + bias, acc2[3][m] + bias);
+    }
+}
+
+}  // namespace
+
+// a = out_d (8 channels), b = state_d (2 channels); everything else keeps the general kernel (k_double_conv, hn_unet.hip)
+bool conv_state_applies(const hn_ctx* ctx, const DcW& w, Src a, Src b, Dst out, int H, int W) {
+    if (!ctx->opt_state_kernel || ctx->zero_page == nullptr || w.act > HN_ACT_LEAKYRELU) return false;
+    if (a.scale != 1.f || b.scale != 1.f || W < 64 || (W & 3) != 0) return false;
+    const bool aligned = (reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(b.p) | reinterpret_cast<uintptr_t>(out.p)) % 16 == 0 &&
+                         (a.sb % 4 | a.sc % 4 | b.sb % 4 | b.sc % 4 | out.sb % 4 | out.sc % 4) == 0;
+    return aligned;
+}
+
+void launch_conv_state(hn_ctx* ctx, Src a, Src b, Dst out, const DcW& w, int H, int W, int batch, hipStream_t s) {
+    hipLaunchKernelGGL(k_conv_state, dim3((W + 63) / 64, (H + 15) / 16, batch), dim3(256), 0, s, a, b, out, w.w1, w.b1, w.slope, w.w2, w.b2, ctx->zero_page, H, W);
+}
+
+}  // namespace hn

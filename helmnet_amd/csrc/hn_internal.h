@@ -191,6 +191,7 @@ struct hn_ctx {
     //            event packet saves); hipStreamWaitValue64 is itself a spinning kernel here and slower.
     // Every store is enqueued before the kernel that waits for it (a tool that runs one kernel at a time in submission order cannot deadlock), every wait is
     // bounded (2 s, then hn_step fails).
+    int opt_state_kernel = 1;  // HN_OPT_STATE_KERNEL: 1 the hidden-state DoubleConvs (10 -> 2 -> 2) of the levels >= 64 wide on the streaming kernel (hn_cs.hip), 0 k_double_conv
     int opt_side_sync = 1;     // HN_OPT_SIDE_SYNC: 1 device words between the iterations of one hn_step call, 0 events everywhere
     unsigned* sync_flags = nullptr;   // device, 64 words
     unsigned sync_epoch = 0;   // (compared wrap-around safe)
@@ -452,6 +453,9 @@ void pack_dca(const float* w_oihw, int cin, const float* scale, float* dst);   /
 bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W);
 void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H, int W,
                    int batch, hipStream_t s);
+// ---- hidden-state DoubleConv as a streaming kernel (hn_cs.hip) ----
+bool conv_state_applies(const hn_ctx* ctx, const DcW& w, Src a, Src b, Dst out, int H, int W);
+void launch_conv_state(hn_ctx* ctx, Src a, Src b, Dst out, const DcW& w, int H, int W, int batch, hipStream_t s);
 // inc and conv_signal_0 as ONE launch with a flag per tile (k_dc_asm_pair): x0_out / x0 are the same tensor as inc's output and conv_signal's input
 bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch);
 void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, hipStream_t s);

@@ -511,7 +511,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
             const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
             ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
-            HN_REP(KID_STATE0 + 3 * e) launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
+            HN_REP(KID_STATE0 + 3 * e) {
+                if (conv_state_applies(ctx, ctx->st[e], featsrc(ctx->buf_o[e], e), so, sn, me, me)) launch_conv_state(ctx, featsrc(ctx->buf_o[e], e), so, sn, ctx->st[e], me, me, batch, side);
+                else launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
+            }
         }
         if (flags) hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, side, ctx->sync_flags + 32, sync_epoch);   // (... before up_0, which waits for it)
         return HN_OK;
@@ -537,8 +540,9 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // state = conv_state(cat[out, state_old])                        (architectures.py:248)
         if (policy == 0) {
             ProfScope ps(ctx, KID_STATE0 + 3 * d, s);
-            launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
-                                                            noepi, m, m, batch, s);
+            if (conv_state_applies(ctx, ctx->st[d], featsrc(ctx->buf_o[d], d), st_old, st_new, m, m)) launch_conv_state(ctx, featsrc(ctx->buf_o[d], d), st_old, st_new, ctx->st[d], m, m, batch, s);
+            else launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
+                                                                noepi, m, m, batch, s);
         } else if (policy == 2) {
             int rc = release_states(d, d + 1, side_lane->ev[d]);
             if (rc != HN_OK) return rc;

@@ -99,6 +99,9 @@ enum hn_option {
                               * a time across all queues (counter collection: rocprofv3 --pmc) can starve such a wait: hn_create then defaults
                               * to 0 (ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS / ROCP_METRICS in the environment); any other such tool gets
                               * HN_ERR_STATE from hn_step after 2 s and must set HN_SIDE_SYNC=0                                              */
+    HN_OPT_STATE_KERNEL = 14, /* 0/1 (default 1): the hidden-state DoubleConvs (10 -> 2 -> 2) of the levels at least 64 wide on the streaming kernel
+                              * (hn_cs.hip: the tile's ten input planes through a ring of LDS-direct loads); 0: the general direct kernel.
+                              * Bit-identical                                                                                          */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of

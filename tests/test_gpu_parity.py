@@ -636,3 +636,24 @@ def test_flag_sync_is_counted_and_stands_down_under_counter_collection():
     line = [l for l in out.stdout.splitlines() if l.startswith("COUNT")][-1].split()
     assert int(line[1]) == 0
     assert abs(float(line[3]) - float(ref.double().abs().sum())) <= 1e-12 * float(ref.double().abs().sum())   # (same kernels, same order: the same bits)
+
+
+@pytest.mark.parametrize("n,b", [(256, 8), (512, 2), (320, 1), (272, 3), (96, 5), (64, 2)])
+def test_streaming_hidden_state_kernel_is_bit_identical_to_the_general_one(n, b):
+    """HN_OPT_STATE_KERNEL (hn_cs.hip): conv_state (architectures.py:248, DoubleConv 10 -> 2 -> 2) of every level at least 64 wide on the streaming kernel
+    (the tile's ten input planes through a ring of LDS-direct loads) performs the general kernel's fused multiply-adds in the same order per accumulator: hidden
+    states, wavefields and residuals of 25 free-running iterations are equal bit for bit -- with whole tiles (256, 512), partial tile columns and rows (320: levels
+    160 and 80; 272: 136 and 68), a level-0-only case (96) and the smallest eligible width (64)."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import ring_sos_batch
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=15)).to(DEV)
+    outs = {}
+    for k in (1, 0):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=SRC.get(n, [n // 3, n // 2]))
+        s.engine().set_option("state_kernel", k)
+        o = s.forward(sos, num_iterations=25, residuals="norms")
+        outs[k] = (s.f.get_states(flatten=True).clone(), o["wavefields"][0].clone(), o["last_residual"].clone())
+        assert torch.isfinite(outs[k][0]).all() and outs[k][0].abs().max() > 0
+    for a, c in zip(outs[1], outs[0]):
+        assert torch.equal(a, c)
