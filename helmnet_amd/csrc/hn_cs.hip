@@ -25,18 +25,43 @@ constexpr int kCin = kFeat + kState, kNG = kCin / 2;          // 10 channels = 5
 constexpr int kMR = 18, kPM = 68;                             // mid tensor [2][18][68] (66 columns used), aliased onto the first ring buffer
 static_assert(3 * kChunk * 4 <= 40960 && 2 * kMR * kPM <= kChunk, "four blocks per CU; the mid tensor fits a buffer");
 
-// (the weights come as const __restrict__ kernel arguments of their own: loads through them are invariant, i.e. scalar loads, whatever the LDS-direct loads and the
-// hand-placed waits in between look like to the alias analysis)
-__global__ __launch_bounds__(256, 4) void k_conv_state(Src sa, Src sb, Dst out, const float* __restrict__ w1, const float* __restrict__ b1,
-                                                       const float* __restrict__ slope_p, const float* __restrict__ w2, const float* __restrict__ b2,
-                                                       const float* __restrict__ zero_page, int H, int W) {
+// One launch serves several levels (conv_state_0 .. of an iteration: their tiles are independent): block ids [tile0, tile0 + tiles) belong to level l, the largest
+// level first.  The weights are offsets into ONE const __restrict__ blob (hn_ctx::wdev): loads through it are invariant, i.e. scalar loads, whatever the
+// LDS-direct loads and the hand-placed waits in between look like to the alias analysis -- a vector load of a weight would break the counted vmcnt waits.
+struct CsLevel {
+    Src a, b;      // out_d (8 channels), state_d (2 channels)
+    Dst out;       // new state_d
+    int ow1, ob1, oslope, ow2, ob2;   // DcW pointers as offsets into the weight blob
+    int H, W, gx, gy, tile0, tiles;
+};
+struct CsArgs { int n; CsLevel lv[kMaxDepth]; };
+
+__global__ __launch_bounds__(256, 4) void k_conv_state(CsArgs args, const float* __restrict__ wbase, const float* __restrict__ zero_page) {
     __shared__ __attribute__((aligned(16))) float ring0[kChunk];
     __shared__ __attribute__((aligned(16))) float ring1[kChunk];
     __shared__ __attribute__((aligned(16))) float ring2[kChunk];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const TileId tl = xcd_tile();
-    const int b = tl.z, x0 = tl.x * 64, y0 = tl.y * 16;
+    // the level of this block (wave-uniform: scalar selects from the kernel-argument segment, no indexed copy of the struct)
+    const int id = blockIdx.x;
+    CsLevel L = args.lv[0];
+#pragma unroll
+    for (int k = 1; k < kMaxDepth; ++k)
+        if (k < args.n && id >= args.lv[k].tile0) L = args.lv[k];
+    const Src sa = L.a, sb = L.b;
+    const Dst out = L.out;
+    const int H = L.H, W = L.W;
+    const float* __restrict__ const w1 = wbase + L.ow1;
+    const float* __restrict__ const b1 = wbase + L.ob1;
+    const float* __restrict__ const slope_p = wbase + L.oslope;
+    const float* __restrict__ const w2 = wbase + L.ow2;
+    const float* __restrict__ const b2 = wbase + L.ob2;
+    int t = id - L.tile0;
+#ifndef HN_NO_XCD
+    if ((L.tiles & 7) == 0 && (L.tile0 & 7) == 0) t = (t & 7) * (L.tiles >> 3) + (t >> 3);   // xcd_tile(): each XCD walks a contiguous run of the level's tiles
+#endif
+    const int q = t / L.gx;
+    const int b = q / L.gy, x0 = (t - q * L.gx) * 64, y0 = (q - b * L.gy) * 16;
     const float* const base_a = sa.p + (long)b * sa.sb;
     const float* const base_b = sb.p + (long)b * sb.sb;
 
@@ -177,15 +202,30 @@ __global__ __launch_bounds__(256, 4) void k_conv_state(Src sa, Src sb, Dst out, 
 
 // a = out_d (8 channels), b = state_d (2 channels); everything else keeps the general kernel (k_double_conv, hn_unet.hip)
 bool conv_state_applies(const hn_ctx* ctx, const DcW& w, Src a, Src b, Dst out, int H, int W) {
-    if (!ctx->opt_state_kernel || ctx->zero_page == nullptr || w.act > HN_ACT_LEAKYRELU) return false;
+    if (!ctx->opt_state_kernel || ctx->zero_page == nullptr || ctx->wdev == nullptr || w.act > HN_ACT_LEAKYRELU) return false;
+    if (w.w1 < ctx->wdev || w.w1 - ctx->wdev > (1 << 28)) return false;   // (the kernel addresses the weights as offsets into the context's blob)
     if (a.scale != 1.f || b.scale != 1.f || W < 64 || (W & 3) != 0) return false;
     const bool aligned = (reinterpret_cast<uintptr_t>(a.p) | reinterpret_cast<uintptr_t>(b.p) | reinterpret_cast<uintptr_t>(out.p)) % 16 == 0 &&
                          (a.sb % 4 | a.sc % 4 | b.sb % 4 | b.sc % 4 | out.sb % 4 | out.sc % 4) == 0;
     return aligned;
 }
 
-void launch_conv_state(hn_ctx* ctx, Src a, Src b, Dst out, const DcW& w, int H, int W, int batch, hipStream_t s) {
-    hipLaunchKernelGGL(k_conv_state, dim3((W + 63) / 64, (H + 15) / 16, batch), dim3(256), 0, s, a, b, out, w.w1, w.b1, w.slope, w.w2, w.b2, ctx->zero_page, H, W);
+// one launch for up to kMaxDepth levels (each checked with conv_state_applies); levels in the order given: the largest first
+void launch_conv_state(hn_ctx* ctx, int n, const Src* a, const Src* b, const Dst* out, const DcW* w, const int* H, const int* W, int batch, hipStream_t s) {
+    CsArgs args{};
+    args.n = n;
+    int tiles = 0;
+    for (int l = 0; l < n; ++l) {
+        CsLevel& L = args.lv[l];
+        L.a = a[l]; L.b = b[l]; L.out = out[l];
+        L.ow1 = (int)(w[l].w1 - ctx->wdev); L.ob1 = (int)(w[l].b1 - ctx->wdev); L.oslope = (int)(w[l].slope - ctx->wdev);
+        L.ow2 = (int)(w[l].w2 - ctx->wdev); L.ob2 = (int)(w[l].b2 - ctx->wdev);
+        L.H = H[l]; L.W = W[l]; L.gx = (W[l] + 63) / 64; L.gy = (H[l] + 15) / 16;
+        L.tile0 = tiles; L.tiles = L.gx * L.gy * batch;
+        tiles += L.tiles;
+    }
+    for (int l = n; l < kMaxDepth; ++l) args.lv[l] = args.lv[0];
+    hipLaunchKernelGGL(k_conv_state, dim3(tiles), dim3(256), 0, s, args, (const float*)ctx->wdev, ctx->zero_page);
 }
 
 }  // namespace hn

@@ -455,7 +455,7 @@ void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const Dc
                    int batch, hipStream_t s);
 // ---- hidden-state DoubleConv as a streaming kernel (hn_cs.hip) ----
 bool conv_state_applies(const hn_ctx* ctx, const DcW& w, Src a, Src b, Dst out, int H, int W);
-void launch_conv_state(hn_ctx* ctx, Src a, Src b, Dst out, const DcW& w, int H, int W, int batch, hipStream_t s);
+void launch_conv_state(hn_ctx* ctx, int n, const Src* a, const Src* b, const Dst* out, const DcW* w, const int* H, const int* W, int batch, hipStream_t s);   // n levels, one launch
 // inc and conv_signal_0 as ONE launch with a flag per tile (k_dc_asm_pair): x0_out / x0 are the same tensor as inc's output and conv_signal's input
 bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch);
 void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, hipStream_t s);

@@ -502,6 +502,11 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             HN_HIP(ctx, hipEventRecord(ev, s));
             HN_HIP(ctx, hipStreamWaitEvent(side, ev, 0));
         }
+        // the levels the streaming kernel takes (hn_cs.hip) share ONE launch, the largest first; the others keep the general kernel, one launch each
+        Src ba[kMaxDepth], bb[kMaxDepth];
+        Dst bo[kMaxDepth];
+        DcW bw[kMaxDepth];
+        int bh[kMaxDepth], nb_levels = 0, first_level = d0;
         for (int e = d0; e < d1; ++e) {
 #ifdef HN_EXP_SKIP_STATE   // timing experiment only (tools/r4_skip_state.sh): environment bit e skips conv_state_e -- the results are WRONG
             static const int exp_skip = getenv("HN_EXP_SKIP_STATE") ? std::atoi(getenv("HN_EXP_SKIP_STATE")) : 0;
@@ -510,11 +515,24 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             const int me = n >> e;
             const Src so{states_in + ctx->state_off[e], 2 * L, L, 1.f};
             const Dst sn{states_out + ctx->state_off[e], 2 * L, L};
+#ifndef HN_EXP_REPEAT   // (the per-kernel probes of tools/energy_probe.py / cs_skip_probe.py launch every level on its own)
+            if (conv_state_applies(ctx, ctx->st[e], featsrc(ctx->buf_o[e], e), so, sn, me, me)) {
+                if (nb_levels == 0) first_level = e;
+                ba[nb_levels] = featsrc(ctx->buf_o[e], e); bb[nb_levels] = so; bo[nb_levels] = sn; bw[nb_levels] = ctx->st[e]; bh[nb_levels] = me;
+                ++nb_levels;
+                continue;
+            }
+#endif
             ProfScope ps2(ctx, KID_STATE0 + 3 * e, side);
             HN_REP(KID_STATE0 + 3 * e) {
-                if (conv_state_applies(ctx, ctx->st[e], featsrc(ctx->buf_o[e], e), so, sn, me, me)) launch_conv_state(ctx, featsrc(ctx->buf_o[e], e), so, sn, ctx->st[e], me, me, batch, side);
+                const Src oe = featsrc(ctx->buf_o[e], e);
+                if (conv_state_applies(ctx, ctx->st[e], oe, so, sn, me, me)) launch_conv_state(ctx, 1, &oe, &so, &sn, &ctx->st[e], &me, &me, batch, side);
                 else launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[e], e), so, none, sn, ctx->st[e], noepi, me, me, batch, side);
             }
+        }
+        if (nb_levels > 0) {
+            ProfScope ps2(ctx, KID_STATE0 + 3 * first_level, side);   // (the merged launch is accounted to its largest level)
+            launch_conv_state(ctx, nb_levels, ba, bb, bo, bw, bh, bh, batch, side);
         }
         if (flags) hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, side, ctx->sync_flags + 32, sync_epoch);   // (... before up_0, which waits for it)
         return HN_OK;
@@ -540,7 +558,8 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         // state = conv_state(cat[out, state_old])                        (architectures.py:248)
         if (policy == 0) {
             ProfScope ps(ctx, KID_STATE0 + 3 * d, s);
-            if (conv_state_applies(ctx, ctx->st[d], featsrc(ctx->buf_o[d], d), st_old, st_new, m, m)) launch_conv_state(ctx, featsrc(ctx->buf_o[d], d), st_old, st_new, ctx->st[d], m, m, batch, s);
+            const Src od = featsrc(ctx->buf_o[d], d);
+            if (conv_state_applies(ctx, ctx->st[d], od, st_old, st_new, m, m)) launch_conv_state(ctx, 1, &od, &st_old, &st_new, &ctx->st[d], &m, &m, batch, s);
             else launch_dc<kFeat, kState, 0, kState, kState, 0>(featsrc(ctx->buf_o[d], d), st_old, none, st_new, ctx->st[d],
                                                                 noepi, m, m, batch, s);
         } else if (policy == 2) {
