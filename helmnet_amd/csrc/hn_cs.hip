@@ -96,25 +96,30 @@ __global__ __launch_bounds__(256, 4) void k_conv_state(CsArgs args, const float*
     auto conv1 = [&](const float* ring, int g) {
         if (!act1) return;
         const unsigned t_addr = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) float*)ring + 4u * (unsigned)(mr * kPI + 6 * s6 + 2);   // LDS byte address
+        // The 2 x 3 x 8 window values of the chunk's two channels through inline assembly, all 24 reads in flight at once: LDS reads the compiler can see make its
+        // wait-count insertion wait for EVERY LDS-direct load in flight -- it cannot see the counted waits below -- which is the prefetch this ring exists for.
+        // Offsets (bytes): row dy at 288 dy, pair j at 8 j, second channel at 6144 (kSlot floats).
+        f32x2 r[2][3][4];
+        asm volatile(
+            "ds_read_b64 %0, %24 offset:0\n\tds_read_b64 %1, %24 offset:8\n\tds_read_b64 %2, %24 offset:16\n\tds_read_b64 %3, %24 offset:24\n\t"
+            "ds_read_b64 %4, %24 offset:288\n\tds_read_b64 %5, %24 offset:296\n\tds_read_b64 %6, %24 offset:304\n\tds_read_b64 %7, %24 offset:312\n\t"
+            "ds_read_b64 %8, %24 offset:576\n\tds_read_b64 %9, %24 offset:584\n\tds_read_b64 %10, %24 offset:592\n\tds_read_b64 %11, %24 offset:600\n\t"
+            "ds_read_b64 %12, %24 offset:6144\n\tds_read_b64 %13, %24 offset:6152\n\tds_read_b64 %14, %24 offset:6160\n\tds_read_b64 %15, %24 offset:6168\n\t"
+            "ds_read_b64 %16, %24 offset:6432\n\tds_read_b64 %17, %24 offset:6440\n\tds_read_b64 %18, %24 offset:6448\n\tds_read_b64 %19, %24 offset:6456\n\t"
+            "ds_read_b64 %20, %24 offset:6720\n\tds_read_b64 %21, %24 offset:6728\n\tds_read_b64 %22, %24 offset:6736\n\tds_read_b64 %23, %24 offset:6744\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(r[0][0][0]), "=&v"(r[0][0][1]), "=&v"(r[0][0][2]), "=&v"(r[0][0][3]), "=&v"(r[0][1][0]), "=&v"(r[0][1][1]), "=&v"(r[0][1][2]), "=&v"(r[0][1][3]),
+              "=&v"(r[0][2][0]), "=&v"(r[0][2][1]), "=&v"(r[0][2][2]), "=&v"(r[0][2][3]), "=&v"(r[1][0][0]), "=&v"(r[1][0][1]), "=&v"(r[1][0][2]), "=&v"(r[1][0][3]),
+              "=&v"(r[1][1][0]), "=&v"(r[1][1][1]), "=&v"(r[1][1][2]), "=&v"(r[1][1][3]), "=&v"(r[1][2][0]), "=&v"(r[1][2][1]), "=&v"(r[1][2][2]), "=&v"(r[1][2][3])
+            : "v"(t_addr)
+            : "memory");
+        static_assert(kPI * 4 == 288 && kSlot * 4 == 6144, "the literal offsets above");
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
             const float* __restrict__ wc = w1 + (2 * g + cc) * 18;   // [cin][3][3][2]
-            // (the 3 x 8 window values of the channel through inline assembly, all twelve reads in flight at once: LDS reads the compiler can see make its wait-count
-            // insertion wait for EVERY LDS-direct load in flight -- it cannot see the counted waits below -- which is the prefetch this ring exists for)
-            f32x2 r[3][4];
-            asm volatile("ds_read_b64 %0, %12 offset:%13\n\tds_read_b64 %1, %12 offset:%14\n\tds_read_b64 %2, %12 offset:%15\n\tds_read_b64 %3, %12 offset:%16\n\t"
-                         "ds_read_b64 %4, %12 offset:%17\n\tds_read_b64 %5, %12 offset:%18\n\tds_read_b64 %6, %12 offset:%19\n\tds_read_b64 %7, %12 offset:%20\n\t"
-                         "ds_read_b64 %8, %12 offset:%21\n\tds_read_b64 %9, %12 offset:%22\n\tds_read_b64 %10, %12 offset:%23\n\tds_read_b64 %11, %12 offset:%24\n\t"
-                         "s_waitcnt lgkmcnt(0)"
-                         : "=&v"(r[0][0]), "=&v"(r[0][1]), "=&v"(r[0][2]), "=&v"(r[0][3]), "=&v"(r[1][0]), "=&v"(r[1][1]), "=&v"(r[1][2]), "=&v"(r[1][3]),
-                           "=&v"(r[2][0]), "=&v"(r[2][1]), "=&v"(r[2][2]), "=&v"(r[2][3])
-                         : "v"(t_addr), "n"(4 * (cc * kSlot)), "n"(4 * (cc * kSlot + 2)), "n"(4 * (cc * kSlot + 4)), "n"(4 * (cc * kSlot + 6)),
-                           "n"(4 * (cc * kSlot + kPI)), "n"(4 * (cc * kSlot + kPI + 2)), "n"(4 * (cc * kSlot + kPI + 4)), "n"(4 * (cc * kSlot + kPI + 6)),
-                           "n"(4 * (cc * kSlot + 2 * kPI)), "n"(4 * (cc * kSlot + 2 * kPI + 2)), "n"(4 * (cc * kSlot + 2 * kPI + 4)), "n"(4 * (cc * kSlot + 2 * kPI + 6))
-                         : "memory");
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
-                const float v[8] = {r[dy][0][0], r[dy][0][1], r[dy][1][0], r[dy][1][1], r[dy][2][0], r[dy][2][1], r[dy][3][0], r[dy][3][1]};
+                const float v[8] = {r[cc][dy][0][0], r[cc][dy][0][1], r[cc][dy][1][0], r[cc][dy][1][1], r[cc][dy][2][0], r[cc][dy][2][1], r[cc][dy][3][0], r[cc][dy][3][1]};
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const f32x2 wv = {wc[(dy * 3 + dx) * 2], wc[(dy * 3 + dx) * 2 + 1]};
