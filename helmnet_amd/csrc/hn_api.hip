@@ -143,6 +143,16 @@ __global__ void k_rmse_finalize(float* __restrict__ v, int count, float inv_n) {
 }
 
 }  // namespace
+int ensure_sync_words(hn_ctx* ctx) {   // flag sync (hn_internal.h): the device words and a host-visible error word, for the context's lifetime
+    if (ctx->sync_flags != nullptr) return HN_OK;
+    HN_HIP(ctx, hipMalloc((void**)&ctx->sync_flags, sizeof(unsigned) * 256));
+    HN_HIP(ctx, hipMemset(ctx->sync_flags, 0, sizeof(unsigned) * 256));
+    HN_HIP(ctx, hipHostMalloc((void**)&ctx->sync_err, sizeof(int), hipHostMallocMapped));
+    *ctx->sync_err = 0;
+    HN_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->sync_err_dev, ctx->sync_err, 0));
+    return HN_OK;
+}
+
 }  // namespace hn
 
 using namespace hn;
@@ -523,13 +533,7 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
     ctx->pair_flags_cap = (long)((n + 63) / 64) * ((n + 15) / 16) * max_batch;   // one flag word per level-0 tile (k_dc_asm_pair); epochs start at 1
     HN_HIP(ctx, hipMalloc((void**)&ctx->pair_flags, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
     HN_HIP(ctx, hipMemset(ctx->pair_flags, 0, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
-    if (ctx->sync_flags == nullptr) {   // flag sync (hn_internal.h): two device words and a host-visible error word, for the context's lifetime
-        HN_HIP(ctx, hipMalloc((void**)&ctx->sync_flags, sizeof(unsigned) * 64));
-        HN_HIP(ctx, hipMemset(ctx->sync_flags, 0, sizeof(unsigned) * 64));
-        HN_HIP(ctx, hipHostMalloc((void**)&ctx->sync_err, sizeof(int), hipHostMallocMapped));
-        *ctx->sync_err = 0;
-        HN_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->sync_err_dev, ctx->sync_err, 0));
-    }
+    if (int rc_sync = ensure_sync_words(ctx); rc_sync != HN_OK) return rc_sync;
     ctx->cap_batch = max_batch;
     return HN_OK;
 }

@@ -265,6 +265,7 @@ struct hn_ctx {
         bool wg_pending[2]{};
         hipEvent_t st_fork = nullptr, st_done = nullptr;   // forward sweep: the hidden-state DoubleConvs of an iteration on wg_stream (idle then) beside its decoder
         bool st_pending = false;
+        unsigned wg_flag_epoch[2]{}, bwd_release_epoch = 0;   // flag sync of the training step (hn_train.hip): join epochs of the two job sets; release still to be stored
         float* part = nullptr;       // [640 rows][blob]: per-block sums of the weight-gradient kernels, all layers and iterations
         size_t part_floats = 0;
         double* slope_part = nullptr; // [3 depth + 2 DoubleConvs][slope_stride]: per-block sums of the PReLU-slope gradients (float64)
@@ -437,7 +438,8 @@ int dc8_bwd_tiles(int H, int W, int batch);   // rows of slope_part a launch add
 int launch_dc8_bwd(hn_ctx* ctx, const McBwd& a, int cin, int H, int W, int batch, hipStream_t s);
 int launch_dc8_tape(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const float* frag1, const float* b1, const float* slope, const float* frag2,
                     const float* b2, int act, float* z, int H, int W, int batch, hipStream_t s);
-void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s);
+void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s,
+                 SyncHook hook = SyncHook{});   // hook: fp32 matrix-core kernels only (k_down_mfma)
 void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, bool accumulate = false,
                SyncHook hook = SyncHook{});   // hook: fp32 matrix-core kernels only (k_up_mfma)
 
@@ -474,7 +476,11 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                  hn_ctx::SideLane* side_lane = nullptr, bool defer_join = false);
 // make stream s wait for the hidden-state kernels of the previous unet_forward(..., defer_join = true) on this lane
 int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
-bool side_flags_apply(hn_ctx* ctx, hipStream_t s);   // would unet_forward(defer_join = true) on hn_step's single lane use the device flags?
+bool side_flags_apply(hn_ctx* ctx, hipStream_t s);
+// flag sync, the side stream's halves (hn_unet.hip): a one-wave kernel that holds stream s until *flag has reached epoch / a one-thread kernel that stores it
+int ensure_sync_words(hn_ctx* ctx);
+void launch_sync_gate(hn_ctx* ctx, const unsigned* flag, unsigned epoch, hipStream_t s);
+void launch_sync_signal(unsigned* flag, unsigned epoch, hipStream_t s);   // would unet_forward(defer_join = true) on hn_step's single lane use the device flags?
 int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, bool may_sync, hipStream_t* out);   // a stream that overlaps with every stream in refs
 
 // standalone sub-modules (hn_double_conv / hn_conv8x8 / hn_out_conv): fp32 vector kernels of hn_unet.hip on packed device weights

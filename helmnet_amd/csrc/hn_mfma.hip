@@ -1875,8 +1875,9 @@ struct DnCfg {
 // barrier gaps (56 -> 49 us at 256^2 x 32; one wavefront per SIMD cannot hide them by itself).
 template <int WX, bool ALL>
 __global__ __launch_bounds__(256, 2) void k_down_mfma(Src in, Dst out, const float* __restrict__ afr /*[8][8][64]*/,
-                                                       const float* __restrict__ bias, int Hin, int Win) {
+                                                       const float* __restrict__ bias, int Hin, int Win, SyncHook hook) {
     using C = DnCfg<WX>;
+    sync_hook_begin(hook);   // (flag sync of the training step: releases the hidden-state launch of the iteration on the side stream, hn_train.hip)
     __shared__ float lds[(ALL ? kFeat : 2) * C::PLANE_P];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2660,7 +2661,7 @@ int launch_dc8_bwd_aux(hn_ctx* ctx, const McBwd& a, const McBwdAux& x, int H, in
     return HN_OK;
 }
 
-void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s) {
+void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const float* bias, int Hin, int Win, int batch, hipStream_t s, SyncHook hook) {
     const int Wout = Win / 2, Hout = Hin / 2;
     // mixed-precision modes: levels 0 and 1 on the 16-bit matrix core; the 3-part split stays on the fp32 kernel
     // here (its 71 KB window and 288 MFMAs per wave measured 55 us against 48 us)
@@ -2674,14 +2675,14 @@ void launch_down(const hn_ctx* ctx, Src in, Dst out, const float* frag, const fl
     }
     // tile shape by level size: 64x16 outputs per block for the big levels, 32x16 at 64 < Wout... (more, shorter blocks
     // when there are few tiles: 17 us instead of 26 us at Wout = 64), all channels at once for the small ones
-    if (Wout > 64) hipLaunchKernelGGL((k_down_mfma<4, false>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+    if (Wout > 64) hipLaunchKernelGGL((k_down_mfma<4, false>), dim3(cdiv_(Wout, 64), cdiv_(Hout, 16), batch), dim3(256), 0, s, in, out, frag, bias, Hin, Win, hook);
     else if (Wout > 32) {
         const dim3 g(cdiv_(Wout, 32), cdiv_(Hout, 16), batch);
-        hipLaunchKernelGGL((k_down_mfma<2, false>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+        hipLaunchKernelGGL((k_down_mfma<2, false>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win, hook);
     }
     else {
         const dim3 g(cdiv_(Wout, 16), cdiv_(Hout, 16), batch);
-        hipLaunchKernelGGL((k_down_mfma<1, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win);
+        hipLaunchKernelGGL((k_down_mfma<1, true>), g, dim3(256), 0, s, in, out, frag, bias, Hin, Win, hook);
     }
 }
 

@@ -962,9 +962,11 @@ __global__ __launch_bounds__(256) void k_outc_bwd(const float* __restrict__ g_wf
 }
 
 // g = [g_in +] c * res   (the loss term of one unrolled iteration: d/d res of scale * mean(res^2))
-__global__ __launch_bounds__(256) void k_loss_seed(float* __restrict__ g, const float* __restrict__ res, float c, int has_in, long total) {
+__global__ __launch_bounds__(256) void k_loss_seed(float* __restrict__ g, const float* __restrict__ res, float c, int has_in, long total, SyncHook hook) {
+    sync_hook_begin(hook);   // (flag sync of the backward sweep: hn_train.hip, backward_step)
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i < total) g[i] = has_in ? fmaf(c, res[i], g[i]) : c * res[i];
+    sync_hook_end(hook);
 }
 // loss = scale * sum(sumsq) / count, summed in a fixed order by one wavefront
 __global__ void k_loss_finalize(const float* __restrict__ sumsq, int n, float scale_over_count, float* __restrict__ loss) {
@@ -1227,6 +1229,9 @@ struct Trainer {
     int wg_cap = 0;          // > 0: at most this many blocks per weight-gradient launch (HN_OPT_TRAIN_OVERLAP 2, see hn_train_grad)
     bool tile_small = false; // HN_OPT_TRAIN_FUSED bit 3 (A/B): the small levels' backward DoubleConvs on the tiled kernel too instead of the per-sample k_dc_small
     bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
+    unsigned fwd_epoch = 0;  // (flag sync: the running forward iteration's epoch)
+    bool flag_sync = false;  // HN_OPT_SIDE_SYNC (hn_internal.h: sync_flags): the side stream's releases and joins of the sweeps through device words carried by k_down_mfma / k_up_mfma /
+                             // k_loss_seed instead of event packets (words 64 / 96: forward release / join; 128 / 160: backward).  One lane, not under capture.
     bool side_state_fwd = false; // forward sweep: the hidden-state DoubleConvs of an iteration on the (then idle) weight-gradient stream, joined in front of the next iteration's conv_signal
     bool merge_state = true; // (with bits 2 and 4) the hidden-state DoubleConv's backward-data pass rides in the decoder's launch of the same level (k_dc_bwd_mfma_aux)
     bool mfma_bwd = true;    // HN_OPT_TRAIN_FUSED bit 4: the backward-data pass of the 8-channel DoubleConvs on the fp32 matrix core (k_dc_bwd_mfma_p) instead of the vector-pipe kernels
@@ -1410,7 +1415,9 @@ struct Trainer {
         for (int d = 0; d < depth; ++d) {
             const TSrc in_sig[3] = {feat(tape(t, W.o_x[d]), d), state_src(st_in, d), nosrc()};
             if ((rc = dc_fwd(L.sig[d], in_sig, tape(t, W.o_zsig[d]), featdst(tape(t, W.o_out[d]), d), d, &F3.sig[d])) != HN_OK) return rc;
-            launch_down(ctx, msrc(tape(t, W.o_out[d]), d), mdst(tape(t, W.o_x[d + 1]), d + 1), frag8(d, 0), w + L.down[d].b, side(d), side(d), B, s);
+            SyncHook hk;   // flag sync: conv_signal of the last level is complete when its `down` starts: the hidden-state launch may go
+            if (flag_sync && fused_state && side_state_fwd && d == depth - 1) { fwd_epoch = ++ctx->sync_epoch; hk.store = ctx->sync_flags + 64; hk.store_epoch = fwd_epoch; }
+            launch_down(ctx, msrc(tape(t, W.o_out[d]), d), mdst(tape(t, W.o_x[d + 1]), d + 1), frag8(d, 0), w + L.down[d].b, side(d), side(d), B, s, hk);
         }
         {   // new_state_d = conv_state_d(cat[out_d, state_d]) (architectures.py:248) for every level at once: nothing of this iteration
             // reads the new states, so the levels' DoubleConvs are two launches (first convolutions, second convolutions) instead of 2 depth
@@ -1425,7 +1432,11 @@ struct Trainer {
                 q2.job[d] = fwd_args(mid, dc.w2, dc.b2, dc.slope, state_dst(st_next, d), d);
                 qf.job[d] = DcSmallArgs{q1.job[d], q2.job[d]};
             }
-            if (fused_state && side_state_fwd) {   // ... beside the decoder: nothing reads the new states before the next iteration
+            if (fused_state && side_state_fwd && flag_sync) {   // ... beside the decoder, released and joined through device words (up_0 below polls)
+                launch_sync_gate(ctx, ctx->sync_flags + 64, fwd_epoch, W.wg_stream);
+                if ((rc = launch_dc_state_batch(ctx, false, qf, B, W.wg_stream)) != HN_OK) return rc;
+                launch_sync_signal(ctx->sync_flags + 96, fwd_epoch, W.wg_stream);
+            } else if (fused_state && side_state_fwd) {   // ... beside the decoder: nothing reads the new states before the next iteration
                 HN_HIP(ctx, hipEventRecord(W.st_fork, s));
                 HN_HIP(ctx, hipStreamWaitEvent(W.wg_stream, W.st_fork, 0));
                 if ((rc = launch_dc_state_batch(ctx, false, qf, B, W.wg_stream)) != HN_OK) return rc;
@@ -1443,7 +1454,9 @@ struct Trainer {
             if ((rc = dc_fwd(L.dec[depth], in, tape(t, W.o_zdec[depth]), featdst(tape(t, W.o_y[depth]), depth), depth, &F3.dec[depth])) != HN_OK) return rc;
         }
         for (int d = depth - 1; d >= 0; --d) {
-            launch_up(ctx, msrc(tape(t, W.o_y[d + 1]), d + 1), mdst(tape(t, W.o_u[d]), d), frag8(d, 2), w + L.up[d].b, side(d + 1), side(d + 1), B, s);
+            SyncHook hk;   // flag sync: the iteration's new hidden states are complete when up_0 is
+            if (flag_sync && fused_state && side_state_fwd && d == 0) { hk.wait = ctx->sync_flags + 96; hk.wait_epoch = fwd_epoch; hk.err = ctx->sync_err_dev; }
+            launch_up(ctx, msrc(tape(t, W.o_y[d + 1]), d + 1), mdst(tape(t, W.o_u[d]), d), frag8(d, 2), w + L.up[d].b, side(d + 1), side(d + 1), B, s, false, hk);
             const TSrc in[3] = {feat(tape(t, W.o_u[d]), d), feat(tape(t, W.o_out[d]), d), nosrc()};
             if ((rc = dc_fwd(L.dec[d], in, tape(t, W.o_zdec[d]), featdst(tape(t, W.o_y[d]), d), d, &F3.dec[d])) != HN_OK) return rc;
         }
@@ -1462,11 +1475,20 @@ struct Trainer {
         const long p0 = plane(0), tot2 = (long)B * 2 * p0;
         const int par = t & 1;
         if (overlap) {   // this iteration writes buffer set `par`: the weight gradients of iteration t + 2, which read it, must be done
-            if (W.wg_pending[par]) { HN_HIP(ctx, hipStreamWaitEvent(s, W.wg_done[par], 0)); W.wg_pending[par] = false; }
+            if (W.wg_pending[par] && !(flag_sync && W.wg_flag_epoch[par] != 0)) { HN_HIP(ctx, hipStreamWaitEvent(s, W.wg_done[par], 0)); W.wg_pending[par] = false; }
             select_gset(W, par);
         } else select_gset(W, 0);
+        // flag sync: the loss-seed kernel, first of the iteration's chain and no user of the buffer sets, carries both hand-overs -- its first thread stores the
+        // release word of iteration t + 1's weight-gradient launches (everything before it on the chain is complete) and, after its own work, waits for the
+        // join word of iteration t + 2's, whose buffer set this iteration overwrites
+        SyncHook hk;
+        if (flag_sync && W.bwd_release_epoch != 0) { hk.store = ctx->sync_flags + 128; hk.store_epoch = W.bwd_release_epoch; W.bwd_release_epoch = 0; }
+        if (flag_sync && overlap && W.wg_pending[par] && W.wg_flag_epoch[par] != 0) {
+            hk.wait = ctx->sync_flags + 160; hk.wait_epoch = W.wg_flag_epoch[par]; hk.err = ctx->sync_err_dev;
+            W.wg_flag_epoch[par] = 0; W.wg_pending[par] = false;
+        }
         // this iteration's loss term, then the adjoint of the residual operator: G = g_wf + L^H(g_res) + ksq * g_res
-        hipLaunchKernelGGL(k_loss_seed, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, s, W.g_res, res_out, loss_c, 1, tot2);
+        hipLaunchKernelGGL(k_loss_seed, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, s, W.g_res, res_out, loss_c, 1, tot2, hk);
         if ((rc = spec_adjoint(ctx, W.g_res, W.g_wf[cur_wf ^ 1], ksq, W.g_wf[cur_wf], B, s)) != HN_OK) return rc;
         cur_wf ^= 1;
         float* G = W.g_wf[cur_wf];   // d loss / d wf_next; wf_next = wf + d / 1e3, so it is also the direct part of d loss / d wf
@@ -1559,18 +1581,28 @@ struct Trainer {
         if (overlap && t == 0 && wg_cap > 0) {
             // the last launches have no chain left to hide behind: in line and at full width, behind the side stream's (they add to the same table rows)
             for (int k = 0; k < 2; ++k)
-                if (W.wg_pending[k]) { HN_HIP(ctx, hipStreamWaitEvent(s, W.wg_done[k], 0)); W.wg_pending[k] = false; }
+                if (W.wg_pending[k]) { HN_HIP(ctx, hipStreamWaitEvent(s, W.wg_done[k], 0)); W.wg_pending[k] = false; W.wg_flag_epoch[k] = 0; }
             const int cap = wg_cap;
             wg_cap = 0;
             rc = flush_wgrads(t, s);
             wg_cap = cap;
             if (rc != HN_OK) return rc;
+        } else if (overlap && flag_sync && t > 0) {   // ... released by the NEXT iteration's loss-seed kernel (t - 1 exists), joined through a device word or, at the end, the event
+            const unsigned e = ++ctx->sync_epoch;
+            W.bwd_release_epoch = e;
+            launch_sync_gate(ctx, ctx->sync_flags + 128, e, W.wg_stream);
+            if ((rc = flush_wgrads(t, W.wg_stream)) != HN_OK) return rc;
+            launch_sync_signal(ctx->sync_flags + 160, e, W.wg_stream);
+            HN_HIP(ctx, hipEventRecord(W.wg_done[par], W.wg_stream));
+            W.wg_pending[par] = true;
+            W.wg_flag_epoch[par] = e;
         } else if (overlap) {   // the filed weight-gradient jobs: three launches on the side stream, beside the backward chain of iteration t - 1
             HN_HIP(ctx, hipEventRecord(W.wg_ready[par], s));
             HN_HIP(ctx, hipStreamWaitEvent(W.wg_stream, W.wg_ready[par], 0));
             if ((rc = flush_wgrads(t, W.wg_stream)) != HN_OK) return rc;
             HN_HIP(ctx, hipEventRecord(W.wg_done[par], W.wg_stream));
             W.wg_pending[par] = true;
+            W.wg_flag_epoch[par] = 0;
         } else if ((rc = flush_wgrads(t, s)) != HN_OK) return rc;
         HN_HIP(ctx, hipGetLastError());
         return HN_OK;
@@ -1783,6 +1815,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     (void)hipStreamIsCapturing(s, &cap);
     const bool capturing = cap == hipStreamCaptureStatusActive;
+    if (!capturing && ctx->opt_side_sync == 1 && (rc = ensure_sync_words(ctx)) != HN_OK) return rc;
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
         // set 0 of the pinned job tables belongs to CAPTURED calls (their graph copies the tables out of it at every replay, so eager calls
@@ -1818,14 +1851,20 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     for (int l = 0; l < lanes; ++l) {
         const long px = (long)lane_nb[l] * n * n;
         const int mode = ctx->opt_train_overlap;
-        tr[l].overlap = mode == 1 || (mode == 2 && px >= 200000);
+        tr[l].flag_sync = ctx->opt_side_sync == 1 && !capturing && lanes == 1 && ctx->sync_flags != nullptr;   // (hn_internal.h: sync_flags; a captured step keeps events)
+        // with device-word hand-overs the forks cost the chain nothing and the window below opens at any size [measured, r5: 96^2 x 8 5.10 -> 4.55 ms, x 4 4.60 -> 4.18,
+        // 64^2 x 32 5.19 -> 4.49, 64^2 x 8 4.13 -> 3.69, 48^2 x 8 4.47 -> 4.07; 128^2 x 32 and 256^2 x 8 unchanged]
+        const long px_min = tr[l].flag_sync ? 0 : 200000;
+        tr[l].overlap = mode == 1 || (mode == 2 && px >= px_min);
         // ... and the forward sweep's hidden-state launch on that (then idle) stream beside the decoder: a fork whose join comes an iteration later.  [measured,
         // profiles/r4_side_state_fwd.txt] 7.36 -> 7.19 ms at 96^2 x 32, -2 % at 128^2 x 32 / 256^2 x 8 / 96^2 x 128; +7 % at 96^2 x 8 and 64^2 x 32, where the event packets cost
         // more than the 24 us kernel they take off the chain -- hence the same window
-        tr[l].side_state_fwd = mode == 2 && px >= 200000;
+        tr[l].side_state_fwd = mode == 2 && px >= px_min;
 #ifndef HN_WG_CAP_DIV
 #define HN_WG_CAP_DIV 350   // pixels per weight-gradient block of the capped launches (tools/build_variant.sh ... -DHN_WG_CAP_DIV=...)
 #endif
+        // (the cap keeps its window whatever the hand-overs: it changes the order in which a weight gradient's partial sums are added, and a captured step -- events --
+        // must reproduce the eager one's bits)
         tr[l].wg_cap = mode == 2 && px >= 200000 && px < 1000000 ? (int)(px / HN_WG_CAP_DIV < 512 ? 512 : px / HN_WG_CAP_DIV) : 0;
     }
     const size_t fwf = (size_t)batch * p2, fst = (size_t)batch * pst;

@@ -656,6 +656,11 @@ int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s) {
     return HN_OK;
 }
 
+void launch_sync_gate(hn_ctx* ctx, const unsigned* flag, unsigned epoch, hipStream_t s) {
+    hipLaunchKernelGGL(k_sync_gate, dim3(1), dim3(64), 0, s, flag, epoch, ctx->sync_err_dev);
+}
+void launch_sync_signal(unsigned* flag, unsigned epoch, hipStream_t s) { hipLaunchKernelGGL(k_sync_signal, dim3(1), dim3(64), 0, s, flag, epoch); }
+
 bool side_flags_apply(hn_ctx* ctx, hipStream_t s) {
     if (ctx->opt_lanes != 1 || ctx->opt_side_stream != 1 || ctx->opt_side_sync == 0 || ctx->sync_flags == nullptr) return false;
     if (ctx->precision != HN_PREC_FP32) return false;   // (the hooks live in k_deep32 / k_up_mfma)

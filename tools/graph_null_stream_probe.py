@@ -1,0 +1,71 @@
+"""A captured training step (torch.cuda.graph around hn_train_grad) replays garbage after ANY library call on the legacy default stream.
+
+    python tools/graph_null_stream_probe.py N B [side|null] [refuse|norefuse] [null|side2|side|fwd|resid|resid_side2|torch|none]
+
+Sequence: eager step on a created stream, capture on it, two replays (equal to the eager gradient), then ONE intervening call (5th argument), then a replay.
+[seen, r5, 64 4 side norefuse ...] null (eager hn_train_grad on the default stream), fwd (solver.forward), resid (hn_residual): replay garbage / NaN in 3 of 4 runs;
+side2 / side (eager step on another / the same created stream), torch (torch kernels on the default stream), none: replay exact.  The round-4 library behaves the same.
+"""
+import sys, os, numpy as np, torch
+sys.path.insert(0, "/root/repo")
+from helmnet_amd import IterativeSolver
+from helmnet_amd.engine import pack_weights
+from helmnet_amd.phantoms import ring_sos_batch
+n, b = int(sys.argv[1]), int(sys.argv[2])
+with np.load("/root/repo/tests/golden/jcp_weights.npz") as z: weights = {k: torch.from_numpy(z[k]) for k in z.files}
+s = IterativeSolver.from_exported_weights(); s.to("cuda:0")
+s.set_domain_size(n, source_location=[n - 14, n // 2])
+eng = s.engine()
+sos = torch.from_numpy(ring_sos_batch(n, b, seed=8)).cuda()
+out = s.forward(sos, num_iterations=3, return_wavefields=True, return_states=True)
+args = [out["wavefields"][-1].contiguous(), out["residuals"][-1].contiguous(), out["states"][-1].contiguous(),
+        ((1.0 / sos) ** 2).contiguous(), s.source.detach().repeat(b, 1, 1, 1).contiguous()]
+blob = torch.from_numpy(pack_weights(weights)).cuda()
+g = torch.zeros_like(blob)
+side = torch.cuda.Stream()
+with torch.cuda.stream(side):
+    eager = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+    torch.cuda.synchronize()
+    want = g.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        captured = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+    for i in range(2):
+        g.zero_(); captured["loss"].zero_(); graph.replay(); torch.cuda.synchronize()
+        print("replay", i, bool(torch.equal(g, want)), float((g - want).abs().max()))
+how = sys.argv[5] if len(sys.argv) > 5 else "null"
+if how == "null":
+    again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+elif how == "side2":
+    with torch.cuda.stream(torch.cuda.Stream()):
+        again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+elif how == "side":
+    with torch.cuda.stream(side):
+        again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+elif how == "fwd":
+    out2 = s.forward(sos, num_iterations=3)
+elif how == "torch":
+    x = torch.randn(1 << 22, device="cuda"); y = (x * 2).sum(); z = torch.fft.fft(x)
+elif how == "resid":
+    r = eng.residual(args[0], args[3][:, :1] if args[3].dim() == 4 else args[3], s.source.detach().contiguous())
+elif how == "resid_side2":
+    with torch.cuda.stream(torch.cuda.Stream()):
+        r = eng.residual(args[0], args[3], s.source.detach().contiguous())
+elif how == "outconv":
+    xx = torch.randn(2, 8, 64, 64, device="cuda"); r = eng.lib and None
+elif how == "none":
+    pass
+torch.cuda.synchronize()
+print("again", how, bool(torch.equal(g, want)), float((g - want).abs().max()))
+if len(sys.argv) <= 4:
+    try:
+        eng.train_grad(blob, *args, 25, 1e4, grad=g)
+    except Exception as e:
+        print("refused")
+mode = sys.argv[3] if len(sys.argv) > 3 else "null"
+if mode == "side":
+    with torch.cuda.stream(side):
+        graph.replay(); torch.cuda.synchronize()
+else:
+    graph.replay(); torch.cuda.synchronize()
+print("replay after on", mode, bool(torch.equal(g, want)), float((g - want).abs().max()))
