@@ -583,8 +583,7 @@ def test_training_step_can_be_captured_in_a_hip_graph(solver, weights, n, b):
             assert torch.equal(g, want) and abs(float(captured["loss"]) - float(want_loss)) <= 1e-6 * float(want_loss)
     # and the eager path still works afterwards.  (On the stream of the capture: [seen, r5, tools/graph_null_stream_probe.py] ANY call of the library on the legacy
     # default stream between capture and replay -- hn_residual is enough, eager work on another created stream or torch's own kernels on the default stream are
-    # not -- leaves the replay with garbage, with the round-4 library as with this one: the graph holds kernels that use scratch memory, and so do the
-    # eager ones.  INTEGRATION.md 5: keep a captured step and the library's eager calls off the legacy default stream.)
+    # not -- leaves the replay with garbage, with the round-4 library as with this one (a runtime interaction, not resolved).  INTEGRATION.md 5: keep a captured step and the library's eager calls off the legacy default stream.)
     with torch.cuda.stream(side):
         again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
         torch.cuda.synchronize()

@@ -1,10 +1,12 @@
 """A captured training step (torch.cuda.graph around hn_train_grad) replays garbage after ANY library call on the legacy default stream.
 
-    python tools/graph_null_stream_probe.py N B [side|null] [refuse|norefuse] [null|side2|side|fwd|resid|resid_side2|torch|none]
+    python tools/graph_null_stream_probe.py N B [side|null] [refuse|norefuse] [null|side2|side|fwd|resid|resid_side2|rmse|rmse_side2|torch|none]
 
 Sequence: eager step on a created stream, capture on it, two replays (equal to the eager gradient), then ONE intervening call (5th argument), then a replay.
 [seen, r5, 64 4 side norefuse ...] null (eager hn_train_grad on the default stream), fwd (solver.forward), resid (hn_residual): replay garbage / NaN in 3 of 4 runs;
 side2 / side (eager step on another / the same created stream), torch (torch kernels on the default stream), none: replay exact.  The round-4 library behaves the same.
+rmse (hn_rmse on the default stream: one hipMemsetAsync and two scratch-free kernels) breaks the replay too; rmse_side2 / resid_side2 (the same calls on a created stream) do not:
+it is the library launching ANYTHING on the legacy default stream, not a particular kernel or its scratch memory.
 """
 import sys, os, numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -53,6 +55,11 @@ elif how == "resid_side2":
         r = eng.residual(args[0], args[3], s.source.detach().contiguous())
 elif how == "outconv":
     xx = torch.randn(2, 8, 64, 64, device="cuda"); r = eng.lib and None
+elif how == "rmse":
+    r = eng.rmse(args[1])
+elif how == "rmse_side2":
+    with torch.cuda.stream(torch.cuda.Stream()):
+        r = eng.rmse(args[1])
 elif how == "none":
     pass
 torch.cuda.synchronize()
