@@ -143,6 +143,30 @@ __global__ void k_rmse_finalize(float* __restrict__ v, int count, float inv_n) {
 }
 
 }  // namespace
+// Zero `bytes` (a multiple of 4) at p on stream s with a kernel of this library instead of hipMemsetAsync.  [seen, r5, tools/graph_null_stream_probe.py] a
+// hipMemsetAsync on the legacy default stream -- from anyone in the process -- between the capture of a graph that holds memset nodes and its replay leaves the
+// replay's memsets zeroing something else (a captured training step then adds its weight gradients onto garbage): a captured hn_train_grad holds no memset
+// node, and the library's eager calls do not put memsets on the caller's stream either.
+namespace {
+__global__ void k_zero(uint4* __restrict__ p16, size_t n16, unsigned* __restrict__ p4, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (size_t i = i0; i < n16; i += stride) p16[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = i0; i < n4; i += stride) p4[i] = 0u;
+}
+}  // namespace
+int zero_async(hn_ctx* ctx, void* p, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return HN_OK;
+    if (bytes % 4 != 0 || reinterpret_cast<uintptr_t>(p) % 4 != 0) return fail(ctx, HN_ERR_ARG, "internal: zero_async needs 4-byte granularity");
+    const bool a16 = reinterpret_cast<uintptr_t>(p) % 16 == 0;
+    const size_t n16 = a16 ? bytes / 16 : 0, n4 = (bytes - 16 * n16) / 4;
+    const size_t work = n16 > n4 ? n16 : n4;
+    const unsigned blocks = (unsigned)((work + 255) / 256 < 4096 ? (work + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_zero, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4*>(p), n16, reinterpret_cast<unsigned*>(reinterpret_cast<char*>(p) + 16 * n16), n4);
+    HN_HIP(ctx, hipGetLastError());
+    return HN_OK;
+}
+
 int ensure_sync_words(hn_ctx* ctx) {   // flag sync (hn_internal.h): the device words and a host-visible error word, for the context's lifetime
     if (ctx->sync_flags != nullptr) return HN_OK;
     HN_HIP(ctx, hipMalloc((void**)&ctx->sync_flags, sizeof(unsigned) * 256));
@@ -613,7 +637,7 @@ int hn_rmse(hn_ctx* ctx, const float* res, float* rmse, int batch, void* stream)
     DeviceGuard guard(ctx);
     hipStream_t s = (hipStream_t)stream;
     const long per = 2L * ctx->tab.n * ctx->tab.n;
-    HN_HIP(ctx, hipMemsetAsync(rmse, 0, sizeof(float) * batch, s));
+    if (int rcz = zero_async(ctx, rmse, sizeof(float) * batch, s); rcz != HN_OK) return rcz;
     hipLaunchKernelGGL(k_sumsq, dim3(32, batch), dim3(256), 0, s, res, rmse, per);
     hipLaunchKernelGGL(k_rmse_finalize, dim3((batch + 255) / 256), dim3(256), 0, s, rmse, batch, 1.0f / (float)per);
     HN_HIP(ctx, hipGetLastError());
@@ -919,8 +943,8 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     (void)hipStreamIsCapturing(s, &cap_status);
     if ((rc = ensure_step_resources(ctx, ns, ctx->opt_side_stream != 0, s, cap_status == hipStreamCaptureStatusNone)) != HN_OK) return rc;
     if (rmse_hist) {
-        HN_HIP(ctx, hipMemsetAsync(rmse_hist, 0, sizeof(float) * (size_t)n_iter * batch, s));
-        HN_HIP(ctx, hipMemsetAsync(ctx->it_counter, 0, 8 * sizeof(int), s));
+        if ((rc = zero_async(ctx, rmse_hist, sizeof(float) * (size_t)n_iter * batch, s)) != HN_OK) return rc;
+        if ((rc = zero_async(ctx, ctx->it_counter, 8 * sizeof(int), s)) != HN_OK) return rc;
     }
     const StepArgs a{wf, res, states, k_sq, src, src_batch, batch, rmse_hist};
     const size_t fb_all = sizeof(float) * (size_t)batch * 2 * plane, sb_all = sizeof(float) * (size_t)batch * kState * L;

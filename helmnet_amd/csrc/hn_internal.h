@@ -479,6 +479,7 @@ int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
 bool side_flags_apply(hn_ctx* ctx, hipStream_t s);
 // flag sync, the side stream's halves (hn_unet.hip): a one-wave kernel that holds stream s until *flag has reached epoch / a one-thread kernel that stores it
 int ensure_sync_words(hn_ctx* ctx);
+int zero_async(hn_ctx* ctx, void* p, size_t bytes, hipStream_t s);   // (hn_api.hip: a kernel of this library, never hipMemsetAsync, on a caller's stream)
 void launch_sync_gate(hn_ctx* ctx, const unsigned* flag, unsigned epoch, hipStream_t s);
 void launch_sync_signal(unsigned* flag, unsigned epoch, hipStream_t s);   // would unet_forward(defer_join = true) on hn_step's single lane use the device flags?
 int side_stream_for(hn_ctx* ctx, int slot, const hipStream_t* refs, int nrefs, bool may_sync, hipStream_t* out);   // a stream that overlaps with every stream in refs

@@ -1911,7 +1911,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
             }
             hipLaunchKernelGGL(k_pack_frag3, dim3(cdiv(16 * 192, 256), fj.n), dim3(256), 0, s, weights, W.f3, fj);
         }
-        HN_HIP(ctx, hipMemsetAsync(W.sumsq, 0, sizeof(float) * (size_t)n_unroll * batch, s));
+        if ((rc = zero_async(ctx, W.sumsq, sizeof(float) * (size_t)n_unroll * batch, s)) != HN_OK) return rc;
     }
     if (lanes == 2) {   // the second lane starts behind the packed weights (and whatever the caller's stream held before)
         HN_HIP(ctx, hipEventRecord(ctx->train_fork, s));
@@ -1919,8 +1919,8 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     }
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
-        HN_HIP(ctx, hipMemsetAsync(W.part, 0, sizeof(float) * W.part_floats, ls[l]));
-        HN_HIP(ctx, hipMemsetAsync(W.slope_part, 0, sizeof(double) * W.slope_stride * (3 * depth + 2), ls[l]));
+        if ((rc = zero_async(ctx, W.part, sizeof(float) * W.part_floats, ls[l])) != HN_OK) return rc;
+        if ((rc = zero_async(ctx, W.slope_part, sizeof(double) * W.slope_stride * (3 * depth + 2), ls[l])) != HN_OK) return rc;
     }
     // per-lane views of the caller's tensors: sample b0 of a [batch][...] tensor
     auto in_wf = [&](int t, int l) { return (t == 0 ? wf : wf_hist + (size_t)(t - 1) * fwf) + (size_t)lane_b0[l] * p2; };
@@ -1961,9 +1961,9 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
     int cur_wf[2] = {0, 0}, cur_st[2] = {0, 0};
     for (int l = 0; l < lanes; ++l) {
         auto& W = *ws[l];
-        HN_HIP(ctx, hipMemsetAsync(W.g_wf[0], 0, sizeof(float) * (size_t)lane_nb[l] * p2, ls[l]));
-        HN_HIP(ctx, hipMemsetAsync(W.g_res, 0, sizeof(float) * (size_t)lane_nb[l] * p2, ls[l]));
-        HN_HIP(ctx, hipMemsetAsync(W.g_st[0], 0, sizeof(float) * (size_t)lane_nb[l] * pst, ls[l]));
+        if ((rc = zero_async(ctx, W.g_wf[0], sizeof(float) * (size_t)lane_nb[l] * p2, ls[l])) != HN_OK) return rc;
+        if ((rc = zero_async(ctx, W.g_res, sizeof(float) * (size_t)lane_nb[l] * p2, ls[l])) != HN_OK) return rc;
+        if ((rc = zero_async(ctx, W.g_st[0], sizeof(float) * (size_t)lane_nb[l] * pst, ls[l])) != HN_OK) return rc;
     }
     const double count = (double)n_unroll * batch * 2.0 * n * n;
     const float loss_c = (float)(2.0 * (double)loss_scale / count);

@@ -581,19 +581,21 @@ def test_training_step_can_be_captured_in_a_hip_graph(solver, weights, n, b):
             torch.cuda.synchronize()
             # (the loss is read off sums the spectral kernel accumulates with float atomics: its last bit is not reproducible once a sample has several workgroups)
             assert torch.equal(g, want) and abs(float(captured["loss"]) - float(want_loss)) <= 1e-6 * float(want_loss)
-    # and the eager path still works afterwards.  (On the stream of the capture: [seen, r5, tools/graph_null_stream_probe.py] ANY call of the library on the legacy
-    # default stream between capture and replay -- hn_residual is enough, eager work on another created stream or torch's own kernels on the default stream are
-    # not -- leaves the replay with garbage, with the round-4 library as with this one (a runtime interaction, not resolved).  INTEGRATION.md 5: keep a captured step and the library's eager calls off the legacy default stream.)
-    with torch.cuda.stream(side):
-        again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
-        torch.cuda.synchronize()
-        assert torch.equal(g, want) and abs(float(again["loss"]) - float(want_loss)) <= 1e-6 * float(want_loss)
-        # ... but an eager call that would have to GROW the workspace is refused while a captured step may still be replayed (its graph points into the
-        # workspace), until hn_train_reserve says the graph is gone
-        with pytest.raises(Exception, match="captured"):
-            eng.train_grad(blob, *args, 25, 1e4, grad=g)
-        graph.replay(); torch.cuda.synchronize()
-        assert torch.equal(g, want)
+    # and the eager path still works afterwards -- on the legacy default stream, deliberately: [seen, r5, tools/graph_null_stream_probe.py] a hipMemsetAsync on that
+    # stream (from anyone in the process) between capture and replay leaves a replay's MEMSET NODES zeroing something else, and the step then adds its weight
+    # gradients onto garbage; the library zeroes with a kernel of its own (zero_async), so a captured step holds no memset node and its eager calls issue none
+    again = eng.train_grad(blob, *args, 3, 1e4, grad=g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want) and abs(float(again["loss"]) - float(want_loss)) <= 1e-6 * float(want_loss)
+    import ctypes
+    x = torch.ones(1024, device=DEV)
+    assert ctypes.CDLL("libamdhip64.so").hipMemsetAsync(ctypes.c_void_p(x.data_ptr()), 0, 4096, ctypes.c_void_p(0)) == 0   # (the runtime's own memset, on the default stream)
+    # ... but an eager call that would have to GROW the workspace is refused while a captured step may still be replayed (its graph points into the
+    # workspace), until hn_train_reserve says the graph is gone
+    with pytest.raises(Exception, match="captured"):
+        eng.train_grad(blob, *args, 25, 1e4, grad=g)
+    graph.replay(); torch.cuda.synchronize()
+    assert torch.equal(g, want)
     del graph
     eng.train_reserve(b, 25)
     more = eng.train_grad(blob, *args, 25, 1e4, grad=g)

@@ -1,4 +1,4 @@
-"""A captured training step (torch.cuda.graph around hn_train_grad) replays garbage after ANY library call on the legacy default stream.
+"""(Fixed in r5 by zero_async: the numbers below are the library BEFORE it.)  A captured training step (torch.cuda.graph around hn_train_grad) replays garbage after ANY library call on the legacy default stream.
 
     python tools/graph_null_stream_probe.py N B [side|null] [refuse|norefuse] [null|side2|side|fwd|resid|resid_side2|rmse|rmse_side2|torch|none]
 
@@ -6,7 +6,8 @@ Sequence: eager step on a created stream, capture on it, two replays (equal to t
 [seen, r5, 64 4 side norefuse ...] null (eager hn_train_grad on the default stream), fwd (solver.forward), resid (hn_residual): replay garbage / NaN in 3 of 4 runs;
 side2 / side (eager step on another / the same created stream), torch (torch kernels on the default stream), none: replay exact.  The round-4 library behaves the same.
 rmse (hn_rmse on the default stream: one hipMemsetAsync and two scratch-free kernels) breaks the replay too; rmse_side2 / resid_side2 (the same calls on a created stream) do not:
-it is the library launching ANYTHING on the legacy default stream, not a particular kernel or its scratch memory.
+it is not a particular kernel or its scratch memory.  hipmemset (the HIP runtime's hipMemsetAsync on the default stream, no library of ours involved) breaks it as well: the
+graph's memset nodes are the victims.  With zero_async (no memset nodes in the graph, no hipMemsetAsync in the eager calls) every variant replays exactly.
 """
 import sys, os, numpy as np, torch
 sys.path.insert(0, "/root/repo")
@@ -60,6 +61,11 @@ elif how == "rmse":
 elif how == "rmse_side2":
     with torch.cuda.stream(torch.cuda.Stream()):
         r = eng.rmse(args[1])
+elif how == "hipmemset":     # no library of ours involved: the HIP runtime called directly on the legacy default stream
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    x = torch.ones(1024, device="cuda")
+    print("hipMemsetAsync(default stream) ->", hip.hipMemsetAsync(ctypes.c_void_p(x.data_ptr()), 0, 4096, ctypes.c_void_p(0)))
 elif how == "none":
     pass
 torch.cuda.synchronize()
