@@ -168,12 +168,30 @@ int zero_async(hn_ctx* ctx, void* p, size_t bytes, hipStream_t s) {
 }
 
 int ensure_sync_words(hn_ctx* ctx) {   // flag sync (hn_internal.h): the device words and a host-visible error word, for the context's lifetime
-    if (ctx->sync_flags != nullptr) return HN_OK;
-    HN_HIP(ctx, hipMalloc((void**)&ctx->sync_flags, sizeof(unsigned) * 256));
-    HN_HIP(ctx, hipMemset(ctx->sync_flags, 0, sizeof(unsigned) * 256));
-    HN_HIP(ctx, hipHostMalloc((void**)&ctx->sync_err, sizeof(int), hipHostMallocMapped));
-    *ctx->sync_err = 0;
-    HN_HIP(ctx, hipHostGetDevicePointer((void**)&ctx->sync_err_dev, ctx->sync_err, 0));
+    if (ctx->sync_flags != nullptr && ctx->sync_err_dev != nullptr) return HN_OK;   // (both or neither: a half-built set is rebuilt, never used)
+    if (ctx->sync_err == nullptr) {
+        HN_HIP(ctx, hipHostMalloc((void**)&ctx->sync_err, sizeof(int), hipHostMallocMapped));
+        *ctx->sync_err = 0;
+    }
+    int* dev = nullptr;
+    HN_HIP(ctx, hipHostGetDevicePointer((void**)&dev, ctx->sync_err, 0));
+    if (ctx->sync_flags == nullptr) {
+        unsigned* words = nullptr;
+        HN_HIP(ctx, hipMalloc((void**)&words, sizeof(unsigned) * 256));
+        if (hipMemset(words, 0, sizeof(unsigned) * 256) != hipSuccess) { (void)hipFree(words); return fail(ctx, HN_ERR_HIP, "hipMemset of the sync words failed"); }
+        ctx->sync_flags = words;
+    }
+    ctx->sync_err_dev = dev;   // last: every user tests sync_flags AND takes sync_err_dev as given
+    return HN_OK;
+}
+
+int check_async(hn_ctx* ctx, const char* who) {
+    if (ctx->sync_err != nullptr && *ctx->sync_err != 0)
+        return fail(ctx, HN_ERR_STATE, "%s: a device-side wait gave up (%s): results since then are incomplete -- destroy the context "
+                                       "(HN_SIDE_SYNC=0 / HN_DC_PAIR=0 select event packets / separate launches instead of device flags)", who,
+                    *ctx->sync_err == 2 ? "a conv_signal_0 tile of the merged level-0 launch never saw its inc tiles: out-of-order workgroup dispatch?"
+                    : *ctx->sync_err == 3 ? "a workgroup of the multi-workgroup deep kernel never saw its neighbour's rows"
+                                          : "a side-stream flag did not arrive within 2 s");
     return HN_OK;
 }
 
@@ -223,7 +241,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_EXP_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}, {"HN_STATE_KERNEL", HN_OPT_STATE_KERNEL}};
+                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}, {"HN_STATE_KERNEL", HN_OPT_STATE_KERNEL}, {"HN_HIST_COPY", HN_OPT_HIST_COPY}};
     // Counter collection (rocprofv3 --pmc, rocprof -i / ROCP_METRICS) runs ONE kernel at a time across all queues, in an order of the tool's choosing: a kernel that
     // waits for a word another queue's kernel stores may then be the one that runs -- the bounded wait gives up after 2 s and hn_step fails [seen, r5].  Under such
     // a tool the hand-overs stay event packets unless HN_SIDE_SYNC says otherwise (the merged level-0 launch is ONE kernel and is not affected).
@@ -289,6 +307,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_STATE_KERNEL:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_STATE_KERNEL must be 0 or 1 (got %d)", value);
             ctx->opt_state_kernel = value;
+            break;
+        case HN_OPT_HIST_COPY:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_HIST_COPY must be 0 or 1 (got %d)", value);
+            ctx->opt_hist_copy = value;
             break;
         case HN_OPT_SIDE_SYNC:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_SIDE_SYNC must be 0 or 1 (got %d)", value);
@@ -835,17 +857,25 @@ int ensure_step_resources(hn_ctx* ctx, int ns, bool want_side, hipStream_t calle
 // One solver iteration of samples [b0, b0 + nb) on stream sj (hybridnet.py:558-584): the UNet update with the
 // wavefield updated in place by its last kernel, then the residual of the new wavefield.  `parity` selects the
 // direction of the hidden-state ping-pong (0: caller's buffer -> library buffer).
-int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, int lane, hipStream_t sj, hipEvent_t stagger, bool defer_join = false) {
+// io (nullable: everything in place in a.wf / a.res): where this iteration reads the old wavefield / residual and where it writes the new ones --
+// hn_step walks the caller's history slots with it instead of copying into them (the reference keeps every residual for free: it appends tensors,
+// hybridnet.py:676-697).  Pointers are whole-batch bases like a.wf.
+struct IterIo { const float* wf_in; float* wf_out; const float* res_in; float* res_out; };
+int one_iteration(hn_ctx* ctx, const StepArgs& a, int parity, int b0, int nb, int lane, hipStream_t sj, hipEvent_t stagger, bool defer_join = false,
+                  const IterIo* io = nullptr) {
     const long plane = (long)ctx->tab.n * ctx->tab.n, L = ctx->state_len;
-    float* wf_j = a.wf + (size_t)b0 * 2 * plane;
-    float* res_j = a.res + (size_t)b0 * 2 * plane;
+    const size_t fo = (size_t)b0 * 2 * plane;
+    float* wf_j = (io ? io->wf_out : a.wf) + fo;
+    float* res_j = (io ? io->res_out : a.res) + fo;
+    const float* wf_in = (io ? io->wf_in : a.wf) + fo;
+    const float* res_in = (io ? io->res_in : a.res) + fo;
     float* st_user = a.states + (size_t)b0 * kState * L;
     float* st_tmp = ctx->st_tmp + (size_t)b0 * kState * L;
-    const Src s_wf{wf_j, 2 * plane, plane, 1.f};
-    const Src s_res{res_j, 2 * plane, plane, 1e3f};      // 1e3 * residual (hybridnet.py:566)
+    const Src s_wf{wf_in, 2 * plane, plane, 1.f};
+    const Src s_res{res_in, 2 * plane, plane, 1e3f};     // 1e3 * residual (hybridnet.py:566)
     const Src s_sig{ctx->tab.sigmas, 0, plane, 1.f};     // sigmas.repeat(B) without the copy
     int rc = unet_forward(ctx, s_wf, s_res, s_sig, parity ? st_tmp : st_user, parity ? st_user : st_tmp, nullptr, wf_j, nb, sj, b0,
-                          stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr, defer_join);
+                          stagger, ctx->opt_side_stream ? &ctx->side[lane] : nullptr, defer_join, wf_in != wf_j ? wf_in : nullptr);
     if (rc != HN_OK) return rc;
     const float* src_j = a.src_batch == 1 ? a.src : a.src + (size_t)b0 * 2 * plane;
     HN_REP(KID_SPEC_PAIR)
@@ -931,9 +961,7 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
     DeviceGuard guard(ctx);
     if ((rc = hn_reserve(ctx, batch)) != HN_OK) return rc;
     if (n_iter == 0) return HN_OK;
-    if (ctx->sync_err != nullptr && *ctx->sync_err != 0)
-        return fail(ctx, HN_ERR_STATE, "hn_step: a device-side wait of an earlier call gave up after 2 s (side-stream flag never arrived): the hidden states of that "
-                                       "call are incomplete; destroy the context (HN_SIDE_SYNC=0 selects event packets instead of device flags)");
+    if ((rc = check_async(ctx, "hn_step (an earlier call)")) != HN_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
     const long plane = (long)ctx->tab.n * ctx->tab.n;
     const long L = ctx->state_len;
@@ -965,6 +993,8 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
         // of event packets.  Its gate kernel spins from the moment the side stream is free, so the side stream first waits for the caller's stream to get
         // here (one event per CALL), and the last iteration joins with an event as before (the caller's stream must own the final states).
         const bool flag_sync = g == nullptr && n_iter > 1 && !st_hist && side_flags_apply(ctx, s);
+        // histories without copies: every iteration launched kernel by kernel (no graph) and the slots not aliasing the caller's own buffers
+        const bool zero_copy = g == nullptr && ctx->opt_hist_copy == 0 && (res_hist == nullptr || res_hist != res) && (wf_hist == nullptr || wf_hist != wf);
         if (flag_sync) {
             HN_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
             HN_HIP(ctx, hipStreamWaitEvent(ctx->side[0].stream, ctx->ev_fork, 0));
@@ -990,12 +1020,26 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
                 // the new hidden states are first needed by the next iteration's conv_signal_0: the side-stream join moves there,
                 // unless something reads them right away (a state history) or this is the last iteration
                 const bool defer = (ctx->opt_defer_join || flag_sync) && ctx->opt_side_stream && !st_hist && it + 1 < n_iter && g == nullptr;
-                if ((rc = one_iteration(ctx, a, it & 1, 0, batch, 0, s, nullptr, defer)) != HN_OK) return rc;
+                // zero-copy histories (kernel-by-kernel launches only: a captured iteration has its buffers baked in): iteration `it` reads slot it - 1
+                // (the caller's wf / res for it = 0) and writes slot it; the caller's buffers receive the last slot once, behind the loop
+                const size_t slot = (size_t)batch * 2 * plane;
+                const IterIo io{wf_hist ? (it ? wf_hist + (it - 1) * slot : wf) : wf, wf_hist ? wf_hist + it * slot : wf,
+                                res_hist ? (it ? res_hist + (it - 1) * slot : res) : res, res_hist ? res_hist + it * slot : res};
+                if ((rc = one_iteration(ctx, a, it & 1, 0, batch, 0, s, nullptr, defer, (zero_copy && hist) ? &io : nullptr)) != HN_OK) return rc;
                 ++ctx->eager_iterations;
+                if (zero_copy) {
+                    if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + (size_t)it * batch * kState * L, (it & 1) ? states : ctx->st_tmp, sb_all, hipMemcpyDeviceToDevice, s));
+                    continue;
+                }
             }
             if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res_hist + (size_t)it * batch * 2 * plane, res, fb_all, hipMemcpyDeviceToDevice, s));
             if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf_hist + (size_t)it * batch * 2 * plane, wf, fb_all, hipMemcpyDeviceToDevice, s));
             if (st_hist) HN_HIP(ctx, hipMemcpyAsync(st_hist + (size_t)it * batch * kState * L, (it & 1) ? states : ctx->st_tmp, sb_all, hipMemcpyDeviceToDevice, s));
+        }
+        if (zero_copy) {   // the caller's buffers hold the final wavefield / residual as they would after n in-place iterations: one copy per CALL
+            const size_t last = (size_t)(n_iter - 1) * batch * 2 * plane;
+            if (res_hist) HN_HIP(ctx, hipMemcpyAsync(res, res_hist + last, fb_all, hipMemcpyDeviceToDevice, s));
+            if (wf_hist) HN_HIP(ctx, hipMemcpyAsync(wf, wf_hist + last, fb_all, hipMemcpyDeviceToDevice, s));
         }
         if (n_iter & 1) HN_HIP(ctx, hipMemcpyAsync(states, ctx->st_tmp, sb_all, hipMemcpyDeviceToDevice, s));
     } else {
@@ -1035,7 +1079,12 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
         hipLaunchKernelGGL(k_rmse_finalize, dim3((count + 255) / 256), dim3(256), 0, s, rmse_hist, count, 1.0f / (float)(2 * plane));
         HN_HIP(ctx, hipGetLastError());
     }
-    return HN_OK;
+    return check_async(ctx, "hn_step");   // (what is up by now; hn_check_async_errors after a synchronise sees the rest)
+}
+
+int hn_check_async_errors(hn_ctx* ctx) {
+    if (!ctx) return HN_ERR_ARG;
+    return check_async(ctx, "hn_check_async_errors");
 }
 
 }  // extern "C"

@@ -91,7 +91,7 @@ __device__ __forceinline__ void conv2_all(f32x2 (&a)[4][4], unsigned mid_addr, c
 // ROLE 0: a launch of its own.  ROLE 1 / 2: the producer / consumer half of a two-phase launch (k_dc_asm_pair below): the producer writes its output tile
 // through (sc1 stores), drains them and publishes flags[tile] = epoch; the consumer first waits for the flags of the (up to nine) producer tiles its input
 // window touches and stages with sc1 LDS-direct loads.
-struct PairSync { unsigned* flags; unsigned epoch; int tile, tx, ty, gx, gy; };
+struct PairSync { unsigned* flags; unsigned epoch; int tile, tx, ty, gx, gy; int* err; };   // err: the context's host-mapped sticky error word (nullable)
 
 template <int CA, int CB, int CC, int EPI, int ROLE>
 __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, Dst out, const DcW& w, const VcEpi& epi, const float* zero_page, int H, int W,
@@ -117,7 +117,10 @@ __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, 
                 if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
                 __builtin_amdgcn_s_sleep(2);
             }
-            if (lane == 0) s_ok = __builtin_amdgcn_ballot_w64(!got) == 0 ? 1 : 0;
+            if (lane == 0) {
+                s_ok = __builtin_amdgcn_ballot_w64(!got) == 0 ? 1 : 0;
+                if (!s_ok && ps.err != nullptr) __hip_atomic_store(ps.err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // (hn_step / hn_check_async_errors: HN_ERR_STATE)
+            }
         }
         __syncthreads();
     }
@@ -280,7 +283,7 @@ __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, 
             rok[r] = yb + r < H && ox < W;
             roff[r] = rok[r] ? 4u * (unsigned)((yb + r) * W + ox) : 0u;
             if (epi.wf != nullptr) {   // the wavefield read-modify-write is prefetched behind conv2
-                const char* base = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane);
+                const char* base = reinterpret_cast<const char*>(epi.wf_in + (long)b * 2 * plane);
                 wf_old[r][0] = *reinterpret_cast<const float*>(base + roff[r]);
                 wf_old[r][1] = *reinterpret_cast<const float*>(base + 4 * plane + roff[r]);
             }
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const TileId tl = xcd_tile();
     const int tr_id = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191;
-    dc_asm_body<CA, CB, CC, EPI, 0>(lds, sa, sb, sc, out, w, epi, zero_page, H, W, tl.z, tl.x * 64, tl.y * 16, tr_id, PairSync{nullptr, 0u, 0, 0, 0, 0, 0});
+    dc_asm_body<CA, CB, CC, EPI, 0>(lds, sa, sb, sc, out, w, epi, zero_page, H, W, tl.z, tl.x * 64, tl.y * 16, tr_id, PairSync{nullptr, 0u, 0, 0, 0, 0, 0, nullptr});
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
 //     kernels as before.  Same arithmetic in the same order as the separate launches: results are bit-identical.
 // ------------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, Dst x0_out, DcW w_inc, Src b0, Src b1, Dst out0, DcW w_sig, const float* zero_page,
-                                                         int H, int W, int gx, int gy, int T, unsigned* flags, unsigned epoch) {
+                                                         int H, int W, int gx, int gy, int T, unsigned* flags, unsigned epoch, int* err) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const bool second = __builtin_amdgcn_readfirstlane((int)blockIdx.x) >= T;   // wave-uniform
     int tile = second ? (int)blockIdx.x - T : (int)blockIdx.x;
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, 
     if ((T & 7) == 0) tile = (tile & 7) * (T >> 3) + (tile >> 3);   // xcd_tile(): block i and block T + i share an XCD, and so do a tile's neighbours
 #endif
     const int tq = tile / gx, tx = tile - tq * gx, b = tq / gy, ty = tq - b * gy;
-    const PairSync ps{flags, epoch, tile, tx, ty, gx, gy};
+    const PairSync ps{flags, epoch, tile, tx, ty, gx, gy, err};
     const VcEpi noepi{nullptr, nullptr, nullptr, nullptr};
     const Src none{nullptr, 0, 0, 1.f};
     if (second) dc_asm_body<kFeat, kState, 0, 0, 2>(lds, b0, b1, none, out0, w_sig, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps);
@@ -426,7 +429,7 @@ bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, i
 
 void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H, int W,
                    int batch, hipStream_t s) {
-    const VcEpi e{d_out, wf, ctx->v_dec0c, ctx->dec0c_b};
+    const VcEpi e{d_out, wf, ctx->v_dec0c, ctx->dec0c_b, ctx->step_wf_in != nullptr ? ctx->step_wf_in : wf};
     switch (kind) {
         case 0: launch<2, 2, 2, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;              // inc
         case 1: launch<kFeat, kState, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;      // conv_signal
@@ -451,7 +454,7 @@ void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x
     const int gx = cdiv_(W, 64), gy = cdiv_(H, 16), T = gx * gy * batch;
     const unsigned epoch = ++ctx->pair_epoch;
     hipLaunchKernelGGL(k_dc_asm_pair, dim3(2 * T), dim3(256), 0, s, wf, res, sig, x0_out, ctx->inc, x0, st, out0, ctx->sig[0], ctx->zero_page, H, W, gx, gy, T,
-                       ctx->pair_flags, epoch);
+                       ctx->pair_flags, epoch, ctx->sync_err_dev);
 }
 
 }  // namespace hn

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_valu(Src sa, Src sb, Sr
             rok[r] = yb + r < H && ox < W;
             roff[r] = rok[r] ? 4u * (unsigned)((yb + r) * W + ox) : 0u;
             if (epi.wf != nullptr) {   // the wavefield read-modify-write is prefetched behind conv2
-                const char* base = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane);
+                const char* base = reinterpret_cast<const char*>(epi.wf_in + (long)b * 2 * plane);
                 wf_old[r][0] = *reinterpret_cast<const float*>(base + roff[r]);
                 wf_old[r][1] = *reinterpret_cast<const float*>(base + 4 * plane + roff[r]);
             }
@@ -318,7 +318,7 @@ bool dc_valu_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, 
 
 void launch_dc_valu(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w, bool final_epi, float* d_out, float* wf, int H,
                     int W, int batch, hipStream_t s) {
-    const VcEpi e{d_out, wf, ctx->v_dec0c, ctx->dec0c_b};
+    const VcEpi e{d_out, wf, ctx->v_dec0c, ctx->dec0c_b, ctx->step_wf_in != nullptr ? ctx->step_wf_in : wf};
     switch (kind) {
         case 0: launch<2, 2, 2, 0>(a, b, c, out, w, e, H, W, batch, s); break;              // inc
         case 1: launch<kFeat, kState, 0, 0>(a, b, c, out, w, e, H, W, batch, s); break;      // conv_signal

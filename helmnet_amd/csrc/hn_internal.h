@@ -191,10 +191,14 @@ struct hn_ctx {
     //            event packet saves); hipStreamWaitValue64 is itself a spinning kernel here and slower.
     // Every store is enqueued before the kernel that waits for it (a tool that runs one kernel at a time in submission order cannot deadlock), every wait is
     // bounded (2 s, then hn_step fails).
+    int opt_hist_copy = 0;     // HN_OPT_HIST_COPY: 0 (default) hn_step writes the residual / wavefield of iteration `it` straight into the caller's history slot and
+                               // reads it there in iteration it + 1; 1: in place in the caller's wf / res plus one device-to-device copy per iteration and history (r1 - r5; A/B)
     int opt_state_kernel = 1;  // HN_OPT_STATE_KERNEL: 1 the hidden-state DoubleConvs (10 -> 2 -> 2) of the levels >= 64 wide on the streaming kernel (hn_cs.hip), 0 k_double_conv
     int opt_side_sync = 1;     // HN_OPT_SIDE_SYNC: 1 device words between the iterations of one hn_step call, 0 events everywhere
-    unsigned* sync_flags = nullptr;   // device, 64 words
+    unsigned* sync_flags = nullptr;   // device, 256 words: 0 release / 32 join of hn_step; 64, 96 forward and 128, 160 backward sweep of hn_train_grad
     unsigned sync_epoch = 0;   // (compared wrap-around safe)
+    const float* step_wf_in = nullptr;   // argument of the NEXT decode_0 launch: the wavefield its update starts from when that is not the buffer it writes
+                               // (hn_step's zero-copy wavefield history: reads slot it - 1, writes slot it); set and cleared by unet_forward
     int dca_dec_pad = 0;       // dynamic LDS of the next decode_0 launch on hn_dca.hip: 7168 (3 blocks per CU) while the gate kernel is resident, else 0
     int* sync_err = nullptr;          // host-mapped: a bounded device-side wait that gave up stores its code here (sticky; checked by hn_step)
     int* sync_err_dev = nullptr;
@@ -470,15 +474,17 @@ int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, f
 
 // ---- unet (hn_unet.hip) ----
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the
-// wavefield is updated in place (wf += d / 1e3) by the last kernel; if d_out != nullptr d is stored.
+// wavefield is updated (wf_update = wf_prev + d / 1e3; in place when wf_prev is nullptr) by the last kernel; if d_out != nullptr d is stored.
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
                  float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off = 0, hipEvent_t after_down0 = nullptr,
-                 hn_ctx::SideLane* side_lane = nullptr, bool defer_join = false);
+                 hn_ctx::SideLane* side_lane = nullptr, bool defer_join = false, const float* wf_prev = nullptr);
+// wf_prev (with wf_update): the update reads the old wavefield THERE and writes wf_update (in_wf should view the same tensor); nullptr: in place
 // make stream s wait for the hidden-state kernels of the previous unet_forward(..., defer_join = true) on this lane
 int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
 bool side_flags_apply(hn_ctx* ctx, hipStream_t s);
 // flag sync, the side stream's halves (hn_unet.hip): a one-wave kernel that holds stream s until *flag has reached epoch / a one-thread kernel that stores it
 int ensure_sync_words(hn_ctx* ctx);
+int check_async(hn_ctx* ctx, const char* who);   // HN_ERR_STATE once a bounded device-side wait has given up (sticky word: 1 side-stream flag, 2 merged level-0 launch, 3 deep kernel)
 int zero_async(hn_ctx* ctx, void* p, size_t bytes, hipStream_t s);   // (hn_api.hip: a kernel of this library, never hipMemsetAsync, on a caller's stream)
 void launch_sync_gate(hn_ctx* ctx, const unsigned* flag, unsigned epoch, hipStream_t s);
 void launch_sync_signal(unsigned* flag, unsigned epoch, hipStream_t s);   // would unet_forward(defer_join = true) on hn_step's single lane use the device flags?

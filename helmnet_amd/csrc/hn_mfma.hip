@@ -102,8 +102,9 @@ struct McEpi {
     const float* b2c;  // its bias [2]
     // training forward (hn_train.hip): the PRE-activation mid tensor of the tile's own 16 x 64 (8 x 32 ...) positions also goes to the
     // tape, element (b, c, y, x) at z[b * z_sb + c * z_sc + y * W + x]; nullptr in the inference path
-    float* z;
-    long z_sb, z_sc;
+    float* z = nullptr;
+    long z_sb = 0, z_sc = 0;
+    const float* wf_in = nullptr;   // the wavefield the update starts from: wf itself (in place), or another buffer (hn_step's zero-copy wavefield history)
 };
 
 template <int CA, int CB, int CC, int TW, int EPI, bool GEN = false>
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_dc_mfma(Src sa, Src sb, Src sc, Dst out
                 for (int c2 = 0; c2 < 2; ++c2)
 #pragma unroll
                     for (int p = 0; p < 2; ++p)
-                        wf_old[gi][c2][p] = (y < H && x + p < W) ? epi.wf[((long)b * 2 + c2) * plane + (long)y * W + x + p] : 0.f;
+                        wf_old[gi][c2][p] = (y < H && x + p < W) ? epi.wf_in[((long)b * 2 + c2) * plane + (long)y * W + x + p] : 0.f;
             }
         }
     }
@@ -588,7 +589,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
             rok[T] = q < 3 && r < C::NR2 && yb + r < H && ox < W;
             roff[T] = rok[T] ? 4u * (unsigned)((yb + r) * W + ox) : 0u;
             if (epi.wf != nullptr) {
-                const char* base = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane);
+                const char* base = reinterpret_cast<const char*>(epi.wf_in + (long)b * 2 * plane);
                 wf_old[T][0] = *reinterpret_cast<const float2*>(base + roff[T]);
                 wf_old[T][1] = *reinterpret_cast<const float2*>(base + 4 * plane + roff[T]);
             }
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(256, GEN ? 2 : 4) void k_dc_mfma_s(Src sa, Src sb, 
 #pragma unroll
             for (int r = 0; r < C::NR2; ++r) {
                 const int y = yb + r < H ? yb + r : 0;
-                const char* row = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane + (long)y * W);
+                const char* row = reinterpret_cast<const char*>(epi.wf_in + (long)b * 2 * plane + (long)y * W);
                 wf_old[r][0] = *reinterpret_cast<const float2*>(row + off);
                 wf_old[r][1] = *reinterpret_cast<const float2*>(row + 4 * plane + off);
             }
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(256, TH == 16 ? 2 : 3) void k_dc_x16(Src sa, Src sb
 #pragma unroll
             for (int r = 0; r < C::NR2; ++r) {
                 const int y = yb + r < H ? yb + r : 0;
-                const char* row = reinterpret_cast<const char*>(epi.wf + (long)b * 2 * plane + (long)y * W);
+                const char* row = reinterpret_cast<const char*>(epi.wf_in + (long)b * 2 * plane + (long)y * W);
                 wf_old[r][0] = *reinterpret_cast<const float2*>(row + off);
                 wf_old[r][1] = *reinterpret_cast<const float2*>(row + 4 * plane + off);
             }
@@ -1317,8 +1318,8 @@ __global__ __launch_bounds__(256) void k_dc_mfma_p(Src sa, Src sb, Src sc, Dst o
                 const int orow = s / C::PPR2, pc = s - orow * C::PPR2;
                 const int y = y0 + orow, x = x0 + 2 * pc;
                 const long o = (long)b * 2 * plane + (long)(y < H ? y : 0) * W + (x < W ? x : 0);
-                wf_old[gi][0] = *reinterpret_cast<const float2*>(epi.wf + o);
-                wf_old[gi][1] = *reinterpret_cast<const float2*>(epi.wf + o + plane);
+                wf_old[gi][0] = *reinterpret_cast<const float2*>(epi.wf_in + o);
+                wf_old[gi][1] = *reinterpret_cast<const float2*>(epi.wf_in + o + plane);
             }
         }
         {
@@ -2584,7 +2585,8 @@ int launch_dc8(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const DcW& w
     const float* s1 = frag1 + (size_t)cin * 3 * 64;      // split-bf16 twin, then the fp16 twin
     const float* s2 = frag2 + (size_t)kFeat * 3 * 64;
     const McW mw{frag1, w.b1, w.slope, frag2, w.b2, s1, s2, s1 + frag_3x3_split_floats(cin), s2 + frag_3x3_split_floats(kFeat), w.act};
-    const McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf, ctx->f_dec0c, ctx->dec0c_b};
+    McEpi e{ctx->outc_w, ctx->outc_b, d_out, wf, ctx->f_dec0c, ctx->dec0c_b};
+    e.wf_in = ctx->step_wf_in != nullptr ? ctx->step_wf_in : wf;
     const int x16 = (ctx->precision >= HN_PREC_BF16X3 && ctx->precision <= HN_PREC_BF16X2) ? ctx->precision : 0;
     switch (kind) {
         case 0: launch_dc_mfma<2, 2, 2, 0>(x16, a, b, c, out, mw, e, H, W, batch, s); break;          // inc

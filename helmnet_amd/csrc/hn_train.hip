@@ -1230,6 +1230,7 @@ struct Trainer {
     bool tile_small = false; // HN_OPT_TRAIN_FUSED bit 3 (A/B): the small levels' backward DoubleConvs on the tiled kernel too instead of the per-sample k_dc_small
     bool fused_state = true; // HN_OPT_TRAIN_FUSED bit 2 (A/B): the hidden-state DoubleConvs as two batched launches per direction (the r3 path)
     unsigned fwd_epoch = 0;  // (flag sync: the running forward iteration's epoch)
+    int deferred_t = -1, deferred_par = 0;   // (flag sync: the backward iteration whose weight-gradient launches are enqueued behind the NEXT iteration's loss-seed kernel)
     bool flag_sync = false;  // HN_OPT_SIDE_SYNC (hn_internal.h: sync_flags): the side stream's releases and joins of the sweeps through device words carried by k_down_mfma / k_up_mfma /
                              // k_loss_seed instead of event packets (words 64 / 96: forward release / join; 128 / 160: backward).  One lane, not under capture.
     bool side_state_fwd = false; // forward sweep: the hidden-state DoubleConvs of an iteration on the (then idle) weight-gradient stream, joined in front of the next iteration's conv_signal
@@ -1489,6 +1490,19 @@ struct Trainer {
         }
         // this iteration's loss term, then the adjoint of the residual operator: G = g_wf + L^H(g_res) + ksq * g_res
         hipLaunchKernelGGL(k_loss_seed, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0, s, W.g_res, res_out, loss_c, 1, tot2, hk);
+        if (deferred_t >= 0) {
+            // the weight-gradient launches of iteration t + 1, gate first: enqueued HERE, behind the kernel that stores their release word, so that every
+            // store precedes its wait in submission order too (a tool or setting that runs kernels strictly in that order cannot starve the gate).
+            // Their jobs are still the filed ones: nothing of this iteration has been filed yet
+            const unsigned e = hk.store_epoch;
+            launch_sync_gate(ctx, ctx->sync_flags + 128, e, W.wg_stream);
+            if ((rc = flush_wgrads(deferred_t, W.wg_stream)) != HN_OK) return rc;
+            launch_sync_signal(ctx->sync_flags + 160, e, W.wg_stream);
+            HN_HIP(ctx, hipEventRecord(W.wg_done[deferred_par], W.wg_stream));
+            W.wg_pending[deferred_par] = true;
+            W.wg_flag_epoch[deferred_par] = e;
+            deferred_t = -1;
+        }
         if ((rc = spec_adjoint(ctx, W.g_res, W.g_wf[cur_wf ^ 1], ksq, W.g_wf[cur_wf], B, s)) != HN_OK) return rc;
         cur_wf ^= 1;
         float* G = W.g_wf[cur_wf];   // d loss / d wf_next; wf_next = wf + d / 1e3, so it is also the direct part of d loss / d wf
@@ -1588,14 +1602,9 @@ struct Trainer {
             wg_cap = cap;
             if (rc != HN_OK) return rc;
         } else if (overlap && flag_sync && t > 0) {   // ... released by the NEXT iteration's loss-seed kernel (t - 1 exists), joined through a device word or, at the end, the event
-            const unsigned e = ++ctx->sync_epoch;
-            W.bwd_release_epoch = e;
-            launch_sync_gate(ctx, ctx->sync_flags + 128, e, W.wg_stream);
-            if ((rc = flush_wgrads(t, W.wg_stream)) != HN_OK) return rc;
-            launch_sync_signal(ctx->sync_flags + 160, e, W.wg_stream);
-            HN_HIP(ctx, hipEventRecord(W.wg_done[par], W.wg_stream));
-            W.wg_pending[par] = true;
-            W.wg_flag_epoch[par] = e;
+            W.bwd_release_epoch = ++ctx->sync_epoch;
+            deferred_t = t;        // (gate, launches, signal and the wg_done record follow that loss-seed kernel: top of backward_step(t - 1))
+            deferred_par = par;
         } else if (overlap) {   // the filed weight-gradient jobs: three launches on the side stream, beside the backward chain of iteration t - 1
             HN_HIP(ctx, hipEventRecord(W.wg_ready[par], s));
             HN_HIP(ctx, hipStreamWaitEvent(W.wg_stream, W.wg_ready[par], 0));
@@ -1771,6 +1780,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
         return fail(ctx, HN_ERR_ARG, "hn_train_grad: NULL argument");
     int rc = train_ready(ctx, batch, n_unroll);
     if (rc != HN_OK) return rc;
+    if ((rc = check_async(ctx, "hn_train_grad (an earlier call)")) != HN_OK) return rc;   // a device-side wait that gave up: tape / gradients since then are not to be trusted
     if (src_batch != 1 && src_batch != batch) return fail(ctx, HN_ERR_ARG, "source batch %d must be 1 or equal to the batch %d", src_batch, batch);
     if (ctx->train_fwd_sumsq != nullptr && (int64_t)n_unroll * batch > ctx->train_fwd_sumsq_cap)
         return fail(ctx, HN_ERR_ARG, "hn_train_grad: the host table of hn_train_set_forward_event holds %lld floats, this call writes %lld", (long long)ctx->train_fwd_sumsq_cap,
@@ -1938,6 +1948,12 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
             (void)hipStreamWaitEvent(s, ctx->train_join, 0);
         }
     };
+    if (tr[0].flag_sync && (tr[0].overlap || tr[0].side_state_fwd)) {
+        // flag sync: the side stream's gate kernels spin from the moment that stream is free, so it first waits for the caller's stream to get HERE (one event per
+        // CALL, as hn_step does): a caller's stream that is seconds behind cannot make a bounded wait give up
+        HN_HIP(ctx, hipEventRecord(ws[0]->st_fork, s));
+        HN_HIP(ctx, hipStreamWaitEvent(ws[0]->wg_stream, ws[0]->st_fork, 0));
+    }
     for (int t = 0; t < n_unroll && rc == HN_OK; ++t)
         for (int l = 0; l < lanes && rc == HN_OK; ++l) {   // the lanes' launches are enqueued alternately, so both streams always hold work
             const size_t o2 = (size_t)t * fwf + (size_t)lane_b0[l] * p2, ost = (size_t)t * fst + (size_t)lane_b0[l] * pst;
@@ -2006,7 +2022,7 @@ int hn_train_grad(hn_ctx* ctx, const float* weights, const float* wf, const floa
                            lanes == 2 ? ws[1]->slope_part : nullptr, (int)ws[1]->slope_stride, sj[1], grad);
     }
     HN_HIP(ctx, hipGetLastError());
-    return HN_OK;
+    return check_async(ctx, "hn_train_grad");   // (what is up by now; hn_check_async_errors behind a synchronise sees the rest)
 }
 
 int hn_train_set_forward_event(hn_ctx* ctx, void* event, float* sumsq_host, int64_t sumsq_capacity) {

@@ -48,6 +48,7 @@ struct DcEpi {
     const float* ob;  // [2]
     float* d_out;     // [B,2,H,W] or nullptr
     float* wf;        // [B,2,H,W] updated in place, or nullptr
+    const float* wf_in = nullptr;   // the wavefield the update starts from (wf itself, or the previous slot of a wavefield history)
 };
 
 // 3x3 taps of one input channel for a 1x4 strip: acc[p][m] += w[dy][dx][m] * row[dy][p + dx]
@@ -221,7 +222,7 @@ __global__ __launch_bounds__((DcCfg<CA, CB, CC, CM, CO, TW>::NT)) void k_double_
             for (int p = 0; p < 4; ++p)
                 if (x + p < W) {
                     if (epi.d_out) epi.d_out[o + p] = d[p];
-                    if (epi.wf) epi.wf[o + p] = d[p] / 1e3f + epi.wf[o + p];
+                    if (epi.wf) epi.wf[o + p] = d[p] / 1e3f + epi.wf_in[o + p];
                 }
         }
     }
@@ -437,8 +438,10 @@ __global__ void k_sync_gate(const unsigned* flag, unsigned epoch, int* err) {
 
 int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* states_in, float* states_out,
                  float* d_out, float* wf_update, int batch, hipStream_t s, int ws_off, hipEvent_t after_down0,
-                 hn_ctx::SideLane* side_lane, bool defer_join) {
+                 hn_ctx::SideLane* side_lane, bool defer_join, const float* wf_prev) {
     const int n = ctx->tab.n, depth = ctx->depth;
+    struct WfIn { hn_ctx* c; ~WfIn() { c->step_wf_in = nullptr; } } wf_in_guard{ctx};   // (read by the decode_0 launchers below)
+    ctx->step_wf_in = wf_update != nullptr ? wf_prev : nullptr;
     const long L = ctx->state_len;
     const Src none{nullptr, 0, 0, 1.f};
     const DcEpi noepi{nullptr, nullptr, nullptr, nullptr};
@@ -629,7 +632,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
                                                         feat(ctx->buf_y[d], d), ctx->dec[d], noepi, m, m, batch, s);
         } else {
             // + outc 1x1 (architectures.py:463) and wf <- d/1e3 + wf (hybridnet.py:570)
-            const DcEpi e{ctx->outc_w, ctx->outc_b, d_out, wf_update};
+            const DcEpi e{ctx->outc_w, ctx->outc_b, d_out, wf_update, ctx->step_wf_in != nullptr ? ctx->step_wf_in : wf_update};
             launch_dc<kFeat, kFeat, 0, kFeat, kFeat, 1>(featsrc(ctx->buf_a[0], 0), featsrc(ctx->buf_o[0], 0), none,
                                                         Dst{nullptr, 0, 0}, ctx->dec[0], e, m, m, batch, s);
         }

@@ -27,6 +27,7 @@ struct VcEpi {
     float* wf;
     const float* w2c;  // conv2 composed with the out-conv: [8 cm][3][3][2]
     const float* b2c;  // [2]
+    const float* wf_in = nullptr;   // the wavefield the update starts from: wf itself (in place), or another buffer (hn_step's zero-copy wavefield history)
 };
 
 // R output rows x 2 NP channels of a 3x3 convolution over one input channel: rows j = 0 .. R+1 at xc[j * pitch + 0..2]

@@ -205,6 +205,11 @@ class Engine:
     def counter(self, name: str) -> int:
         return int(self.lib.hn_get_counter(self.ctx, _lib.HN_COUNTER[name]))
 
+    def check_async_errors(self):
+        """Raise if a bounded device-side wait of any earlier call on this context gave up (hn_check_async_errors); reliable once the stream the work
+        ran on has been synchronised."""
+        _lib.check(self.lib.hn_check_async_errors(self.ctx), self.ctx, "hn_check_async_errors")
+
     @property
     def state_len(self) -> int:
         return int(self.lib.hn_state_len(self.ctx))

@@ -342,6 +342,7 @@ class Trainer:
         nb = wavefields.shape[0]
         if fwd_recorded:
             self._fwd_event.synchronize()
+            self.engine.check_async_errors()   # (a side-stream hand-over of the forward sweep that timed out: the tape behind it is incomplete)
             meansq = self._sumsq_host[: T * nb].view(T, nb)[iteration].numpy() / np.float32(res_it[0].numel())   # res.pow(2).mean() per sample, fp32
         else:   # the library did not record the event for this call (a captured step, or another engine user replaced the registration): the reference's own reduction
             meansq = res_it.pow(2).mean(dim=(1, 2, 3)).cpu().numpy()

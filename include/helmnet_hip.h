@@ -75,8 +75,8 @@ enum hn_precision { HN_PREC_FP32 = 0, HN_PREC_BF16X3 = 1, HN_PREC_FP16 = 2, HN_P
  * fp32 arithmetic and agree to fp32 rounding, like two fp32 implementations of the reference do: DEEP (other summation order,
  * 2e-6 * max), SPECTRAL_PFA (FFT instead of the dense operator), SPECTRAL_RADIX16 (other butterfly order), DC_VALU. */
 enum hn_option {
-    HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1; [measured] 2 loses 3 % at 256^2 x 32 and
-                              * wins where a lane is a full batch of 32: 256^2 x 64 as two chains +19 % samples/s)              */
+    HN_OPT_LANES = 0,        /* 1..8 sub-batches pipelined on internal streams (default 1; [measured, r5] 2 loses 3 % at 256^2 x 32 and 2 % at
+                              * 256^2 x 64 -- one chain of 64 maps is the faster form since the r5 level-0 kernels --, +1 % at batch 128) */
     HN_OPT_SIDE_STREAM = 1,  /* conv_state kernels: 0 in line; on a library side stream released 1 after the last `down`,
                               * 2 level by level behind conv_signal, 3 behind the fused deep level               */
     HN_OPT_DEEP = 3,         /* 0/1: deepest level + bottleneck fused into one per-sample LDS kernel (default 1)      */
@@ -90,11 +90,19 @@ enum hn_option {
                               * activations and unaligned tensors always take hn_dcv.hip                                          */
     HN_OPT_DC_PAIR = 12,     /* 0/1 (default 1): where inc and conv_signal_0 both run on hn_dca.hip they are ONE launch -- conv_signal's blocks wait, tile by
                               * tile, on a flag the inc blocks of the tiles they read publish (write-through stores, agent-scope flag).  hn_step's
-                              * single-lane eager path only (not under capture, not with HN_OPT_LANES > 1).  Bit-identical to the two launches      */
+                              * single-lane eager path only (not under capture, not with HN_OPT_LANES > 1).  Bit-identical to the two launches.
+                              * ASSUMES that the workgroups of a launch are dispatched in index order (true of the hardware dispatcher; a tool that
+                              * re-orders or caps dispatch must run with 0): a conv_signal block whose inputs have not arrived after ~2 M polls
+                              * writes NaN into its tile AND raises the context's sticky device error (HN_ERR_STATE from this or the next hn_step) */
     HN_OPT_SIDE_SYNC = 13,   /* 0/1 (default 1): between the iterations of ONE hn_step call the side stream is joined -- and, at 256^2, released -- through
                               * device words that kernels of the main chain store / poll on their way (one thread each) instead of event packets,
                               * each of which holds the main stream for ~7 us; a call forks the side stream with one event and its LAST iteration uses events.
-                              * hn_step's single-lane eager path, fp32, HN_OPT_SIDE_STREAM 1; waits are bounded (2 s, then hn_step fails).
+                              * hn_step's single-lane eager path, fp32, HN_OPT_SIDE_STREAM 1; waits are bounded (2 s, then hn_step fails: the call in
+                              * which a wait gave up returns HN_ERR_STATE if the error word is up by the time its launches are enqueued, else the next
+                              * call does; hn_check_async_errors after a stream synchronise is the reliable test).
+                              * The same option switches hn_train_grad's side stream (HN_OPT_TRAIN_OVERLAP 2) to device words (words 64 .. 160 of the
+                              * context's 256 sync words; eager calls only) and then opens that side-stream window at every problem size instead of
+                              * 200 k .. 1 M pixels; hn_train_grad reports a timed-out wait of an EARLIER call as HN_ERR_STATE at entry.
                               * Same kernels, same results; [measured, r5] +1 % it/s at 256^2 x 32, +8 % at batch 8.  A tool that runs ONE kernel at
                               * a time across all queues (counter collection: rocprofv3 --pmc) can starve such a wait: hn_create then defaults
                               * to 0 (ROCPROF_COUNTER_COLLECTION / ROCPROF_COUNTERS / ROCP_METRICS in the environment); any other such tool gets
@@ -102,6 +110,8 @@ enum hn_option {
     HN_OPT_STATE_KERNEL = 14, /* 0/1 (default 1): the hidden-state DoubleConvs (10 -> 2 -> 2) of the levels at least 64 wide on the streaming kernel
                               * (hn_cs.hip: the tile's ten input planes through a ring of LDS-direct loads); 0: the general direct kernel.
                               * Bit-identical                                                                                          */
+    HN_OPT_HIST_COPY = 15,   /* 0 (default): hn_step's residual / wavefield histories are written in place of the copies (see hn_step); 1: every
+                              * iteration works in the caller's wf / res and copies them into the history slots (A/B; bit-identical)       */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of
@@ -137,7 +147,7 @@ enum hn_counter { HN_CNT_GRAPH_REPLAYS = 0, HN_CNT_EAGER_ITERATIONS = 1, HN_CNT_
                   HN_CNT_FLAG_SYNC_ITERATIONS = 6 };/* hn_step iterations whose side-stream hand-overs went through device words (HN_OPT_SIDE_SYNC): n_iter - 1 per
                                                  * eligible call, 0 with the option off, under stream capture, under counter collection, with several lanes */
 
-#define HN_ABI_VERSION 6
+#define HN_ABI_VERSION 7
 int hn_abi_version(void);
 
 /* Create / destroy a context on HIP device `device_id`. */
@@ -167,6 +177,10 @@ int hn_set_unet_precision(hn_ctx* ctx, int precision);
 int hn_get_unet_precision(const hn_ctx* ctx);
 int hn_set_option(hn_ctx* ctx, int option, int value);
 int64_t hn_get_counter(const hn_ctx* ctx, int counter);
+/* Device-side waits of this library (HN_OPT_SIDE_SYNC, HN_OPT_DC_PAIR) are bounded and report through a sticky host-visible word; a call can only
+ * see what is up by the time it returns, and the last hn_step of a solve has no successor.  HN_OK, or HN_ERR_STATE (with the message) if any wait
+ * of any earlier call on this context gave up -- call it after synchronising the stream the work ran on.  No GPU work, no synchronisation. */
+int hn_check_async_errors(hn_ctx* ctx);
 
 /* Build the spectral-operator constants for an n x n domain (float64 on the host, fp32 on the
  * device): k grids, PML coefficients ax/bx/ay/by, sigma maps, FFT twiddles.
@@ -238,7 +252,11 @@ int hn_out_conv(hn_ctx* ctx, const float* x, const float* weights_host, float* o
  *     res_hist  [n_iter, B, 2, n, n]  residual after every iteration (the reference keeps them all)
  *     wf_hist   [n_iter, B, 2, n, n]  wavefield after every iteration (return_wavefields=True)
  *     st_hist   [n_iter, B, 2, L]     flat hidden state after every iteration (return_states=True)
- *     rmse_hist [n_iter, B]           per-sample residual RMSE after every iteration            */
+ *     rmse_hist [n_iter, B]           per-sample residual RMSE after every iteration
+ * Histories cost no copies (v7): the residual / wavefield of iteration `it` is WRITTEN into slot `it` of res_hist / wf_hist by the kernels
+ * that compute it and read there by iteration it + 1 -- the reference keeps every residual for free too (it appends tensors, :676-697);
+ * wf and res receive the last slot with one device-to-device copy per call.  Requires the slots not to alias wf / res; with captured
+ * iterations (HN_EXP_GRAPH), several lanes or HN_OPT_HIST_COPY 1 the r1 - r6 form (in place + one copy per iteration and history) runs. */
 int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq, const float* src,
             int src_batch, int batch, int n_iter, float* res_hist, float* wf_hist, float* st_hist,
             float* rmse_hist, void* stream);

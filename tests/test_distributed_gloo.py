@@ -103,3 +103,19 @@ def test_shard_bounds_cover_batch():
     x = torch.tensor([1.0, 3.0, 2.0])
     assert allreduce_residual_norms(x, "max").item() == 3.0      # no process group: local reduction
     assert allreduce_residual_norms(x, "mean").item() == 2.0
+
+
+def test_bench_starts_its_own_ranks_and_says_what_it_needs():
+    """`python bench.py --gpus 2` without a launcher spawns two child ranks before any GPU call; on a box with fewer than two devices every
+    rank that has no device says so and the launcher exits non-zero (no hang in the rendezvous, no 'use torch.distributed.run' hint)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices visible: the launcher would run the benchmark")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "needs 2 devices on this node" in r.stderr and "torch.distributed.run" not in r.stderr, r.stderr[-2000:]
+    assert "rank 1" in r.stderr      # the child without a device reported it itself

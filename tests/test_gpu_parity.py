@@ -47,7 +47,7 @@ def _err(name, got, g, n):
 def test_library_is_the_hip_build():
     from helmnet_amd import _lib
     lib = _lib.load()
-    assert lib.hn_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.hn_abi_version() == _lib.ABI_VERSION == 7
     assert torch.cuda.is_available()
 
 
@@ -657,3 +657,31 @@ def test_streaming_hidden_state_kernel_is_bit_identical_to_the_general_one(n, b)
         assert torch.isfinite(outs[k][0]).all() and outs[k][0].abs().max() > 0
     for a, c in zip(outs[1], outs[0]):
         assert torch.equal(a, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,b,k", [(256, 4, 9), (128, 3, 6), (512, 1, 4)])
+def test_histories_written_in_place_are_bit_identical_to_copied_ones(n, b, k):
+    """HN_OPT_HIST_COPY (ABI v7): by default iteration `it` of hn_step writes its residual / wavefield straight into slot `it` of the caller's histories and
+    iteration it + 1 reads them there (the reference keeps every residual for free: it appends tensors, hybridnet.py:676-697); with 1 every iteration works
+    in the caller's wf / res and copies.  Same kernels on the same values: every history slot, the final wf / res / states and the RMSE rows are equal bit
+    for bit -- with all three histories, with the residual history alone (the drop-in default of forward()), and with none."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import ring_sos_batch
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=21)).to(DEV)
+    outs = {}
+    for copy in (0, 1):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=SRC.get(n, [n // 3, n // 2]))
+        s.engine().set_option("hist_copy", copy)
+        full = s.forward(sos, num_iterations=k, return_wavefields=True, return_states=True)           # res + wf + state histories
+        dflt = s.forward(sos, num_iterations=k)                                                         # the reference's default: every residual
+        none = s.forward(sos, num_iterations=k, residuals="norms")
+        outs[copy] = (torch.stack(full["residuals"]), torch.stack(full["wavefields"]), torch.stack(full["states"]), full["residual_norms"],
+                      torch.stack(dflt["residuals"]), dflt["wavefields"][0], dflt["residual_norms"], none["wavefields"][0], none["last_residual"],
+                      s.f.get_states(flatten=True).clone())
+        assert torch.equal(outs[copy][0], outs[copy][4]) and torch.equal(outs[copy][1][-1], outs[copy][5]) and torch.equal(outs[copy][5], outs[copy][7])
+        assert torch.equal(outs[copy][0][-1], outs[copy][8])
+        s.engine().check_async_errors()
+    for a, c in zip(outs[0], outs[1]):
+        assert torch.isfinite(a).all() and torch.equal(a, c)

@@ -22,7 +22,7 @@ def test_header_symbols_all_exported():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.hn_abi_version() == _lib.ABI_VERSION == 6
+    assert lib.hn_abi_version() == _lib.ABI_VERSION == 7
     assert lib.hn_weight_count(8, 4, 2) == 48160
     assert lib.hn_weight_count(16, 4, 2) == 0
     # no GPU here: creating a context must fail cleanly with a message, not crash
