@@ -16,7 +16,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libhelmnet_hip.so")
-SOURCES = ["hn_api.hip", "hn_spectral.hip", "hn_unet.hip", "hn_mfma.hip", "hn_deep.hip", "hn_dcv.hip", "hn_dca.hip", "hn_cs.hip", "hn_train.hip", "hn_rows.hip"]
+SOURCES = ["hn_api.hip", "hn_spectral.hip", "hn_unet.hip", "hn_mfma.hip", "hn_deep.hip", "hn_deepx.hip", "hn_dcv.hip", "hn_dca.hip", "hn_cs.hip", "hn_train.hip", "hn_rows.hip"]
 HEADERS = [os.path.join(CSRC, "hn_internal.h"), os.path.join(CSRC, "hn_vec.h"), os.path.join(CSRC, "hn_dca_pass.inc"), os.path.join(REPO, "include", "helmnet_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-I" + os.path.join(REPO, "include"), "-I" + CSRC,
          "-Wall", "-Wno-unused-function"]

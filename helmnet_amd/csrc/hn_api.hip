@@ -115,6 +115,8 @@ void free_workspace(hn_ctx* c) {
     }
     (void)hipFree(c->st_tmp); c->st_tmp = nullptr;
     (void)hipFree(c->pair_flags); c->pair_flags = nullptr; c->pair_flags_cap = 0;
+    (void)hipFree(c->dx_flags); c->dx_flags = nullptr;
+    (void)hipFree(c->dx_done); c->dx_done = nullptr;
     c->cap_batch = 0;
 }
 
@@ -289,7 +291,7 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
             ctx->opt_graph = value;
             break;
         case HN_OPT_DEEP:
-            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_DEEP must be 0 or 1 (got %d)", value);
+            if (value < 0 || value > 2) return fail(ctx, HN_ERR_ARG, "HN_OPT_DEEP must be 0, 1 or 2 (got %d)", value);
             ctx->opt_deep = value;
             break;
         case HN_OPT_SPECTRAL_PFA:
@@ -579,6 +581,11 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
     ctx->pair_flags_cap = (long)((n + 63) / 64) * ((n + 15) / 16) * max_batch;   // one flag word per level-0 tile (k_dc_asm_pair); epochs start at 1
     HN_HIP(ctx, hipMalloc((void**)&ctx->pair_flags, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
     HN_HIP(ctx, hipMemset(ctx->pair_flags, 0, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
+    // hn_deepx.hip: 64 epoch words and one counter per sample slot (zero: the first launch's epoch is 1)
+    HN_HIP(ctx, hipMalloc((void**)&ctx->dx_flags, sizeof(unsigned) * 64 * (size_t)max_batch));
+    HN_HIP(ctx, hipMemset(ctx->dx_flags, 0, sizeof(unsigned) * 64 * (size_t)max_batch));
+    HN_HIP(ctx, hipMalloc((void**)&ctx->dx_done, sizeof(unsigned) * (size_t)max_batch));
+    HN_HIP(ctx, hipMemset(ctx->dx_done, 0, sizeof(unsigned) * (size_t)max_batch));
     if (int rc_sync = ensure_sync_words(ctx); rc_sync != HN_OK) return rc_sync;
     ctx->cap_batch = max_batch;
     return HN_OK;
@@ -1080,6 +1087,17 @@ int hn_step(hn_ctx* ctx, float* wf, float* res, float* states, const float* k_sq
         HN_HIP(ctx, hipGetLastError());
     }
     return check_async(ctx, "hn_step");   // (what is up by now; hn_check_async_errors after a synchronise sees the rest)
+}
+
+// Laboratory accessor (tools/deepx_check.py; not part of the ABI of include/helmnet_hip.h): the workspace tensor kind (0 x_d / upsampled, 1 skip out_d,
+// 2 decoder output y_d) of level d, [reserved batch][8][n_d][n_d] floats.
+int hn_debug_workspace(hn_ctx* ctx, int kind, int level, float** ptr, long* floats) {
+    if (!ctx || !ptr || !floats || level < 0 || level > kMaxDepth) return HN_ERR_ARG;
+    float* p = kind == 0 ? ctx->buf_a[level] : kind == 1 ? (level < kMaxDepth ? ctx->buf_o[level] : nullptr) : ctx->buf_y[level];
+    const long m = ctx->tab.n >> level;
+    *ptr = p;
+    *floats = p ? (long)ctx->cap_batch * kFeat * m * m : 0;
+    return HN_OK;
 }
 
 int hn_check_async_errors(hn_ctx* ctx) {

@@ -173,7 +173,12 @@ struct hn_ctx {
     int opt_radix16 = 1;       // 256-point transforms as two register-resident radix-16 passes (0: the radix-4 Stockham kernels)
     int opt_cols_t = 1;        // 256-point column pass through an LDS transpose: 0 the r2 kernel (16-byte global accesses), 1: 16 columns per block, 2: 32
     bool cols_t_attr_set = false, cols512_attr_set = false;
-    int opt_deep = 1;          // deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel
+    int opt_deep = 2;          // HN_OPT_DEEP: 1 deepest encoder level + bottleneck + deepest decoder level as one per-sample LDS kernel (hn_deep.hip, deepest level 32^2);
+                               // 2 (default) the last one or two levels + bottleneck as ONE launch with eight workgroups per sample where it applies (hn_deepx.hip:
+                               // a 64-wide level, with a 32-wide one below it or not), else as 1; 0 layer by layer
+    unsigned* dx_flags = nullptr;   // hn_deepx.hip: [sample slot][8 bands][8 hand-offs] epoch words
+    unsigned* dx_done = nullptr;    // [sample slot]: bands that have ended, ever (the launch's epoch is derived from it on the device)
+    bool deepx_attr_set = false;
     int opt_dc_valu = 4;       // fp32 DoubleConvs of the big levels on the packed vector FMA: 0 none, 1 inc + decoder (hn_dcv.hip), 2 all three;
                                // 3 / 4 (default): the same two / three on the hand-scheduled kernel (hn_dca.hip)
     int opt_dc_pair = 1;       // HN_OPT_DC_PAIR: inc and conv_signal_0 as one launch with per-tile flags (hn_dca.hip, k_dc_asm_pair); hn_step's single-lane eager path
@@ -471,6 +476,10 @@ void pack_frag_3x3_c2(const float* w_oihw, int cin, float* dst);  // 2 output ch
 bool deep_applies(const hn_ctx* ctx);
 int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, float* st_out, long st_sb, long st_sc, float* y_out,
                 long y_sb, int batch, hipStream_t s, SyncHook hook = SyncHook{});
+
+// ---- the last one or two levels + bottleneck with eight workgroups per sample (hn_deepx.hip) ----
+int deepx_levels(const hn_ctx* ctx);   // 2 / 1 / 0: levels the kernel would fuse for the current domain, options and precision
+int launch_deepx(hn_ctx* ctx, int levels, const float* states_in, float* states_out, int ws_off, int batch, hipStream_t s, SyncHook hook = SyncHook{});
 
 // ---- unet (hn_unet.hip) ----
 // One HybridNet forward.  wf/res/sigma sources are generic views; if wf_update != nullptr the

@@ -482,8 +482,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         if (rc != HN_OK) return rc;
     }
     // the deepest level (32 x 32) and the bottleneck run as one per-sample kernel (hn_deep.hip) where they fit LDS
-    const bool deep = mfma && deep_applies(ctx);
-    const int n_enc = deep ? depth - 1 : depth;   // encoder levels launched layer by layer
+    // ... or the last one / two levels and the bottleneck as one launch with eight workgroups per sample (hn_deepx.hip)
+    const int deepx = mfma ? deepx_levels(ctx) : 0;
+    const bool deep = mfma && deepx == 0 && deep_applies(ctx);
+    const int n_enc = deepx ? depth - deepx : deep ? depth - 1 : depth;   // encoder levels launched layer by layer
     // conv_state_d (architectures.py:248) feeds nothing in this iteration, so with a side stream it leaves the main
     // chain.  When it is released (ctx->opt_side_stream):
     //   1  all levels after the last layer-by-layer `down`: the main chain is entering its small, latency-bound levels
@@ -496,7 +498,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     // up_0 polling a word, and, where the deep kernel exists to carry the store, the release is a word too: no event packet touches the main stream
     const bool flags = eager && defer_join && policy == 1 && ctx->opt_side_sync == 1 && ctx->sync_flags != nullptr && ctx->precision == HN_PREC_FP32 &&
                        n_enc >= 1;
-    const bool rel_flag = flags && deep;   // otherwise the release stays an event record (no other kernel sits where the store belongs)
+    const bool rel_flag = flags && (deep || deepx);   // otherwise the release stays an event record (no other kernel sits where the store belongs)
     const unsigned sync_epoch = flags ? ++ctx->sync_epoch : 0u;
     auto release_states = [&](int d0, int d1, hipEvent_t ev) -> int {
         if (rel_flag) {   // (the kernel that stores the release word has been enqueued)
@@ -584,6 +586,18 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
             if (rc != HN_OK) return rc;
         }
     }
+    if (deepx) {
+        {
+            ProfScope ps(ctx, KID_DEEP, s);
+            int rc = HN_OK;
+            HN_REP(KID_DEEP) rc = launch_deepx(ctx, deepx, states_in, states_out, ws_off, batch, s, rel_hook);
+            if (rc != HN_OK) return rc;
+        }
+        if (rel_flag) {
+            int rc = release_states(0, n_enc, nullptr);
+            if (rc != HN_OK) return rc;
+        }
+    }
     if (deep) {
         const int d = depth - 1;
         {
@@ -603,7 +617,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         if (rc != HN_OK) return rc;
     }
     // bottleneck: decode[depth]                                          (architectures.py:453)
-    if (!deep) {
+    if (!deep && !deepx) {
         ProfScope ps(ctx, KID_BOTTLENECK, s);
         if (mfma) launch_dc8(ctx, 2, featsrc(ctx->buf_a[depth], depth), none, none, feat(ctx->buf_y[depth], depth), ctx->dec[depth],
                              ctx->f_dec[depth][0], ctx->f_dec[depth][1], false, nullptr, nullptr, n >> depth, n >> depth, batch, s);
