@@ -437,7 +437,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     HN_HIP(ctx, hipMemcpy(ctx->wdev, packed.data(), want * sizeof(float), hipMemcpyHostToDevice));
     {   // A-operand fragments for the matrix-core kernels, built from the original OIHW tensors
         std::vector<float> fr;
-        std::vector<size_t> off, offq, offa;   // offq / offa: conv1 of every 8-channel DoubleConv re-packed for hn_dcv.hip / hn_dca.hip, in blob order   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order; offu: its
+        std::vector<size_t> off, offq, offa, offd2;   // offq / offa: conv1 of every 8-channel DoubleConv re-packed for hn_dcv.hip / hn_dca.hip, in blob order   // offq: the vector-pipe re-pack of conv1 of every 8-channel DoubleConv, in blob order; offu: its
                                                // two convolutions in the Winograd domain (hn_wino.hip)
         size_t pos = 0;
         auto dc = [&](int cin, int cm, int co) {  // returns offsets of (frag1, frag2) or (npos, npos)
@@ -471,6 +471,8 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
                 if (up) pack_frag_up_x16(blob + pos, fr.data() + o, fr.data() + o + k8_split_floats());
                 else pack_frag_down_x16(blob + pos, fr.data() + o, fr.data() + o + k8_split_floats());
             }
+            // (behind the twins, which the 16-bit launchers address relative to the fp32 block) the column-pair packing of hn_deepx.hip
+            if (!up) { offd2.push_back(fr.size()); fr.resize(fr.size() + (size_t)kFeat * 2 * 10 * 64); pack_frag_down2(blob + pos, fr.data() + offd2.back()); }
             pos += k8_count();
         };
         dc(kInCh, kFeat, kFeat);
@@ -510,6 +512,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         }
         for (int d = 0; d <= depth; ++d) { ctx->f_dec[d][0] = nxt(); ctx->f_dec[d][1] = nxt(); }
         for (int d = 0; d < depth; ++d) ctx->f_up[d] = nxt();
+        for (int d = 0; d < depth; ++d) ctx->f_down2[d] = ctx->fragdev + offd2[d];
         {
             size_t iq = 0;
             ctx->inc.w1q = ctx->fragdev + offq[iq++];

@@ -43,9 +43,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-constexpr int kG = 8;       // bands (workgroups) per sample
-constexpr int kNT = 512;    // 8 wavefronts
-constexpr int kC0 = 4;      // column of pixel 0 in every LDS plane (4 zero columns on the left, 3 on the right: odd pitch W + 7)
+constexpr int kG = 8;        // bands (workgroups) per sample
+#ifndef HN_DX_NT
+#define HN_DX_NT 512         // (A/B: 1024 = 16 wavefronts)
+#endif
+constexpr int kNT = HN_DX_NT;   // 8 wavefronts: 2 per SIMD, which leaves registers and LDS for two blocks of the side stream's hidden-state kernel per CU
+constexpr int kNW = kNT / 64;
+constexpr int kC0 = 4;       // column of pixel 0 in every LDS plane (4 zero columns on the left, 3 on the right: odd pitch W + 7)
 
 // LDS planes: element (channel c, band row r, column x) at p[c * plane + r * pitch + x]; r and x may be negative (halo rows, zero padding)
 struct Pl {
@@ -56,37 +60,39 @@ struct Pl {
 // ---- LDS map of one level (floats, relative to the level's base).  Band rows R = W / 8.
 //   OUT  conv_signal's output (skip connection), rows [-3, R + 3): also the window of the 8x8 stride-2 convolution
 //   ST   the level's hidden state, rows [-2, R + 2)
-//   CSM  conv_state's 2-channel mid tensor, rows [-1, R + 1)
-//   U    the upsampled tensor, rows [-2, R + 2)
-//   X    the level's input, rows [-2, R + 2)            } dead after conv_signal: the INNER block (next level or bottleneck) lives in
-//   MID  mid tensor of the two 8-channel DoubleConvs    } [X, END); the decoder's mid tensor returns to MID afterwards
-// An inner block starts with a plane set of OUT geometry (at its own width) that receives its result: the enclosing `up` reads it there.
+//   MID  mid tensor of the two 8-channel DoubleConvs, rows [-1, R + 1)    } P1 = [MID | XU]: between conv_signal and `up` the INNER block (next level or
+//   XU   the level's input x, later the upsampled tensor, rows [-2, R+2)  } bottleneck) lives here; its first plane set (OUT geometry at W / 2) receives
+//                                                                           its result, which `up` reads there -- inside MID's place, clear of XU
+//   CSM  conv_state's 2-channel mid tensor: the tail of P1 (x is dead by then, the inner block does not reach it)
+//   the partial sums of `down` take the head of P1 (below the inner block's input plane) and are cleared again
+// 88.6 KB at W = 64: two blocks of the side stream's hidden-state kernel (36 KB each) fit beside a workgroup of this kernel.
 template <int W>
 struct Lay {
     static constexpr int R = W / kG, P = W + 7;
     static constexpr int OUT = 0, OUT_SZ = 8 * (R + 6) * P;
     static constexpr int ST = OUT + OUT_SZ, ST_SZ = 2 * (R + 4) * P;
-    static constexpr int CSM = ST + ST_SZ, CSM_SZ = 2 * (R + 2) * P;
-    static constexpr int U = CSM + CSM_SZ, U_SZ = 8 * (R + 4) * P;
-    static constexpr int X = U + U_SZ, X_SZ = 8 * (R + 4) * P;
-    static constexpr int MID = X + X_SZ, MID_SZ = 8 * (R + 2) * P;
-    static constexpr int END = MID + MID_SZ;
-    static constexpr int INNER_SZ = END - X;
-    static constexpr int X_IN = X;   // where the enclosing level's `down` puts this level's input
+    static constexpr int P1 = ST + ST_SZ;
+    static constexpr int MID = P1, MID_SZ = 8 * (R + 2) * P;
+    static constexpr int XU = MID + MID_SZ, XU_SZ = 8 * (R + 4) * P;
+    static constexpr int END = XU + XU_SZ;
+    static constexpr int INNER = P1, INNER_SZ = END - P1;
+    static constexpr int CSM_SZ = 2 * (R + 2) * P, CSM = END - CSM_SZ;
+    static constexpr int X_IN = XU;   // (as an inner block) where the enclosing level's `down` puts this level's input
 };
-// the bottleneck as an inner block: Y (OUT geometry: rows [-3, R + 3)), X rows [-2, R + 2), MID rows [-1, R + 1)
+// the bottleneck as an inner block: Y (OUT geometry: rows [-3, R + 3)), MID rows [-1, R + 1), X rows [-2, R + 2)
 template <int W>
 struct LayB {
     static constexpr int R = W / kG, P = W + 7;
     static constexpr int Y = 0, Y_SZ = 8 * (R + 6) * P;
-    static constexpr int X = Y + Y_SZ, X_SZ = 8 * (R + 4) * P;
-    static constexpr int MID = X + X_SZ, MID_SZ = 8 * (R + 2) * P;
-    static constexpr int END = MID + MID_SZ;
+    static constexpr int MID = Y + Y_SZ, MID_SZ = 8 * (R + 2) * P;
+    static constexpr int X = MID + MID_SZ, X_SZ = 8 * (R + 4) * P;
+    static constexpr int END = X + X_SZ;
     static constexpr int X_IN = X;
 };
-static_assert(Lay<32>::END <= Lay<64>::INNER_SZ && LayB<32>::END <= Lay<64>::INNER_SZ && LayB<16>::END <= Lay<32>::INNER_SZ, "inner blocks must fit");
-static_assert(Lay<64>::X % 4 == 0 && Lay<64>::END % 4 == 0 && Lay<32>::X % 4 == 0 && Lay<32>::END % 4 == 0 && Lay<64>::MID % 4 == 0 && Lay<32>::MID % 4 == 0 &&
-              Lay<32>::OUT_SZ % 4 == 0, "float4 zero fill");
+static_assert(Lay<32>::END <= Lay<64>::INNER_SZ - Lay<64>::CSM_SZ && LayB<32>::END <= Lay<64>::INNER_SZ - Lay<64>::CSM_SZ &&
+              LayB<16>::END <= Lay<32>::INNER_SZ - Lay<32>::CSM_SZ, "inner blocks must fit below conv_state's mid tensor");
+static_assert(Lay<64>::P1 % 4 == 0 && Lay<64>::INNER_SZ % 4 == 0 && Lay<32>::P1 % 4 == 0 && Lay<32>::INNER_SZ % 4 == 0 && Lay<64>::MID_SZ % 4 == 0 && Lay<32>::MID_SZ % 4 == 0 &&
+              Lay<64>::XU_SZ % 4 == 0 && Lay<32>::XU_SZ % 4 == 0 && Lay<32>::OUT_SZ % 4 == 0 && Lay<64>::END % 4 == 0, "float4 zero fill");
 
 template <int W>
 __device__ __forceinline__ Pl plane_at(float* base, int off, int rows_above, int nrows) {
@@ -96,7 +102,7 @@ __device__ __forceinline__ Pl plane_at(float* base, int off, int rows_above, int
 struct DxLevel {
     const float *sig1, *sig1_b, *sig_slope, *sig2, *sig2_b;   // conv_signal: fragments [10][3][64], bias [8], slope [1], [8][3][64], [8]
     const float *st1, *st1_b, *st_slope, *st2, *st2_b;        // conv_state (2 output channels in rows 0..3 of M)
-    const float *down, *down_b;                               // [8][8][64], [8]
+    const float *down, *down_b;                               // pack_frag_down2: [8 ci][2 h][10 kx'][64], [8]
     const float *up, *up_b;                                   // [8][2][4][64], [8]
     const float *dec1, *dec1_b, *dec_slope, *dec2, *dec2_b;   // decoder: [16][3][64], [8][3][64]
     const float* st_in;                                       // the level's state planes of sample slot 0 (strides: DxArgs)
@@ -120,20 +126,32 @@ struct Ctl {   // what every stage needs to know about this workgroup
     unsigned epoch;
     unsigned* flags;   // of this sample: [band][8]
     int* err;
-    bool ok;
 };
 
+typedef unsigned long long u64;
 __device__ __forceinline__ void st_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh2(float* p, float v0, float v1) {   // p 8-byte aligned
+    const u64 bits = (u64)__float_as_uint(v0) | ((u64)__float_as_uint(v1) << 32);
+    __hip_atomic_store(reinterpret_cast<u64*>(p), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 ld_coh2(const float* p) { return __hip_atomic_load(reinterpret_cast<const u64*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// workgroup barrier for LDS hand-overs only: global loads in flight (fragment prefetches) stay in flight across it
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // this band's rows of hand-off h are complete in memory: every thread's write-through stores have been acknowledged, then ONE flag store
 __device__ __forceinline__ void signal(const Ctl& c, int h) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     if (threadIdx.x == 0) __hip_atomic_store(c.flags + c.g * 8 + h, c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // the bands above and below have published hand-off h (every wavefront polls for itself: no barrier behind the wait)
-__device__ __forceinline__ void wait_neighbours(Ctl& c, int h) {
+__device__ __forceinline__ void wait_neighbours(const Ctl& c, int h) {
     const int lane = threadIdx.x & 63;
     const int nb = lane == 0 ? c.g - 1 : c.g + 1;
     const bool need = lane < 2 && nb >= 0 && nb < kG;
@@ -145,7 +163,6 @@ __device__ __forceinline__ void wait_neighbours(Ctl& c, int h) {
         if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
         if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s of the 100 MHz counter: loud, not silent, and nobody hangs
             if (lane == 0 && c.err != nullptr) __hip_atomic_store(c.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            c.ok = false;
             break;
         }
         __builtin_amdgcn_s_sleep(1);
@@ -157,17 +174,52 @@ __device__ __forceinline__ void zero_fill(float* p, int count, int tid) {   // c
     for (int i = tid; i < count / 4; i += kNT) reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// rows [r0, r0 + nr) (band coordinates) of an NCH-channel tensor [.][W][W] of one sample -> LDS; rows outside the image are left alone (zero).
-// COH: the rows are another band's of THIS launch (agent-scope loads)
-template <int W, int NCH, bool COH>
-__device__ __forceinline__ void load_rows(Pl dst, const float* src, long src_sc, int band_row0, int r0, int nr, int tid) {
-    const int total = NCH * nr * W;
-    for (int e = tid; e < total; e += kNT) {
-        const int c = e / (nr * W), rem = e - c * (nr * W), r = rem / W, x = rem - r * W;
-        const int gy = band_row0 + r0 + r;
-        if (gy >= 0 && gy < W) {
-            const float* p = src + (long)c * src_sc + (long)gy * W + x;
-            dst.p[c * dst.plane + (r0 + r) * dst.pitch + x] = COH ? ld_coh(p) : *p;
+// rows [R0, R0 + NR) (band coordinates) of an NCH-channel tensor [.][W][W] of one sample written by an EARLIER kernel -> registers (16-byte loads,
+// issued together) -> LDS.  Rows outside the image are left alone (zero).
+template <int W, int NCH, int R0, int NR>
+struct RowLoad {
+    static constexpr int W4 = W / 4, N4 = NCH * NR * W4, IT = (N4 + kNT - 1) / kNT;
+    float4 v[IT];
+    __device__ __forceinline__ void issue(const float* src, long src_sc, int band_row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int e = tid + i * kNT, c = e / (NR * W4), rem = e - c * (NR * W4), r = rem / W4, x4 = rem - r * W4;
+            const int gy = band_row0 + R0 + r;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < N4 && gy >= 0 && gy < W) v[i] = *reinterpret_cast<const float4*>(src + (long)c * src_sc + (long)gy * W + 4 * x4);
+        }
+    }
+    __device__ __forceinline__ void commit(Pl dst, int band_row0, int tid) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int e = tid + i * kNT, c = e / (NR * W4), rem = e - c * (NR * W4), r = rem / W4, x4 = rem - r * W4;
+            const int gy = band_row0 + R0 + r;
+            if (e < N4 && gy >= 0 && gy < W) {
+                float* d = dst.p + c * dst.plane + (R0 + r) * dst.pitch + 4 * x4;
+                d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+            }
+        }
+    }
+};
+// the HR rows above and below the band of an 8-channel exchange tensor, written by the neighbour bands of THIS launch: agent-scope 8-byte loads -> LDS
+template <int W, int HR>
+__device__ __forceinline__ void load_halo(Pl dst, const float* src, int band_row0, int tid) {
+    constexpr int R = W / kG, W2 = W / 2, N2 = 8 * 2 * HR * W2, IT = (N2 + kNT - 1) / kNT;
+    u64 v[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = tid + i * kNT, c = e / (2 * HR * W2), rem = e - c * (2 * HR * W2), k = rem / W2, x2 = rem - k * W2;
+        const int r = k < HR ? k - HR : R + k - HR, gy = band_row0 + r;
+        v[i] = 0;
+        if (e < N2 && gy >= 0 && gy < W) v[i] = ld_coh2(src + (long)c * W * W + (long)gy * W + 2 * x2);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = tid + i * kNT, c = e / (2 * HR * W2), rem = e - c * (2 * HR * W2), k = rem / W2, x2 = rem - k * W2;
+        const int r = k < HR ? k - HR : R + k - HR, gy = band_row0 + r;
+        if (e < N2 && gy >= 0 && gy < W) {
+            float* d = dst.p + c * dst.plane + r * dst.pitch + 2 * x2;
+            d[0] = __uint_as_float((unsigned)v[i]); d[1] = __uint_as_float((unsigned)(v[i] >> 32));
         }
     }
 }
@@ -178,135 +230,184 @@ __device__ __forceinline__ float activ(float x, float slope, float sel, int act)
 }
 
 // ---- 3x3 convolution of band rows [row0, row0 + NR) from two plane sets (the implicit concatenation), 8 (or 2: rows 0..3 of M) output channels.
-// Task = T rows x 32 columns (W = 64: strip = wave & 1, 4 row groups; W = 32: 8 row groups of one row) or, at W = 16, 2 rows x 16 columns.
-// A task whose rows would pass the end is moved up (it recomputes rows of its neighbour: same values).  emit(r, x, q, v) receives
-// v = {ch 2q: pixels x, x + 1; ch 2q + 1: pixels x, x + 1} of row r.
-template <int W, int NR>
-struct Conv3Map {
-    static constexpr int GROUPS = W == 64 ? 4 : 8;
+// Task = T rows x 32 columns (W = 64: strip = wave & 1, 8 row groups; W = 32: 16 row groups of one row) or, at W = 16, 2 rows x 16 columns.
+// A task whose rows would pass the end is moved up (it recomputes rows of its neighbour: same values).  prefetch() requests the task's A fragments
+// (it may run before the barrier that publishes the input planes); run() -> emit(r, x, q, v), v = {ch 2q: pixels x, x + 1; ch 2q + 1: pixels x, x + 1}.
+template <int W, int NR, int CA, int CB>
+struct Conv3 {
+    static constexpr int GROUPS = W == 64 ? kNW / 2 : kNW;
     static constexpr int T = W == 16 ? 1 : (NR + GROUPS - 1) / GROUPS;     // (W = 16: one task = rows r, r + 1)
     static constexpr int RPT = W == 16 ? 2 : T;                            // rows per task
     static constexpr int NTASK = (NR + RPT - 1) / RPT;                     // row groups that have work
+    static constexpr int C = CA + CB;
+    float af[C][3];
+    int r0, col0;
+    bool active;
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int row0, int wave, int lane) {
+        const int grp = W == 64 ? wave >> 1 : wave;
+        active = grp < NTASK;
+        r0 = row0 + grp * RPT;
+        if (r0 + RPT > row0 + NR) r0 = row0 + NR - RPT;
+        col0 = W == 64 ? 32 * (wave & 1) : 0;
+        if (active) {
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) af[c][dy] = afr[(c * 3 + dy) * 64 + lane];
+        }
+    }
+    template <class Emit>
+    __device__ __forceinline__ void run(Pl a, Pl b, const float (&bias)[2], int lane, Emit emit) {
+        if (!active) return;
+        const int n = lane & 15, q = lane >> 4;
+        // lane's B element of row r: column 2n + q - 1 (+ col0); at W = 16 lane n holds (row r + (n >> 3), pair n & 7)
+        const int boff = W == 16 ? (n >> 3) * a.pitch + 2 * (n & 7) + q - 1 : col0 + 2 * n + q - 1;
+        const int boff_b = W == 16 ? (n >> 3) * b.pitch + 2 * (n & 7) + q - 1 : col0 + 2 * n + q - 1;
+        f32x4 acc[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = (f32x4){bias[0], bias[0], bias[1], bias[1]};
+        float br[2][T + 2];
+        auto rows = [&](int c, float (&dst)[T + 2]) {
+            const float* p = c < CA ? a.p + c * a.plane + (r0 - 1) * a.pitch + boff : b.p + (c - CA) * b.plane + (r0 - 1) * b.pitch + boff_b;
+            const int pitch = c < CA ? a.pitch : b.pitch;
+#pragma unroll
+            for (int j = 0; j < T + 2; ++j) dst[j] = p[j * pitch];
+        };
+        rows(0, br[0]);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if (c + 1 < C) rows(c + 1, br[(c + 1) & 1]);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int j = 0; j < T; ++j) acc[j] = mfma4(af[c][dy], br[c & 1][j + dy], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            const int r = W == 16 ? r0 + (n >> 3) : r0 + j;
+            const int x = W == 16 ? 2 * (n & 7) : col0 + 2 * n;
+            emit(r, x, q, acc[j]);
+        }
+    }
 };
 
-template <int W, int NR, int CA, int CB, class Emit>
-__device__ __forceinline__ void conv3(Pl a, Pl b, const float* __restrict__ afr, const float (&bias)[2], int row0, int wave, int lane, Emit emit) {
-    using M = Conv3Map<W, NR>;
-    constexpr int C = CA + CB, T = M::T;
-    const int n = lane & 15, q = lane >> 4;
-    const int grp = W == 64 ? wave >> 1 : wave;
-    if (grp >= M::NTASK) return;
-    int r0 = row0 + grp * M::RPT;
-    if (r0 + M::RPT > row0 + NR) r0 = row0 + NR - M::RPT;
-    const int col0 = W == 64 ? 32 * (wave & 1) : 0;
-    // lane's B element of row r: column 2n + q - 1 (+ col0); at W = 16 lane n holds (row r + (n >> 3), pair n & 7)
-    const int boff = W == 16 ? (n >> 3) * a.pitch + 2 * (n & 7) + q - 1 : col0 + 2 * n + q - 1;
-    const int boff_b = W == 16 ? (n >> 3) * b.pitch + 2 * (n & 7) + q - 1 : col0 + 2 * n + q - 1;
-    float af[C][3];
+// ---- 8x8 stride-2 convolution, band rows [0, R / 2) of the output (width W / 2) from OUT rows [-3, R + 3).
+//   out[co][Y][X] = b + sum_ci sum_h sum_k sum_kx w[co][ci][4h + k][kx] * in[ci][2Y - 3 + 4h + k][2X - 3 + kx]
+// Packing (pack_frag_down2): K = the 4 rows k of a row half h, N = 16 PAIRS of output columns (X = 2n, 2n + 1: 32 columns per instruction),
+// M = (co, dX): the two columns of a pair read the same input column 4n - 3 + kx' with taps kx = kx' and kx' - 2 (kx' = 0..9: 8 of 10 useful
+// slots, against 1 of 2 in the window form of hn_mfma.hip).  The (ci, h) products of an output are spread over PARTS wavefronts whose partial sums
+// meet in LDS (`part`: the head of the inner block, cleared afterwards); the threads then add up the outputs (+ bias), in a fixed order.
+//   W = 64: task = (row Y, h[, half of the channels]);  W = 32: both rows in N (lane n -> row n >> 3, pair n & 7), task = (h, two channels).
+template <int W>
+struct Down2 {
+    static constexpr int W2 = W / 2, ROWS = W / kG / 2;
+    // W = 64: task = (row Y, h, 1 / SPLIT of the channels): 16 wavefronts 4 channels, 8 wavefronts all 8;  W = 32: both rows in N, task = (h, two channels)
+    static constexpr int SPLIT = W == 64 ? kNW / 8 : 4;
+    static constexpr int NTASK = W == 64 ? 8 * SPLIT : 8, PARTS = 2 * SPLIT, CPT = 8 / SPLIT;   // partial sums per output; channels per task
+    static constexpr int OUTS = 8 * ROWS * W2;                                                  // 1024 / 256
+    static constexpr int PART_SZ = PARTS * OUTS;
+    float af[CPT][10];   // the task's fragments, all requested up front (they come from beyond the L2: the weights do not survive an iteration there)
+    int Y, h, c0, part_id;
+    bool active;
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int wave, int lane) {
+        active = wave < NTASK;
+        if (W == 64) { Y = wave & 3; h = (wave >> 2) & 1; c0 = CPT * (wave >> 3); part_id = h * SPLIT + (wave >> 3); }
+        else { Y = 0; h = wave & 1; c0 = 2 * ((wave >> 1) & 3); part_id = h * 4 + ((wave >> 1) & 3); }
+        if (active) {
 #pragma unroll
-    for (int c = 0; c < C; ++c)
+            for (int cc = 0; cc < CPT; ++cc)
 #pragma unroll
-        for (int dy = 0; dy < 3; ++dy) af[c][dy] = afr[(c * 3 + dy) * 64 + lane];
-    f32x4 acc[T];
-#pragma unroll
-    for (int j = 0; j < T; ++j) acc[j] = (f32x4){bias[0], bias[0], bias[1], bias[1]};
-    float br[2][T + 2];
-    auto rows = [&](int c, float (&dst)[T + 2]) {
-        const float* p = c < CA ? a.p + c * a.plane + (r0 - 1) * a.pitch + boff : b.p + (c - CA) * b.plane + (r0 - 1) * b.pitch + boff_b;
-        const int pitch = c < CA ? a.pitch : b.pitch;
-#pragma unroll
-        for (int j = 0; j < T + 2; ++j) dst[j] = p[j * pitch];
-    };
-    rows(0, br[0]);
-#pragma unroll
-    for (int c = 0; c < C; ++c) {
-        if (c + 1 < C) rows(c + 1, br[(c + 1) & 1]);
-#pragma unroll
-        for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-            for (int j = 0; j < T; ++j) acc[j] = mfma4(af[c][dy], br[c & 1][j + dy], acc[j]);
-    }
-#pragma unroll
-    for (int j = 0; j < T; ++j) {
-        const int r = W == 16 ? r0 + (n >> 3) : r0 + j;
-        const int x = W == 16 ? 2 * (n & 7) : col0 + 2 * n;
-        emit(r, x, q, acc[j]);
-    }
-}
-
-// ---- 8x8 stride-2 convolution, band rows [0, R / 2) of the output (width W / 2) from OUT rows [-3, R + 3) (hn_mfma.hip, k_down_mfma):
-//   P_h[Yw][X] = sum_ci sum_kx sum_{k<4} w[co][ci][4h + k][kx] * in[ci][2 Yw - 3 + k][2 X - 3 + kx];   out[Y][X] = b + P_0[Y][X] + P_1[Y + 2][X]
-// Task = one output row x 16 columns: windows Y and Y + 2.  emit(Y, X, q, v0, v1): channels 2q, 2q + 1 at (Y, X).
-template <int W, class Emit>
-__device__ __forceinline__ void down8(Pl in, const float* __restrict__ afr, const float* __restrict__ bias, int wave, int lane, Emit emit) {
-    constexpr int UNITS = W / 32, ROWS = W / kG / 2;
-    const int n = lane & 15, q = lane >> 4;
-    const int unit = wave % UNITS, Y = wave / UNITS;
-    if (Y >= ROWS) return;
-    const float* b0 = in.p + (2 * Y - 3 + q) * in.pitch + 2 * (16 * unit + n) - 3;
-    const float* b1 = b0 + 4 * in.pitch;   // window Y + 2
-    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-    float af[2][8], bv[2][2];
-#pragma unroll
-    for (int kx = 0; kx < 8; ++kx) af[0][kx] = afr[kx * 64 + lane];
-    bv[0][0] = b0[0]; bv[0][1] = b1[0];
-#pragma unroll
-    for (int u = 0; u < 64; ++u) {
-        const int ci = u >> 3, kx = u & 7;
-        if (u + 1 < 64) {
-            const int c1 = (u + 1) >> 3, k1 = (u + 1) & 7;
-            bv[(u + 1) & 1][0] = b0[c1 * in.plane + k1];
-            bv[(u + 1) & 1][1] = b1[c1 * in.plane + k1];
+                for (int k = 0; k < 10; ++k) af[cc][k] = afr[(((c0 + cc) * 2 + h) * 10 + k) * 64 + lane];
         }
-        if (ci + 1 < 8) af[(ci + 1) & 1][kx] = afr[((ci + 1) * 8 + kx) * 64 + lane];
-        acc0 = mfma4(af[ci & 1][kx], bv[u & 1][0], acc0);
-        acc1 = mfma4(af[ci & 1][kx], bv[u & 1][1], acc1);
     }
-    // D rows of lane (n, q): (co = 2q, h = 0), (2q, 1), (2q + 1, 0), (2q + 1, 1)
-    emit(Y, 16 * unit + n, q, acc0[0] + acc1[1] + bias[2 * q], acc0[2] + acc1[3] + bias[2 * q + 1]);
-}
+    __device__ __forceinline__ void run(Pl in, float* part, int lane) {
+        if (!active) return;
+        const int n = lane & 15, q = lane >> 4;
+        const float* b0 = W == 64 ? in.p + (2 * Y - 3 + 4 * h + q) * in.pitch + 4 * n - 3
+                                  : in.p + (2 * (n >> 3) - 3 + 4 * h + q) * in.pitch + 4 * (n & 7) - 3;
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // two chains (even / odd channel of the task)
+        float bv[2][10];
+#pragma unroll
+        for (int k = 0; k < 10; ++k) bv[0][k] = b0[c0 * in.plane + k];
+#pragma unroll
+        for (int cc = 0; cc < CPT; ++cc) {
+            if (cc + 1 < CPT) {
+#pragma unroll
+                for (int k = 0; k < 10; ++k) bv[(cc + 1) & 1][k] = b0[(c0 + cc + 1) * in.plane + k];
+            }
+#pragma unroll
+            for (int k = 0; k < 10; ++k) acc[cc & 1] = mfma4(af[cc][k], bv[cc & 1][k], acc[cc & 1]);
+        }
+        const f32x4 sum = acc[0] + acc[1];
+        // D rows of lane (n, q): (co = 2q, X = 2n), (2q, 2n + 1), (2q + 1, 2n), (2q + 1, 2n + 1)
+        const int row = W == 64 ? Y : n >> 3, x = W == 64 ? 2 * n : 2 * (n & 7);
+        float* o = part + part_id * OUTS + ((2 * q) * ROWS + row) * W2 + x;
+        *reinterpret_cast<float2*>(o) = make_float2(sum[0], sum[1]);
+        *reinterpret_cast<float2*>(o + ROWS * W2) = make_float2(sum[2], sum[3]);
+    }
+    // (behind a barrier) outputs spread over the threads, added up in a fixed order: LDS plane of the inner block + exchange tensor
+    __device__ __forceinline__ static void reduce(const float* part, const float* __restrict__ bias, Pl xi, float* g_x, int band_row0, int tid) {
+        for (int o = tid; o < OUTS; o += kNT) {
+            const int ch = o / (ROWS * W2), rem = o - ch * (ROWS * W2), row = rem / W2, x = rem - row * W2;
+            float sum = part[o];
+#pragma unroll
+            for (int p = 1; p < PARTS; ++p) sum += part[p * OUTS + o];
+            sum += bias[ch];
+            xi.p[ch * xi.plane + row * xi.pitch + x] = sum;
+            st_coh(g_x + (long)ch * W2 * W2 + (long)(band_row0 + row) * W2 + x, sum);
+        }
+    }
+};
 
 // ---- 8x8 stride-2 transposed convolution, band rows [0, R) of the output (width W) from the input (width W / 2) rows [-2, R / 2 + 3) (k_up_mfma):
 // window row Yw (-1 .. R / 2 - 1) produces output rows 2 Yw + 1 + py from input rows Yw - 1 + a (a = 0..3, the K dimension); output column
-// 2 X + px from input columns X - 2 + px + bb (bb = 0..3).  Task = (16 input columns, px, NROW window rows 2 apart).
+// 2 X + px from input columns X - 2 + px + bb (bb = 0..3).  Task = (16 input columns, px, one window row): 32 instructions.
+//   W = 64: 20 tasks, W = 32: 6: wavefront -> (unit, px, first window), further windows NWG apart
 // emit(yo, xo, q, v[4]): rows yo, yo + 1 (py) of channels 2q (v[0], v[1]) and 2q + 1 (v[2], v[3]) at column xo, bias added; yo may be outside [0, R)
-template <int W, class Emit>
-__device__ __forceinline__ void up8(Pl in, const float* __restrict__ afr, const float* __restrict__ bias, int wave, int lane, Emit emit) {
-    constexpr int UNITS = W / 32;                     // 16-column units of the input
-    constexpr int NROW = W == 64 ? 3 : 1;
-    constexpr int WSTEP = W == 64 ? 2 : 1;            // window rows of a task are WSTEP apart
-    const int n = lane & 15, q = lane >> 4;
-    const int unit = wave % UNITS, px = (wave / UNITS) & 1, wg = wave / (2 * UNITS);
-    const int Yw0 = -1 + wg;                          // W = 64: wg 0 -> -1, 1, 3; wg 1 -> 0, 2, (4: past the band);  W = 32: wg 0..3 -> -1, 0, 1, (2: past the band)
-    const float* bb0 = in.p + (Yw0 - 1 + q) * in.pitch + 16 * unit + n - 2 + px;
-    const float* a0 = afr + px * 4 * 64 + lane;
-    f32x4 acc[NROW];
+template <int W>
+struct Up2 {
+    static constexpr int UNITS = W / 32, NWG = kNW / (2 * UNITS), R2 = W / kG / 2;   // window rows -1 .. R2 - 1 dealt over NWG groups of wavefronts
+    float af[8][4];   // all fragments of (px): every task of this wavefront uses them
+    int unit, px, wg;
+    bool active;
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int wave, int lane) {
+        unit = wave % UNITS; px = (wave / UNITS) & 1; wg = wave / (2 * UNITS);
+        active = -1 + wg < R2;
+        if (active) {
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float af[2][4], bv[2][NROW];
+            for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
-    for (int bb = 0; bb < 4; ++bb) af[0][bb] = a0[bb * 64];
-#pragma unroll
-    for (int k = 0; k < NROW; ++k) bv[0][k] = bb0[WSTEP * k * in.pitch];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) {
-        const int ci = u >> 2, bb = u & 3;
-        if (u + 1 < 32) {
-            const int c1 = (u + 1) >> 2, b1 = (u + 1) & 3;
-#pragma unroll
-            for (int k = 0; k < NROW; ++k) bv[(u + 1) & 1][k] = bb0[c1 * in.plane + WSTEP * k * in.pitch + b1];
+                for (int bb = 0; bb < 4; ++bb) af[ci][bb] = afr[((ci * 2 + px) * 4 + bb) * 64 + lane];
         }
-        if (ci + 1 < 8) af[(ci + 1) & 1][bb] = a0[((ci + 1) * 8 + bb) * 64];
-#pragma unroll
-        for (int k = 0; k < NROW; ++k) acc[k] = mfma4(af[ci & 1][bb], bv[u & 1][k], acc[k]);
     }
-    const float b0 = bias[2 * q], b1 = bias[2 * q + 1];
+    template <class Emit>
+    __device__ __forceinline__ void task(Pl in, const float* __restrict__ bias, int Yw, int lane, Emit emit) {
+        const int n = lane & 15, q = lane >> 4;
+        const float* bb0 = in.p + (Yw - 1 + q) * in.pitch + 16 * unit + n - 2 + px;
+        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        float bv[2][4];
 #pragma unroll
-    for (int k = 0; k < NROW; ++k) {
-        const float v[4] = {acc[k][0] + b0, acc[k][1] + b0, acc[k][2] + b1, acc[k][3] + b1};
-        emit(2 * (Yw0 + WSTEP * k) + 1, 2 * (16 * unit + n) + px, q, v);
+        for (int bb = 0; bb < 4; ++bb) bv[0][bb] = bb0[bb];
+#pragma unroll
+        for (int ci = 0; ci < 8; ++ci) {
+            if (ci + 1 < 8) {
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) bv[(ci + 1) & 1][bb] = bb0[(ci + 1) * in.plane + bb];
+            }
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) acc[ci & 1] = mfma4(af[ci][bb], bv[ci & 1][bb], acc[ci & 1]);
+        }
+        const f32x4 sum = acc[0] + acc[1];
+        const float b0 = bias[2 * q], b1 = bias[2 * q + 1];
+        const float v[4] = {sum[0] + b0, sum[1] + b0, sum[2] + b1, sum[3] + b1};
+        emit(2 * Yw + 1, 2 * (16 * unit + n) + px, q, v);
     }
-}
+    template <class Emit>
+    __device__ __forceinline__ void run(Pl in, const float* __restrict__ bias, int lane, Emit emit) {
+        if (!active) return;
+        for (int Yw = -1 + wg; Yw < R2; Yw += NWG) task(in, bias, Yw, lane, emit);
+    }
+};
 
 // rows [0, R) of an 8-channel band tensor: LDS plane + the global exchange tensor (write-through)
 template <int W>
@@ -316,9 +417,16 @@ __device__ __forceinline__ void put_pair(Pl pl, float* g, int band_row0, int r, 
     l[pl.plane] = v[2]; l[pl.plane + 1] = v[3];
     if (g != nullptr) {
         float* o = g + (long)(2 * q) * W * W + (long)(band_row0 + r) * W + x;
-        st_coh(o, v[0]); st_coh(o + 1, v[1]);
-        st_coh(o + (long)W * W, v[2]); st_coh(o + (long)W * W + 1, v[3]);
+        st_coh2(o, v[0], v[1]);
+        st_coh2(o + (long)W * W, v[2], v[3]);
     }
+}
+template <bool GEN>
+__device__ __forceinline__ void put_mid(Pl mid, int gy, int W, int r, int x, int q, const f32x4& v, float slope, float sel, int act) {
+    const bool in = gy >= 0 && gy < W;   // the mid tensor is zero outside the image (conv2's padding)
+    float* m = mid.p + (2 * q) * mid.plane + r * mid.pitch + x;
+    m[0] = in ? activ<GEN>(v[0], slope, sel, act) : 0.f; m[1] = in ? activ<GEN>(v[1], slope, sel, act) : 0.f;
+    m[mid.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[mid.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
 }
 
 // ---- the bottleneck as an inner block: x (rows [0, R) placed by the enclosing `down`) -> DoubleConv -> Y plane + exchange tensor, hand-off hy
@@ -330,29 +438,26 @@ __device__ void bottleneck(float* base, const DxArgs& a, int act, Ctl& c, const 
     const Pl X = plane_at<W>(base, L::X, 2, R + 4), MID = plane_at<W>(base, L::MID, 1, R + 2), Y = plane_at<W>(base, L::Y, 3, R + 6);
     const int row0 = c.g * R;
     const float inf = __builtin_inff();
+    Conv3<W, R + 2, 8, 0> c1;
+    Conv3<W, R, 8, 0> c2;
     DX_T(32);
+    c1.prefetch(a.bot1, -1, wave, lane);
     wait_neighbours(c, hx);
     DX_T(33);
-    load_rows<W, 8, true>(X, g_x, (long)W * W, row0, -2, 2, tid);
-    load_rows<W, 8, true>(X, g_x, (long)W * W, row0, R, 2, tid);
-    __syncthreads();
+    load_halo<W, 2>(X, g_x, row0, tid);
+    c2.prefetch(a.bot2, 0, wave, lane);
+    lds_barrier();
     DX_T(34);
     {
         const float slope = a.bot_slope[0], sel = slope <= 1.f ? inf : -inf;
         const float bias[2] = {a.bot1_b[2 * q], a.bot1_b[2 * q + 1]};
-        conv3<W, R + 2, 8, 0>(X, X, a.bot1, bias, -1, wave, lane, [&](int r, int x, int qq, const f32x4& v) {
-            const int gy = row0 + r;
-            const bool in = gy >= 0 && gy < W;
-            float* m = MID.p + (2 * qq) * MID.plane + r * MID.pitch + x;
-            m[0] = in ? activ<GEN>(v[0], slope, sel, act) : 0.f; m[1] = in ? activ<GEN>(v[1], slope, sel, act) : 0.f;
-            m[MID.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[MID.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
-        });
+        c1.run(X, X, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
     }
-    __syncthreads();
+    lds_barrier();
     DX_T(35);
     {
         const float bias[2] = {a.bot2_b[2 * q], a.bot2_b[2 * q + 1]};
-        conv3<W, R, 8, 0>(MID, MID, a.bot2, bias, 0, wave, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(Y, g_y, row0, r, x, qq, v); });
+        c2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(Y, g_y, row0, r, x, qq, v); });
     }
     DX_T(36);
     signal(c, hy);
@@ -369,8 +474,8 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     const DxLevel& w = a.lv[li];
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4;
     const Pl OUT = plane_at<W>(base, L::OUT, 3, R + 6), ST = plane_at<W>(base, L::ST, 2, R + 4), CSM = plane_at<W>(base, L::CSM, 1, R + 2),
-             U = plane_at<W>(base, L::U, 2, R + 4), X = plane_at<W>(base, L::X, 2, R + 4), MID = plane_at<W>(base, L::MID, 1, R + 2);
-    float* const inner = base + L::X;
+             U = plane_at<W>(base, L::XU, 2, R + 4), X = U, MID = plane_at<W>(base, L::MID, 1, R + 2);
+    float* const inner = base + L::INNER;
     const int row0 = c.g * R, row0_2 = c.g * R2;
     const float inf = __builtin_inff();
     const int h_out = 4 * li, h_x = 4 * li + 1, h_y = 4 * li + 2, h_u = 4 * li + 3;
@@ -380,59 +485,74 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     float* const g_y = w.g_y + bo2;
     float* const g_u = w.g_u + bo;
     constexpr int TB = OUTER ? 0 : 16;   // (trace slots)
+    (void)TB;
     DX_T(TB + 0);
 
     // ---- inputs: x with 2 halo rows, the level's state with 2 halo rows ----
-    if (OUTER) {
-        load_rows<W, 8, false>(X, a.x_in + bo, (long)W * W, row0, -2, R + 4, tid);
-    } else {
-        wait_neighbours(c, hx_in);
-        DX_T(TB + 1);
-        load_rows<W, 8, true>(X, g_x_in, (long)W * W, row0, -2, 2, tid);
-        load_rows<W, 8, true>(X, g_x_in, (long)W * W, row0, R, 2, tid);
+    Conv3<W, R + 2, 8, 2> s1;
+    Conv3<W, R, 8, 0> s2;
+    {
+        RowLoad<W, 2, -2, R + 4> lst;
+        lst.issue(w.st_in + (long)c.b * a.st_sb, a.st_sc, row0, tid);
+        if (OUTER) {
+            RowLoad<W, 8, -2, R + 4> lx;
+            lx.issue(a.x_in + bo, (long)W * W, row0, tid);
+            s1.prefetch(w.sig1, -1, wave, lane);
+            zero_fill(base, L::END, tid);
+            lds_barrier();
+            lx.commit(X, row0, tid);
+        } else {
+            s1.prefetch(w.sig1, -1, wave, lane);
+            wait_neighbours(c, hx_in);
+            DX_T(TB + 1);
+            load_halo<W, 2>(X, g_x_in, row0, tid);
+        }
+        lst.commit(ST, row0, tid);
     }
-    load_rows<W, 2, false>(ST, w.st_in + (long)c.b * a.st_sb, a.st_sc, row0, -2, R + 4, tid);
-    __syncthreads();
+    s2.prefetch(w.sig2, 0, wave, lane);
+    lds_barrier();
     DX_T(TB + 2);
 
     // ---- out = conv_signal(cat[x, state]) ----
     {
         const float slope = w.sig_slope[0], sel = slope <= 1.f ? inf : -inf;
         const float bias[2] = {w.sig1_b[2 * q], w.sig1_b[2 * q + 1]};
-        conv3<W, R + 2, 8, 2>(X, ST, w.sig1, bias, -1, wave, lane, [&](int r, int x, int qq, const f32x4& v) {
-            const int gy = row0 + r;
-            const bool in = gy >= 0 && gy < W;   // the mid tensor is zero outside the image (conv2's padding)
-            float* m = MID.p + (2 * qq) * MID.plane + r * MID.pitch + x;
-            m[0] = in ? activ<GEN>(v[0], slope, sel, act) : 0.f; m[1] = in ? activ<GEN>(v[1], slope, sel, act) : 0.f;
-            m[MID.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[MID.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
-        });
+        s1.run(X, ST, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
     }
-    __syncthreads();
+    lds_barrier();
     DX_T(TB + 3);
+    Down2<W> dn;
     {
         const float bias[2] = {w.sig2_b[2 * q], w.sig2_b[2 * q + 1]};
-        conv3<W, R, 8, 0>(MID, MID, w.sig2, bias, 0, wave, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(OUT, g_out, row0, r, x, qq, v); });
+        s2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(OUT, g_out, row0, r, x, qq, v); });
     }
+    dn.prefetch(w.down, wave, lane);
     DX_T(TB + 4);
-    signal(c, h_out);                       // (its barrier: x and the mid tensor are dead, out's band rows are visible)
-    zero_fill(inner, L::INNER_SZ, tid);     // the inner block's planes: fresh zero borders
+    lds_barrier();                          // x and the mid tensor are dead
+    zero_fill(inner, L::INNER_SZ, tid);     // the inner block's planes and conv_state's mid tensor: fresh zero borders (while the write-through stores drain)
+    signal(c, h_out);
     DX_T(TB + 5);
     wait_neighbours(c, h_out);
     DX_T(TB + 6);
-    load_rows<W, 8, true>(OUT, g_out, (long)W * W, row0, -3, 3, tid);
-    load_rows<W, 8, true>(OUT, g_out, (long)W * W, row0, R, 3, tid);
-    __syncthreads();
+    load_halo<W, 3>(OUT, g_out, row0, tid);
+    lds_barrier();
     DX_T(TB + 7);
 
-    // ---- x' = down(out): into the inner block's input plane + the exchange tensor ----
+    // ---- x' = down(out): partial sums -> one output per thread -> the inner block's input plane + the exchange tensor ----
+    Conv3<W, R + 2, 8, 2> t1;
+    Conv3<W, R, 2, 0> t2;
     {
-        const Pl XI = plane_at<W2>(inner, K > 1 ? Lay<W2>::X_IN : LayB<W2>::X_IN, 2, R2 + 4);
-        down8<W>(OUT, w.down, w.down_b, wave, lane, [&](int Y, int Xc, int qq, float v0, float v1) {
-            float* l = XI.p + (2 * qq) * XI.plane + Y * XI.pitch + Xc;
-            l[0] = v0; l[XI.plane] = v1;
-            float* o = g_x + (long)(2 * qq) * W2 * W2 + (long)(row0_2 + Y) * W2 + Xc;
-            st_coh(o, v0); st_coh(o + (long)W2 * W2, v1);
-        });
+        constexpr int XIN = K > 1 ? Lay<W2>::X_IN : LayB<W2>::X_IN;
+        static_assert(Down2<W>::PART_SZ <= XIN && Down2<W>::PART_SZ % 4 == 0, "the partial sums lie below the inner block's input plane");
+        float* const part = inner;
+        dn.run(OUT, part, lane);
+        t1.prefetch(w.st1, -1, wave, lane);
+        t2.prefetch(w.st2, 0, wave, lane);
+        lds_barrier();
+        const Pl XI = plane_at<W2>(inner, XIN, 2, R2 + 4);
+        Down2<W>::reduce(part, w.down_b, XI, g_x, row0_2, tid);
+        lds_barrier();
+        zero_fill(part, Down2<W>::PART_SZ, tid);   // (planes of the inner block again)
     }
     DX_T(TB + 8);
     signal(c, h_x);
@@ -441,7 +561,7 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     {
         const float slope = w.st_slope[0], sel = slope <= 1.f ? inf : -inf;
         const float bias[2] = {w.st1_b[0], w.st1_b[1]};
-        conv3<W, R + 2, 8, 2>(OUT, ST, w.st1, bias, -1, wave, lane, [&](int r, int x, int qq, const f32x4& v) {
+        t1.run(OUT, ST, bias, lane, [&](int r, int x, int qq, const f32x4& v) {
             if (qq != 0) return;   // (only rows 0..3 of M are real)
             const int gy = row0 + r;
             const bool in = gy >= 0 && gy < W;
@@ -450,15 +570,15 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
             m[CSM.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[CSM.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
         });
     }
-    __syncthreads();
+    lds_barrier();
     {
         const float bias[2] = {w.st2_b[0], w.st2_b[1]};
         float* const so = w.st_out + (long)c.b * a.st_sb;
-        conv3<W, R, 2, 0>(CSM, CSM, w.st2, bias, 0, wave, lane, [&](int r, int x, int qq, const f32x4& v) {
+        t2.run(CSM, CSM, bias, lane, [&](int r, int x, int qq, const f32x4& v) {
             if (qq != 0) return;
             float* o = so + (long)(row0 + r) * W + x;
-            o[0] = v[0]; o[1] = v[1];
-            o[a.st_sc] = v[2]; o[a.st_sc + 1] = v[3];
+            *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+            *reinterpret_cast<float2*>(o + a.st_sc) = make_float2(v[2], v[3]);
         });
     }
     DX_T(TB + 10);
@@ -466,17 +586,19 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     if constexpr (K > 1) level<W2, K - 1, false, GEN>(inner, a, act, li + 1, c, g_x, h_x, g_y, h_y, tid);
     else bottleneck<W2, GEN>(inner, a, act, c, g_x, g_y, h_x, h_y, tid);
     // ---- u = up(y') ----
+    Conv3<W, R + 2, 8, 8> d1;
     {
         const Pl YI = plane_at<W2>(inner, 0, 3, R2 + 6);
+        Up2<W> up;
+        up.prefetch(w.up, wave, lane);
         DX_T(TB + 11);
+        zero_fill(base + L::XU, L::XU_SZ, tid);     // the upsampled tensor's planes: fresh zero borders (the inner block is dead but for its result, which lies below XU)
         wait_neighbours(c, h_y);
         DX_T(TB + 12);
-        load_rows<W2, 8, true>(YI, g_y, (long)W2 * W2, row0_2, -2, 2, tid);
-        load_rows<W2, 8, true>(YI, g_y, (long)W2 * W2, row0_2, R2, 2, tid);
-        zero_fill(base + L::MID, L::MID_SZ, tid);   // the decoder's mid tensor returns here: fresh zero borders (the inner block's result lies below it)
-        __syncthreads();
+        load_halo<W2, 2>(YI, g_y, row0_2, tid);
+        lds_barrier();
         DX_T(TB + 13);
-        up8<W>(YI, w.up, w.up_b, wave, lane, [&](int yo, int xo, int qq, const float (&v)[4]) {
+        up.run(YI, w.up_b, lane, [&](int yo, int xo, int qq, const float (&v)[4]) {
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 const int y = yo + py;
@@ -490,47 +612,42 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
         });
     }
     DX_T(TB + 14);
+    d1.prefetch(w.dec1, -1, wave, lane);
     signal(c, h_u);
+    zero_fill(base + L::MID, L::MID_SZ, tid);       // the decoder's mid tensor returns to where the inner block's result was: fresh zero borders
     wait_neighbours(c, h_u);
     DX_T(TB + 15);
-    load_rows<W, 8, true>(U, g_u, (long)W * W, row0, -2, 2, tid);
-    load_rows<W, 8, true>(U, g_u, (long)W * W, row0, R, 2, tid);
-    __syncthreads();
-    DX_T(TB + 40 - (OUTER ? 0 : 16) + (OUTER ? 0 : 3));
+    load_halo<W, 2>(U, g_u, row0, tid);
+    Conv3<W, R, 8, 0> d2;
+    d2.prefetch(w.dec2, 0, wave, lane);
+    lds_barrier();
+    DX_T(OUTER ? 40 : 43);
     // ---- y = decode(cat[u, out]) ----
     {
         const float slope = w.dec_slope[0], sel = slope <= 1.f ? inf : -inf;
         const float bias[2] = {w.dec1_b[2 * q], w.dec1_b[2 * q + 1]};
-        conv3<W, R + 2, 8, 8>(U, OUT, w.dec1, bias, -1, wave, lane, [&](int r, int x, int qq, const f32x4& v) {
-            const int gy = row0 + r;
-            const bool in = gy >= 0 && gy < W;
-            float* m = MID.p + (2 * qq) * MID.plane + r * MID.pitch + x;
-            m[0] = in ? activ<GEN>(v[0], slope, sel, act) : 0.f; m[1] = in ? activ<GEN>(v[1], slope, sel, act) : 0.f;
-            m[MID.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[MID.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
-        });
+        d1.run(U, OUT, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
     }
-    __syncthreads();   // (out is dead from here on)
+    lds_barrier();   // (out is dead from here on)
     DX_T(OUTER ? 41 : 44);
     {
         const float bias[2] = {w.dec2_b[2 * q], w.dec2_b[2 * q + 1]};
         if (OUTER) {
             float* const yo = a.y_out + bo;
-            conv3<W, R, 8, 0>(MID, MID, w.dec2, bias, 0, wave, lane, [&](int r, int x, int qq, const f32x4& v) {
+            d2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) {
                 float* o = yo + (long)(2 * qq) * W * W + (long)(row0 + r) * W + x;
-                o[0] = v[0]; o[1] = v[1];
-                o[(long)W * W] = v[2]; o[(long)W * W + 1] = v[3];
+                *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
+                *reinterpret_cast<float2*>(o + (long)W * W) = make_float2(v[2], v[3]);
             });
         } else {
             // the result takes OUT's place (the enclosing `up` reads it there with its halo rows): zero borders first, which needs every
             // thread's zeros to have landed before any band row is written -- so the products are held in registers across a barrier
-            using M = Conv3Map<W, R>;
-            f32x4 keep[M::T];
-            int kr[M::T], kx[M::T], kq = 0, nk = 0;
+            constexpr int T = Conv3<W, R, 8, 0>::T;
+            f32x4 keep[T];
+            int kr[T], kx[T], kq = 0, nk = 0;
             zero_fill(base + L::OUT, L::OUT_SZ, tid);
-            conv3<W, R, 8, 0>(MID, MID, w.dec2, bias, 0, wave, lane, [&](int r, int x, int qq, const f32x4& v) {
-                keep[nk] = v; kr[nk] = r; kx[nk] = x; kq = qq; ++nk;
-            });
-            __syncthreads();
+            d2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) { keep[nk] = v; kr[nk] = r; kx[nk] = x; kq = qq; ++nk; });
+            lds_barrier();
             for (int k = 0; k < nk; ++k) put_pair<W>(OUT, g_y_out, row0, kr[k], kx[k], kq, keep[k]);
             DX_T(45);
             signal(c, hy_out);
@@ -553,12 +670,40 @@ __global__ __launch_bounds__(kNT) void k_deepx(DxArgs a, int act, SyncHook hook)
     if (c.b >= a.batch) return;
     c.flags = a.flags + (long)c.b * (kG * 8);
     c.err = a.err;
-    c.ok = true;
     // the launch's epoch: bands of this sample that have ever ended / 8 + 1 -- the same for all eight (a band ends only after its last
     // hand-off, i.e. after every other band of the sample has read the word at least... read it or will read a value < 8 more)
     c.epoch = __hip_atomic_load(a.done + c.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kG + 1u;
-    zero_fill(lds, Lay<W>::END, tid);
-    __syncthreads();
+    {
+        // The weights do not survive an iteration in the L2 (the level-0 kernels stream > 100 MB through every XCD's 4 MB), so every fragment load of the stages
+        // below would pay the way to HBM -- 2 - 3 us where an L2 hit is a fraction of that [measured: a stage's time followed its count of dependent fragment
+        // fetches].  Touch every fragment line now, one 128-byte line per lane, with LDS-direct loads (no destination register to keep alive):
+        // by the time a stage asks, its lines are in this XCD's L2.
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        // (the junk row: a band row of conv_signal's output plane, written long after these loads have landed -- they precede the first stage's own loads in
+        // the in-order memory counter)
+        float* const junk = lds + Lay<W>::OUT + ((wave >> 3) * (Lay<W>::R + 6) + 3 + (wave & 7)) * Lay<W>::P + kC0;
+        int ins = 0;
+        auto warm = [&](const float* p, int nfloats) {
+            const int lines = nfloats / 32;
+            for (int l0 = 0; l0 < lines; l0 += 64, ++ins)
+                if ((ins & (kNW - 1)) == wave) {
+                    const int l = l0 + lane < lines ? l0 + lane : lines - 1;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 32 * l), (__attribute__((address_space(3))) void*)junk, 4, 0, 0);
+                }
+        };
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const DxLevel& w = a.lv[k];
+            if (k > 0) warm(w.sig1, 10 * 3 * 64);
+            warm(w.sig2, 8 * 3 * 64); warm(w.down, 8 * 2 * 10 * 64); warm(w.st1, 10 * 3 * 64); warm(w.st2, 2 * 3 * 64);
+        }
+        warm(a.bot1, 8 * 3 * 64); warm(a.bot2, 8 * 3 * 64);
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+            const DxLevel& w = a.lv[k];
+            warm(w.up, 8 * 2 * 4 * 64); warm(w.dec1, 16 * 3 * 64); warm(w.dec2, 8 * 3 * 64);
+        }
+    }
     level<W, K, true, GEN>(lds, a, act, 0, c, nullptr, 0, nullptr, 0, tid);
     DX_T(47);
     if (tid == 0) __hip_atomic_fetch_add(a.done + c.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -566,8 +711,23 @@ __global__ __launch_bounds__(kNT) void k_deepx(DxArgs a, int act, SyncHook hook)
 
 }  // namespace
 
+// down conv, weight [8][8][8][8] (co, ci, ky, kx) -> [ci][h][kx' 0..9][64]: lane -> (m = l & 15: co = m >> 1, dX = m & 1; k = l >> 4):
+// w[co][ci][4h + k][kx' - 2 dX], zero where that tap does not exist (Down2 above)
+void pack_frag_down2(const float* w, float* dst) {
+    for (int ci = 0; ci < kFeat; ++ci)
+        for (int h = 0; h < 2; ++h)
+            for (int kp = 0; kp < 10; ++kp)
+                for (int l = 0; l < 64; ++l) {
+                    const int co = (l & 15) >> 1, dX = l & 1, k = l >> 4, kx = kp - 2 * dX;
+                    dst[((ci * 2 + h) * 10 + kp) * 64 + l] = (kx >= 0 && kx < 8) ? w[((co * kFeat + ci) * 8 + 4 * h + k) * 8 + kx] : 0.f;
+                }
+}
+
 // which form: 2 = two levels (the last two encoder levels are 64 and 32 wide), 1 = one level (the last encoder level is 64 wide), 0 = not applicable
-int deepx_levels(const hn_ctx* ctx) {
+int deepx_levels(const hn_ctx* ctx, int batch) {
+    // one workgroup per CU (88 KB of LDS): up to ~1.25 rounds of workgroups the launch beats the layers it replaces; beyond that (batch 64: two full rounds)
+    // the per-sample kernel + the layer-by-layer level are ahead [measured, r6: 256^2 x 64 1145 vs 1173 it/s]
+    if (batch > 40) return 0;
     if (ctx->opt_deep < 2 || ctx->precision != HN_PREC_FP32 || ctx->act_kind > HN_ACT_LEAKYRELU || ctx->dx_flags == nullptr) return 0;
     const int n = ctx->tab.n, depth = ctx->depth;
     // (at least one level above the fused ones: the decoder's output buffer of level 0 does not exist -- decode_0 ends in the wavefield update)
@@ -586,7 +746,7 @@ int launch_deepx(hn_ctx* ctx, int K, const float* states_in, float* states_out, 
         DxLevel& w = a.lv[k];
         w.sig1 = ctx->f_sig[d][0]; w.sig1_b = ctx->sig[d].b1; w.sig_slope = ctx->sig[d].slope; w.sig2 = ctx->f_sig[d][1]; w.sig2_b = ctx->sig[d].b2;
         w.st1 = ctx->f_st[d][0]; w.st1_b = ctx->st[d].b1; w.st_slope = ctx->st[d].slope; w.st2 = ctx->f_st[d][1]; w.st2_b = ctx->st[d].b2;
-        w.down = ctx->f_down[d]; w.down_b = ctx->down[d].b;
+        w.down = ctx->f_down2[d]; w.down_b = ctx->down[d].b;
         w.up = ctx->f_up[d]; w.up_b = ctx->up[d].b;
         w.dec1 = ctx->f_dec[d][0]; w.dec1_b = ctx->dec[d].b1; w.dec_slope = ctx->dec[d].slope; w.dec2 = ctx->f_dec[d][1]; w.dec2_b = ctx->dec[d].b2;
         w.st_in = states_in + ctx->state_off[d];

@@ -151,6 +151,7 @@ struct hn_ctx {
     float* fragdev = nullptr;
     const float *f_inc[2]{}, *f_sig[hn::kMaxDepth][2]{}, *f_dec[hn::kMaxDepth + 1][2]{};
     const float *f_down[hn::kMaxDepth]{}, *f_up[hn::kMaxDepth]{};
+    const float* f_down2[hn::kMaxDepth]{};   // the 8x8 stride-2 convolution again in the column-pair packing of hn_deepx.hip: [8 ci][2 h][10 kx'][64]
     const float *f_dec0c = nullptr, *dec0c_b = nullptr;   // decode[0] conv2 composed with the out-conv: [8][5][64] row-triple fragments, bias [2]
     const float* v_dec0c = nullptr;   // the same composed convolution for the vector-pipe kernel: [8 cm][3][3][2] (hn_dcv.hip)
     const float* f_st[hn::kMaxDepth][2]{};   // conv_state (2 output channels in rows 0..3 of M): [10][3][64], [2][3][64] (hn_deep.hip)
@@ -478,7 +479,8 @@ int launch_deep(hn_ctx* ctx, const float* x_in, long x_sb, const float* st_in, f
                 long y_sb, int batch, hipStream_t s, SyncHook hook = SyncHook{});
 
 // ---- the last one or two levels + bottleneck with eight workgroups per sample (hn_deepx.hip) ----
-int deepx_levels(const hn_ctx* ctx);   // 2 / 1 / 0: levels the kernel would fuse for the current domain, options and precision
+void pack_frag_down2(const float* w_oihw, float* dst);   // -> [8 ci][2 h][10 kx'][64]
+int deepx_levels(const hn_ctx* ctx, int batch);   // 2 / 1 / 0: levels the kernel would fuse for the current domain, options and precision
 int launch_deepx(hn_ctx* ctx, int levels, const float* states_in, float* states_out, int ws_off, int batch, hipStream_t s, SyncHook hook = SyncHook{});
 
 // ---- unet (hn_unet.hip) ----

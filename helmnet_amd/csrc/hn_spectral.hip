@@ -543,7 +543,14 @@ __device__ __forceinline__ void dft8(v2 (&x)[8]) {
 }
 
 constexpr int kE1 = 36;            // exchange 1: slot q * 36 + t (reads a + 8 b of rows 2 qp, 2 qp + 1: four 8-lane groups on disjoint bank quarters)
-constexpr int kE2 = 9;             // exchange 2: slot (q + 8 c) * 9 + a (32 lanes, stride 18 dwords: conflict-free)
+// exchange 2: slot (q + 8 c) * 9 + a: the 32 lanes of a read (stride 9 float2) are conflict-free; a 16-lane group of the WRITE (ds_write_b64: 16 lanes over
+// 32 banks, MI355X_MICROARCH.md) has lanes (qp, a) and (qp + 1, a - 2) on one bank pair -- the 1.57 conflict cycles per LDS instruction of the r5 counters.
+// [measured, r6: profiles/r6_spectral_ab.txt] a layout free of conflicts both ways (8-slot rows, parity swap + rotation by u >> 2) LOSES: its eight reads
+// and writes per transform no longer share one address register with immediate offsets (28.4 -> 33.4 us per residual at 256^2 x 32, 66.5 -> 82 at
+// 512^2 x 16, where the kernel sits at its register limit); the conflicts are ~0.6 us of LDS time per launch.  Requesting the row's other operands
+// (column-pass partial, k_sq, source) in the first round trip instead of after the transforms is no faster either (29.2 vs 28.0 us; 71.7 vs 66.3 at 512,
+// where it costs the fourth wavefront per SIMD): the pass is bound by its ~10 us of vector arithmetic per wavefront quartet, not by that second trip.
+constexpr int kE2 = 9;
 constexpr int kReg8 = 8 * kE1;     // float2 per transform region (= 32 * kE2)
 
 struct Tw8 {

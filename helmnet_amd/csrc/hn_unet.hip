@@ -483,7 +483,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     }
     // the deepest level (32 x 32) and the bottleneck run as one per-sample kernel (hn_deep.hip) where they fit LDS
     // ... or the last one / two levels and the bottleneck as one launch with eight workgroups per sample (hn_deepx.hip)
-    const int deepx = mfma ? deepx_levels(ctx) : 0;
+    const int deepx = mfma ? deepx_levels(ctx, batch) : 0;
     const bool deep = mfma && deepx == 0 && deep_applies(ctx);
     const int n_enc = deepx ? depth - deepx : deep ? depth - 1 : depth;   // encoder levels launched layer by layer
     // conv_state_d (architectures.py:248) feeds nothing in this iteration, so with a side stream it leaves the main
@@ -546,6 +546,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     if (flags) ++ctx->flag_sync_iterations;
     ctx->dca_dec_pad = rel_flag ? 7168 : 0;   // (the gate wave is resident while decode_0 runs: hn_dca.hip, launch_dc_asm)
     if (rel_flag) { rel_hook.store = ctx->sync_flags; rel_hook.store_epoch = sync_epoch; }
+    // which kernel carries the release: the deep kernel (its start = everything before it is complete), or -- experiment, HN_EXP_REL_DOWN=1 -- the last
+    // layer-by-layer `down`, one kernel earlier (conv_signal of every level launched layer by layer is complete when it starts)
+    static const bool rel_on_down = getenv("HN_EXP_REL_DOWN") != nullptr && std::atoi(getenv("HN_EXP_REL_DOWN")) != 0;
+    const bool rel_early = rel_flag && rel_on_down && deepx != 0 && n_enc >= 1;
     if (flags) { join_hook.wait = ctx->sync_flags + 32; join_hook.wait_epoch = sync_epoch; join_hook.err = ctx->sync_err_dev; }
     for (int d = 0; d < n_enc; ++d) {
         const int m = n >> d;
@@ -575,13 +579,14 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         {
             ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
             HN_REP(KID_DOWN0 + 3 * d)
-            if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
+            if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s,
+                                  rel_early && d == n_enc - 1 ? rel_hook : SyncHook{});
             else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
                                     dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                                     ctx->down[d], m, m);
         }
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
-        if (policy == 1 && d == n_enc - 1 && !rel_flag) {
+        if (policy == 1 && d == n_enc - 1 && (!rel_flag || rel_early)) {
             int rc = release_states(0, n_enc, side_lane->ev[0]);
             if (rc != HN_OK) return rc;
         }
@@ -590,10 +595,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         {
             ProfScope ps(ctx, KID_DEEP, s);
             int rc = HN_OK;
-            HN_REP(KID_DEEP) rc = launch_deepx(ctx, deepx, states_in, states_out, ws_off, batch, s, rel_hook);
+            HN_REP(KID_DEEP) rc = launch_deepx(ctx, deepx, states_in, states_out, ws_off, batch, s, rel_early ? SyncHook{} : rel_hook);
             if (rc != HN_OK) return rc;
         }
-        if (rel_flag) {
+        if (rel_flag && !rel_early) {
             int rc = release_states(0, n_enc, nullptr);
             if (rc != HN_OK) return rc;
         }

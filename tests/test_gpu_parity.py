@@ -689,3 +689,78 @@ def test_histories_written_in_place_are_bit_identical_to_copied_ones(n, b, k):
             assert torch.allclose(a, c, rtol=1e-5)
         else:
             assert torch.equal(a, c), i
+
+
+@pytest.mark.parametrize("n,b", [(256, 3), (256, 9), (512, 2), (1024, 1)])
+def test_deep_levels_on_eight_workgroups_per_sample_match_the_layer_by_layer_path(weights, n, b):
+    """hn_deepx.hip (HN_OPT_DEEP 2, the default): the last two levels + bottleneck (256: 64^2, 32^2, 16^2) or the last level + bottleneck (512: 64^2, 32^2) as
+    ONE launch in which eight workgroups per sample exchange halo rows through flag-guarded global memory -- against the same layers launched one by one
+    (HN_OPT_DEEP 0) and against the oracle: wavefield, residual and every level's new hidden state after one teacher-forced step.  Repeated evaluations (the
+    hand-off epochs advance on the device) reproduce the bits; batch 9 leaves XCD groups partly empty; 1024 (deepest level 128) does not apply and must fall
+    back silently."""
+    from helmnet_amd import IterativeSolver
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=556).items()}
+    loc = SRC.get(n, [n // 8, n // 2])
+    outs = {}
+    for deep in (2, 0):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=loc)
+        s.engine().set_option("deep", deep)
+        g = {k: v.to(DEV) for k, v in ti.items()}
+        k_sq, _ = s.get_initials(g["sos"])
+        runs = []
+        for _ in range(3):
+            s.f.set_states(g["states"], flatten=True)
+            wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
+            runs.append((wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu()))
+        for r in runs[1:]:
+            assert all(torch.equal(x, y) for x, y in zip(r, runs[0]))
+        outs[deep] = runs[0]
+        prof = s.engine()
+        prof.profile_enable(None)
+        s.f.set_states(g["states"], flatten=True)
+        s.single_step(g["wf"], k_sq, g["res"])
+        torch.cuda.synchronize()
+        names = set(prof.profile_collect())
+        prof.profile_enable([])
+        prof.check_async_errors()
+        assert ("deep" in names) == (deep == 2 and n in (256, 512)), names
+    for a, c in zip(outs[2], outs[0]):
+        assert (a - c).abs().max().item() <= 4e-6 * c.abs().max().item()
+    if n <= 512:
+        t = O.SpectralTables(n, 8, 2, 1.0)
+        k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+        want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, loc, 10.0), t)
+        want = (want[0], want[1], O.flatten_states(want[2]))
+        for a, w in zip(outs[2], want):
+            assert (a - w).abs().max().item() <= 1e-5 * w.abs().max().item()
+        off = 0
+        for d in range(4):     # every level's slice of the new hidden state on its own scale (levels 2 / 3 are written by the fused kernel)
+            m = (n >> d) ** 2
+            sl = slice(off, off + m)
+            assert (outs[2][2][:, :, sl] - want[2][:, :, sl]).abs().max().item() <= 1e-5 * want[2][:, :, sl].abs().max().item(), d
+            off += m
+
+
+def test_deep_level_kernel_under_lanes_replay_and_batch_changes():
+    """The hand-off epochs of hn_deepx.hip live on the device, one counter per sample slot: two pipeline lanes (other slots), a captured iteration replayed
+    (the same kernel arguments every time) and a solver whose batch size changes between calls all give the bits of the plain loop."""
+    from helmnet_amd import IterativeSolver
+    n = 256
+    sos = torch.from_numpy(ring_sos_batch(n, 10, seed=31)).to(DEV)
+    s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+    s.set_domain_size(n, source_location=SRC[n])
+    eng = s.engine()
+    ref = s.forward(sos, num_iterations=24, residuals="norms")
+    ref_wf, ref_res, ref_st = ref["wavefields"][0].clone(), ref["last_residual"].clone(), s.f.get_states(flatten=True).clone()
+    small = s.forward(sos[:3], num_iterations=24, residuals="norms")          # another batch size on the same context, then back
+    assert torch.equal(small["wavefields"][0], ref_wf[:3])
+    for opt, val in (("lanes", 2), ("graph", 1)):
+        eng.set_option(opt, val)
+        try:
+            o = s.forward(sos, num_iterations=24, residuals="norms")
+            assert torch.equal(o["wavefields"][0], ref_wf) and torch.equal(o["last_residual"], ref_res), opt
+            assert torch.equal(s.f.get_states(flatten=True), ref_st), opt
+        finally:
+            eng.set_option(opt, 1 if opt == "lanes" else 0)
+    eng.check_async_errors()
