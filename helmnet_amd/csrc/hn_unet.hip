@@ -546,10 +546,8 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     if (flags) ++ctx->flag_sync_iterations;
     ctx->dca_dec_pad = rel_flag ? 7168 : 0;   // (the gate wave is resident while decode_0 runs: hn_dca.hip, launch_dc_asm)
     if (rel_flag) { rel_hook.store = ctx->sync_flags; rel_hook.store_epoch = sync_epoch; }
-    // which kernel carries the release: the deep kernel (its start = everything before it is complete), or -- experiment, HN_EXP_REL_DOWN=1 -- the last
-    // layer-by-layer `down`, one kernel earlier (conv_signal of every level launched layer by layer is complete when it starts)
-    static const bool rel_on_down = getenv("HN_EXP_REL_DOWN") != nullptr && std::atoi(getenv("HN_EXP_REL_DOWN")) != 0;
-    const bool rel_early = rel_flag && rel_on_down && deepx != 0 && n_enc >= 1;
+    // (the deep kernel carries the release: its start = everything before it is complete.  [measured, r6: profiles/r6_release_point_ab.txt] the last
+    // layer-by-layer `down` carrying it instead -- the hidden-state kernels one kernel earlier -- loses 2 % at 256^2 x 32 and 512^2 x 16)
     if (flags) { join_hook.wait = ctx->sync_flags + 32; join_hook.wait_epoch = sync_epoch; join_hook.err = ctx->sync_err_dev; }
     for (int d = 0; d < n_enc; ++d) {
         const int m = n >> d;
@@ -579,14 +577,13 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         {
             ProfScope ps(ctx, KID_DOWN0 + 3 * d, s);
             HN_REP(KID_DOWN0 + 3 * d)
-            if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s,
-                                  rel_early && d == n_enc - 1 ? rel_hook : SyncHook{});
+            if (mfma) launch_down(ctx, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1), ctx->f_down[d], ctx->down[d].b, m, m, batch, s);
             else hipLaunchKernelGGL(k_down8x8, dim3(cdiv(m / 2, DownCfg::TW), cdiv(m / 2, DownCfg::TH), batch),
                                     dim3(DownCfg::NT), 0, s, featsrc(ctx->buf_o[d], d), feat(ctx->buf_a[d + 1], d + 1),
                                     ctx->down[d], m, m);
         }
         if (d == 0 && after_down0 != nullptr) HN_HIP(ctx, hipEventRecord(after_down0, s));
-        if (policy == 1 && d == n_enc - 1 && (!rel_flag || rel_early)) {
+        if (policy == 1 && d == n_enc - 1 && !rel_flag) {
             int rc = release_states(0, n_enc, side_lane->ev[0]);
             if (rc != HN_OK) return rc;
         }
@@ -595,10 +592,10 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
         {
             ProfScope ps(ctx, KID_DEEP, s);
             int rc = HN_OK;
-            HN_REP(KID_DEEP) rc = launch_deepx(ctx, deepx, states_in, states_out, ws_off, batch, s, rel_early ? SyncHook{} : rel_hook);
+            HN_REP(KID_DEEP) rc = launch_deepx(ctx, deepx, states_in, states_out, ws_off, batch, s, rel_hook);
             if (rc != HN_OK) return rc;
         }
-        if (rel_flag && !rel_early) {
+        if (rel_flag) {
             int rc = release_states(0, n_enc, nullptr);
             if (rc != HN_OK) return rc;
         }
