@@ -101,7 +101,7 @@ __device__ __forceinline__ Pl plane_at(float* base, int off, int rows_above, int
 
 struct DxLevel {
     const float *sig1, *sig1_b, *sig_slope, *sig2, *sig2_b;   // conv_signal: fragments [10][3][64], bias [8], slope [1], [8][3][64], [8]
-    const float *st1, *st1_b, *st_slope, *st2, *st2_b;        // conv_state (2 output channels in rows 0..3 of M)
+    const float *st1, *st1_b, *st_slope, *st2, *st2_b;        // conv_state on the vector ALU: DcW layout w1 [10][3][3][2], b1 [2], slope [1], w2 [2][3][3][2], b2 [2]
     const float *down, *down_b;                               // pack_frag_down2: [8 ci][2 h][10 kx'][64], [8]
     const float *up, *up_b;                                   // [8][2][4][64], [8]
     const float *dec1, *dec1_b, *dec_slope, *dec2, *dec2_b;   // decoder: [16][3][64], [8][3][64]
@@ -301,9 +301,11 @@ struct Conv3 {
 template <int W>
 struct Down2 {
     static constexpr int W2 = W / 2, ROWS = W / kG / 2;
-    // W = 64: task = (row Y, h, 1 / SPLIT of the channels): 16 wavefronts 4 channels, 8 wavefronts all 8;  W = 32: both rows in N, task = (h, two channels)
-    static constexpr int SPLIT = W == 64 ? kNW / 8 : 4;
-    static constexpr int NTASK = W == 64 ? 8 * SPLIT : 8, PARTS = 2 * SPLIT, CPT = 8 / SPLIT;   // partial sums per output; channels per task
+    // W = 64: task = (NROW rows, h, half of the channels) -- 8 wavefronts: two rows each, so that a fragment (256 bytes per wavefront through the vector
+    // memory path: as scarce here as the matrix core) serves two instructions; 16 wavefronts: one row;  W = 32: both rows in N, task = (h, two channels)
+    static constexpr int SPLIT = W == 64 ? 2 : 4;
+    static constexpr int NROW = W == 64 ? 16 / kNW : 1;
+    static constexpr int NTASK = W == 64 ? kNW : 8, PARTS = 2 * SPLIT, CPT = 8 / SPLIT;   // partial sums per output; channels per task
     static constexpr int OUTS = 8 * ROWS * W2;                                                  // 1024 / 256
     static constexpr int PART_SZ = PARTS * OUTS;
     float af[CPT][10];   // the task's fragments, all requested up front (they come from beyond the L2: the weights do not survive an iteration there)
@@ -311,7 +313,7 @@ struct Down2 {
     bool active;
     __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int wave, int lane) {
         active = wave < NTASK;
-        if (W == 64) { Y = wave & 3; h = (wave >> 2) & 1; c0 = CPT * (wave >> 3); part_id = h * SPLIT + (wave >> 3); }
+        if (W == 64) { h = wave & 1; c0 = CPT * ((wave >> 1) & 1); part_id = h * SPLIT + ((wave >> 1) & 1); Y = NROW * (wave >> 2); }
         else { Y = 0; h = wave & 1; c0 = 2 * ((wave >> 1) & 3); part_id = h * 4 + ((wave >> 1) & 3); }
         if (active) {
 #pragma unroll
@@ -325,25 +327,35 @@ struct Down2 {
         const int n = lane & 15, q = lane >> 4;
         const float* b0 = W == 64 ? in.p + (2 * Y - 3 + 4 * h + q) * in.pitch + 4 * n - 3
                                   : in.p + (2 * (n >> 3) - 3 + 4 * h + q) * in.pitch + 4 * (n & 7) - 3;
-        f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};   // two chains (even / odd channel of the task)
-        float bv[2][10];
+        f32x4 acc[NROW];   // (rows: independent chains)
 #pragma unroll
-        for (int k = 0; k < 10; ++k) bv[0][k] = b0[c0 * in.plane + k];
+        for (int j = 0; j < NROW; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float bv[2][NROW][10];
+#pragma unroll
+        for (int j = 0; j < NROW; ++j)
+#pragma unroll
+            for (int k = 0; k < 10; ++k) bv[0][j][k] = b0[c0 * in.plane + 2 * j * in.pitch + k];
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) {
             if (cc + 1 < CPT) {
 #pragma unroll
-                for (int k = 0; k < 10; ++k) bv[(cc + 1) & 1][k] = b0[(c0 + cc + 1) * in.plane + k];
+                for (int j = 0; j < NROW; ++j)
+#pragma unroll
+                    for (int k = 0; k < 10; ++k) bv[(cc + 1) & 1][j][k] = b0[(c0 + cc + 1) * in.plane + 2 * j * in.pitch + k];
             }
 #pragma unroll
-            for (int k = 0; k < 10; ++k) acc[cc & 1] = mfma4(af[cc][k], bv[cc & 1][k], acc[cc & 1]);
+            for (int k = 0; k < 10; ++k)
+#pragma unroll
+                for (int j = 0; j < NROW; ++j) acc[j] = mfma4(af[cc][k], bv[cc & 1][j][k], acc[j]);
         }
-        const f32x4 sum = acc[0] + acc[1];
         // D rows of lane (n, q): (co = 2q, X = 2n), (2q, 2n + 1), (2q + 1, 2n), (2q + 1, 2n + 1)
-        const int row = W == 64 ? Y : n >> 3, x = W == 64 ? 2 * n : 2 * (n & 7);
-        float* o = part + part_id * OUTS + ((2 * q) * ROWS + row) * W2 + x;
-        *reinterpret_cast<float2*>(o) = make_float2(sum[0], sum[1]);
-        *reinterpret_cast<float2*>(o + ROWS * W2) = make_float2(sum[2], sum[3]);
+#pragma unroll
+        for (int j = 0; j < NROW; ++j) {
+            const int row = W == 64 ? Y + j : n >> 3, x = W == 64 ? 2 * n : 2 * (n & 7);
+            float* o = part + part_id * OUTS + ((2 * q) * ROWS + row) * W2 + x;
+            *reinterpret_cast<float2*>(o) = make_float2(acc[j][0], acc[j][1]);
+            *reinterpret_cast<float2*>(o + ROWS * W2) = make_float2(acc[j][2], acc[j][3]);
+        }
     }
     // (behind a barrier) outputs spread over the threads, added up in a fixed order: LDS plane of the inner block + exchange tensor
     __device__ __forceinline__ static void reduce(const float* part, const float* __restrict__ bias, Pl xi, float* g_x, int band_row0, int tid) {
@@ -427,6 +439,66 @@ __device__ __forceinline__ void put_mid(Pl mid, int gy, int W, int r, int x, int
     float* m = mid.p + (2 * q) * mid.plane + r * mid.pitch + x;
     m[0] = in ? activ<GEN>(v[0], slope, sel, act) : 0.f; m[1] = in ? activ<GEN>(v[1], slope, sel, act) : 0.f;
     m[mid.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[mid.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
+}
+
+// ---- conv_state (DoubleConv 10 -> 2 -> 2) of a band on the vector ALU.  On the matrix core its two output channels fill 4 of the 16 rows of M: 720 + 96
+// instructions per workgroup at W = 64, 4 us; as plain FMAs it is 180 + 36 MACs per pixel at full lane use: [measured, r6] ~1 us.  conv1 -> CSM rows [-1, R + 1)
+// (pairs of pixels per thread; zero outside the image), barrier, conv2 -> the new state in global memory.  Weights through scalar loads (wave-uniform).
+template <int W, bool GEN>
+__device__ __forceinline__ void conv_state_valu(Pl OUT, Pl ST, Pl CSM, const DxLevel& w, float* st_out, long st_sc, int row0, int act, int tid) {
+    constexpr int R = W / kG, W2 = W / 2;
+    const float inf = __builtin_inff();
+    {
+        const float slope = w.st_slope[0], sel = slope <= 1.f ? inf : -inf;
+        const float b0 = w.st1_b[0], b1 = w.st1_b[1];
+        for (int p = tid; p < (R + 2) * W2; p += kNT) {
+            const int r = p / W2 - 1, x = 2 * (p - (r + 1) * W2);
+            float a00 = b0, a01 = b1, a10 = b0, a11 = b1;   // [pixel][channel]
+            auto channel = [&](const float* src, int pitch, const float* wk) {   // wk: [dy][dx][2]
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float v0 = src[dy * pitch], v1 = src[dy * pitch + 1], v2 = src[dy * pitch + 2], v3 = src[dy * pitch + 3];
+                    a00 = fmaf(wk[dy * 6 + 0], v0, a00); a01 = fmaf(wk[dy * 6 + 1], v0, a01); a10 = fmaf(wk[dy * 6 + 0], v1, a10); a11 = fmaf(wk[dy * 6 + 1], v1, a11);
+                    a00 = fmaf(wk[dy * 6 + 2], v1, a00); a01 = fmaf(wk[dy * 6 + 3], v1, a01); a10 = fmaf(wk[dy * 6 + 2], v2, a10); a11 = fmaf(wk[dy * 6 + 3], v2, a11);
+                    a00 = fmaf(wk[dy * 6 + 4], v2, a00); a01 = fmaf(wk[dy * 6 + 5], v2, a01); a10 = fmaf(wk[dy * 6 + 4], v3, a10); a11 = fmaf(wk[dy * 6 + 5], v3, a11);
+                }
+            };
+            // (two channels at a time: the 24 values in flight hide the LDS latency; all 120 at once would cost the registers that let the side stream's
+            // hidden-state kernel share the CU)
+#pragma unroll 2
+            for (int ci = 0; ci < 8; ++ci) channel(OUT.p + ci * OUT.plane + (r - 1) * OUT.pitch + x - 1, OUT.pitch, w.st1 + ci * 18);
+#pragma unroll 2
+            for (int ci = 0; ci < 2; ++ci) channel(ST.p + ci * ST.plane + (r - 1) * ST.pitch + x - 1, ST.pitch, w.st1 + (8 + ci) * 18);
+            const int gy = row0 + r;
+            const bool in = gy >= 0 && gy < W;
+            float* m = CSM.p + r * CSM.pitch + x;
+            m[0] = in ? activ<GEN>(a00, slope, sel, act) : 0.f; m[1] = in ? activ<GEN>(a10, slope, sel, act) : 0.f;
+            m[CSM.plane] = in ? activ<GEN>(a01, slope, sel, act) : 0.f; m[CSM.plane + 1] = in ? activ<GEN>(a11, slope, sel, act) : 0.f;
+        }
+    }
+    lds_barrier();
+    {
+        const float b0 = w.st2_b[0], b1 = w.st2_b[1];
+        for (int p = tid; p < R * W2; p += kNT) {
+            const int r = p / W2, x = 2 * (p - r * W2);
+            float a00 = b0, a01 = b1, a10 = b0, a11 = b1;
+#pragma unroll
+            for (int ci = 0; ci < 2; ++ci) {
+                const float* src = CSM.p + ci * CSM.plane + (r - 1) * CSM.pitch + x - 1;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float v0 = src[dy * CSM.pitch], v1 = src[dy * CSM.pitch + 1], v2 = src[dy * CSM.pitch + 2], v3 = src[dy * CSM.pitch + 3];
+                    const float* wk = w.st2 + (ci * 3 + dy) * 6;
+                    a00 = fmaf(wk[0], v0, a00); a01 = fmaf(wk[1], v0, a01); a10 = fmaf(wk[0], v1, a10); a11 = fmaf(wk[1], v1, a11);
+                    a00 = fmaf(wk[2], v1, a00); a01 = fmaf(wk[3], v1, a01); a10 = fmaf(wk[2], v2, a10); a11 = fmaf(wk[3], v2, a11);
+                    a00 = fmaf(wk[4], v2, a00); a01 = fmaf(wk[5], v2, a01); a10 = fmaf(wk[4], v3, a10); a11 = fmaf(wk[5], v3, a11);
+                }
+            }
+            float* o = st_out + (long)(row0 + r) * W + x;
+            *reinterpret_cast<float2*>(o) = make_float2(a00, a10);
+            *reinterpret_cast<float2*>(o + st_sc) = make_float2(a01, a11);
+        }
+    }
 }
 
 // ---- the bottleneck as an inner block: x (rows [0, R) placed by the enclosing `down`) -> DoubleConv -> Y plane + exchange tensor, hand-off hy
@@ -539,15 +611,11 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     DX_T(TB + 7);
 
     // ---- x' = down(out): partial sums -> one output per thread -> the inner block's input plane + the exchange tensor ----
-    Conv3<W, R + 2, 8, 2> t1;
-    Conv3<W, R, 2, 0> t2;
     {
         constexpr int XIN = K > 1 ? Lay<W2>::X_IN : LayB<W2>::X_IN;
         static_assert(Down2<W>::PART_SZ <= XIN && Down2<W>::PART_SZ % 4 == 0, "the partial sums lie below the inner block's input plane");
         float* const part = inner;
         dn.run(OUT, part, lane);
-        t1.prefetch(w.st1, -1, wave, lane);
-        t2.prefetch(w.st2, 0, wave, lane);
         lds_barrier();
         const Pl XI = plane_at<W2>(inner, XIN, 2, R2 + 4);
         Down2<W>::reduce(part, w.down_b, XI, g_x, row0_2, tid);
@@ -558,29 +626,7 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     signal(c, h_x);
     DX_T(TB + 9);
     // ---- state = conv_state(cat[out, state]) (feeds nothing in this iteration: it fills the wait for the neighbours' x') ----
-    {
-        const float slope = w.st_slope[0], sel = slope <= 1.f ? inf : -inf;
-        const float bias[2] = {w.st1_b[0], w.st1_b[1]};
-        t1.run(OUT, ST, bias, lane, [&](int r, int x, int qq, const f32x4& v) {
-            if (qq != 0) return;   // (only rows 0..3 of M are real)
-            const int gy = row0 + r;
-            const bool in = gy >= 0 && gy < W;
-            float* m = CSM.p + r * CSM.pitch + x;
-            m[0] = in ? activ<GEN>(v[0], slope, sel, act) : 0.f; m[1] = in ? activ<GEN>(v[1], slope, sel, act) : 0.f;
-            m[CSM.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[CSM.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
-        });
-    }
-    lds_barrier();
-    {
-        const float bias[2] = {w.st2_b[0], w.st2_b[1]};
-        float* const so = w.st_out + (long)c.b * a.st_sb;
-        t2.run(CSM, CSM, bias, lane, [&](int r, int x, int qq, const f32x4& v) {
-            if (qq != 0) return;
-            float* o = so + (long)(row0 + r) * W + x;
-            *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
-            *reinterpret_cast<float2*>(o + a.st_sc) = make_float2(v[2], v[3]);
-        });
-    }
+    conv_state_valu<W, GEN>(OUT, ST, CSM, w, w.st_out + (long)c.b * a.st_sb, a.st_sc, row0, act, tid);
     DX_T(TB + 10);
     // ---- the level below, or the bottleneck: result in the inner block's first plane set (OUT geometry at W / 2) and in g_y ----
     if constexpr (K > 1) level<W2, K - 1, false, GEN>(inner, a, act, li + 1, c, g_x, h_x, g_y, h_y, tid);
@@ -662,11 +708,13 @@ __global__ __launch_bounds__(kNT) void k_deepx(DxArgs a, int act, SyncHook hook)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     sync_hook_begin(hook);   // (flag sync: releases the hidden-state kernels of the larger levels on the side stream, hn_internal.h)
     const int tid = threadIdx.x;
-    // block -> (sample, band): the eight bands of a sample on one XCD (block i runs on XCD i % 8)
-    const int i = blockIdx.x, xcd = i & 7, j = i >> 3;
+    // block -> (sample, band): the eight bands of a sample on one XCD (block i runs on XCD i % 8), and XCD x takes the samples [x nb8, (x + 1) nb8) --
+    // the run of samples whose tiles the XCD-aware order of the kernels before and after this one gives to the same XCD (hn_internal.h, xcd_tile):
+    // the input was written, and the output will be read, through this L2
+    const int i = blockIdx.x, xcd = i & 7, j = i >> 3, nb8 = (a.batch + 7) >> 3;
     Ctl c;
     c.g = j & 7;
-    c.b = xcd + 8 * (j >> 3);
+    c.b = xcd * nb8 + (j >> 3);
     if (c.b >= a.batch) return;
     c.flags = a.flags + (long)c.b * (kG * 8);
     c.err = a.err;
@@ -695,7 +743,7 @@ __global__ __launch_bounds__(kNT) void k_deepx(DxArgs a, int act, SyncHook hook)
         for (int k = 0; k < K; ++k) {
             const DxLevel& w = a.lv[k];
             if (k > 0) warm(w.sig1, 10 * 3 * 64);
-            warm(w.sig2, 8 * 3 * 64); warm(w.down, 8 * 2 * 10 * 64); warm(w.st1, 10 * 3 * 64); warm(w.st2, 2 * 3 * 64);
+            warm(w.sig2, 8 * 3 * 64); warm(w.down, 8 * 2 * 10 * 64);
         }
         warm(a.bot1, 8 * 3 * 64); warm(a.bot2, 8 * 3 * 64);
 #pragma unroll
@@ -745,7 +793,7 @@ int launch_deepx(hn_ctx* ctx, int K, const float* states_in, float* states_out, 
         const int d = d0 + k;
         DxLevel& w = a.lv[k];
         w.sig1 = ctx->f_sig[d][0]; w.sig1_b = ctx->sig[d].b1; w.sig_slope = ctx->sig[d].slope; w.sig2 = ctx->f_sig[d][1]; w.sig2_b = ctx->sig[d].b2;
-        w.st1 = ctx->f_st[d][0]; w.st1_b = ctx->st[d].b1; w.st_slope = ctx->st[d].slope; w.st2 = ctx->f_st[d][1]; w.st2_b = ctx->st[d].b2;
+        w.st1 = ctx->st[d].w1; w.st1_b = ctx->st[d].b1; w.st_slope = ctx->st[d].slope; w.st2 = ctx->st[d].w2; w.st2_b = ctx->st[d].b2;
         w.down = ctx->f_down2[d]; w.down_b = ctx->down[d].b;
         w.up = ctx->f_up[d]; w.up_b = ctx->up[d].b;
         w.dec1 = ctx->f_dec[d][0]; w.dec1_b = ctx->dec[d].b1; w.dec_slope = ctx->dec[d].slope; w.dec2 = ctx->f_dec[d][1]; w.dec2_b = ctx->dec[d].b2;

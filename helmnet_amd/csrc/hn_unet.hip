@@ -547,7 +547,8 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     ctx->dca_dec_pad = rel_flag ? 7168 : 0;   // (the gate wave is resident while decode_0 runs: hn_dca.hip, launch_dc_asm)
     if (rel_flag) { rel_hook.store = ctx->sync_flags; rel_hook.store_epoch = sync_epoch; }
     // (the deep kernel carries the release: its start = everything before it is complete.  [measured, r6: profiles/r6_release_point_ab.txt] the last
-    // layer-by-layer `down` carrying it instead -- the hidden-state kernels one kernel earlier -- loses 2 % at 256^2 x 32 and 512^2 x 16)
+    // layer-by-layer `down` carrying it instead -- the hidden-state kernels one kernel earlier -- loses 2 % at 256^2 x 32 and 512^2 x 16; conv_state_0 alone
+    // released by down_0 (a matrix-core kernel with registers, LDS and bandwidth to spare) loses 2.5 %: it runs on into conv_signal_1, profiles/r6_cs_split_ab.txt)
     if (flags) { join_hook.wait = ctx->sync_flags + 32; join_hook.wait_epoch = sync_epoch; join_hook.err = ctx->sync_err_dev; }
     for (int d = 0; d < n_enc; ++d) {
         const int m = n >> d;
