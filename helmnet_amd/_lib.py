@@ -21,7 +21,7 @@ _lib = None
 HN_ACT = {"prelu": 0, "relu": 1, "leakyrelu": 2, "celu": 3, "tanh": 4, "gelu": 5, "tanhshrink": 6, "softplus": 7}
 # enum hn_precision / hn_option / hn_counter of include/helmnet_hip.h
 HN_PRECISION = {"fp32": 0, "bf16x3": 1, "fp16": 2, "bf16x2": 3, "valu": 4}
-HN_OPTION = {"lanes": 0, "side_stream": 1, "deep": 3, "spectral_pfa": 4, "spectral_radix16": 5, "dc_valu": 6, "spectral_cols": 7, "train_fused": 10, "train_overlap": 11, "dc_pair": 12, "side_sync": 13, "state_kernel": 14, "hist_copy": 15,
+HN_OPTION = {"lanes": 0, "side_stream": 1, "deep": 3, "spectral_pfa": 4, "spectral_radix16": 5, "dc_valu": 6, "spectral_cols": 7, "train_fused": 10, "train_overlap": 11, "dc_pair": 12, "side_sync": 13, "state_kernel": 14, "hist_copy": 15, "inc_sigma_map": 16,
              "graph": 100, "train_lanes": 101}   # 100 +: laboratory knobs (HN_EXP_*)
 HN_COUNTER = {"graph_replays": 0, "eager_iterations": 1, "graphs_captured": 2, "stream_probes": 3, "side_candidate": 4, "train_fwd_events": 5, "flag_sync_iterations": 6}
 ABI_VERSION = 7

@@ -187,6 +187,46 @@ int ensure_sync_words(hn_ctx* ctx) {   // flag sync (hn_internal.h): the device 
     return HN_OK;
 }
 
+// The sigma maps are the fifth and sixth input channel of every UNet evaluation the solver makes (hybridnet.py:564-566: cat[wf, 1e3 res, sigmas]) and constants
+// of the domain, so their share of the input layer's first convolution is too: P[co][y][x] = sum_c sum_taps w[co][4 + c][dy][dx] sigma_c[y + dy - 1][x + dx - 1]
+// (zero padding), evaluated in float64 from the fp32 weights and the fp32 maps the device holds, stored as channel pairs [4][n][n] float2 -- zero wherever the
+// 3x3 neighbourhood lies outside the absorbing layer, i.e. farther than `band` pixels from the border.  Rebuilt whenever weights or domain change.
+int build_inc_sigma_map(hn_ctx* ctx) {
+    (void)hipFree(ctx->inc_sigma_map);
+    ctx->inc_sigma_map = nullptr;
+    ctx->inc_sigma_band = 0;
+    if (!ctx->have_weights || ctx->tab.n == 0 || ctx->tab.sigmas == nullptr) return HN_OK;
+    const int n = ctx->tab.n;
+    const size_t px = (size_t)n * n;
+    std::vector<float> sig(2 * px);
+    HN_HIP(ctx, hipMemcpy(sig.data(), ctx->tab.sigmas, sizeof(float) * 2 * px, hipMemcpyDeviceToHost));
+    std::vector<float> map(8 * px, 0.f);   // [4][n][n][2]
+    int band = 0;
+    for (int y = 0; y < n; ++y)
+        for (int x = 0; x < n; ++x) {
+            double acc[kFeat] = {0, 0, 0, 0, 0, 0, 0, 0};
+            bool any = false;
+            for (int c = 0; c < 2; ++c)
+                for (int dy = 0; dy < 3; ++dy)
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int yy = y + dy - 1, xx = x + dx - 1;
+                        if (yy < 0 || yy >= n || xx < 0 || xx >= n) continue;
+                        const double v = (double)sig[c * px + (size_t)yy * n + xx];
+                        if (v == 0.0) continue;
+                        any = true;
+                        for (int co = 0; co < kFeat; ++co) acc[co] += (double)ctx->inc_w_sigma[(co * 2 + c) * 9 + dy * 3 + dx] * v;
+                    }
+            if (!any) continue;
+            for (int co = 0; co < kFeat; ++co) map[(((size_t)(co >> 1) * n + y) * n + x) * 2 + (co & 1)] = (float)acc[co];
+            const int dist = std::min(std::min(y, n - 1 - y), std::min(x, n - 1 - x)) + 1;   // pixels from the nearest border, counting the border pixel
+            if (dist > band) band = dist;
+        }
+    HN_HIP(ctx, hipMalloc((void**)&ctx->inc_sigma_map, sizeof(float) * 8 * px));
+    HN_HIP(ctx, hipMemcpy(ctx->inc_sigma_map, map.data(), sizeof(float) * 8 * px, hipMemcpyHostToDevice));
+    ctx->inc_sigma_band = band;
+    return HN_OK;
+}
+
 int check_async(hn_ctx* ctx, const char* who) {
     if (ctx->sync_err != nullptr && *ctx->sync_err != 0)
         return fail(ctx, HN_ERR_STATE, "%s: a device-side wait gave up (%s): results since then are incomplete -- destroy the context "
@@ -243,7 +283,7 @@ int hn_create(hn_ctx** out, int device_id) {
     }
     const struct { const char* env; int opt; } knobs[] = {{"HN_STREAMS", HN_OPT_LANES}, {"HN_SIDE_STREAM", HN_OPT_SIDE_STREAM},
                                                             {"HN_GRAPH", HN_EXP_GRAPH}, {"HN_DEEP", HN_OPT_DEEP},
-                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}, {"HN_STATE_KERNEL", HN_OPT_STATE_KERNEL}, {"HN_HIST_COPY", HN_OPT_HIST_COPY}};
+                                                            {"HN_TRAIN_LANES", HN_EXP_TRAIN_LANES}, {"HN_TRAIN_FUSED", HN_OPT_TRAIN_FUSED}, {"HN_TRAIN_OVERLAP", HN_OPT_TRAIN_OVERLAP}, {"HN_DC_VALU", HN_OPT_DC_VALU}, {"HN_DC_PAIR", HN_OPT_DC_PAIR}, {"HN_SIDE_SYNC", HN_OPT_SIDE_SYNC}, {"HN_STATE_KERNEL", HN_OPT_STATE_KERNEL}, {"HN_HIST_COPY", HN_OPT_HIST_COPY}, {"HN_INC_SIGMA_MAP", HN_OPT_INC_SIGMA_MAP}};
     // Counter collection (rocprofv3 --pmc, rocprof -i / ROCP_METRICS) runs ONE kernel at a time across all queues, in an order of the tool's choosing: a kernel that
     // waits for a word another queue's kernel stores may then be the one that runs -- the bounded wait gives up after 2 s and hn_step fails [seen, r5].  Under such
     // a tool the hand-overs stay event packets unless HN_SIDE_SYNC says otherwise (the merged level-0 launch is ONE kernel and is not affected).
@@ -309,6 +349,10 @@ int hn_set_option(hn_ctx* ctx, int option, int value) {
         case HN_OPT_STATE_KERNEL:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_STATE_KERNEL must be 0 or 1 (got %d)", value);
             ctx->opt_state_kernel = value;
+            break;
+        case HN_OPT_INC_SIGMA_MAP:
+            if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_INC_SIGMA_MAP must be 0 or 1 (got %d)", value);
+            ctx->opt_inc_sigma_map = value;
             break;
         case HN_OPT_HIST_COPY:
             if (value < 0 || value > 1) return fail(ctx, HN_ERR_ARG, "HN_OPT_HIST_COPY must be 0 or 1 (got %d)", value);
@@ -377,6 +421,7 @@ void hn_destroy(hn_ctx* ctx) {
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     (void)hipFree(ctx->sync_flags);
+    (void)hipFree(ctx->inc_sigma_map);
     if (ctx->sync_err) (void)hipHostFree(ctx->sync_err);
     for (int j = 0; j < 8; ++j) {
         auto& sl = ctx->side[j];
@@ -421,6 +466,9 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
     std::vector<float> packed(want);
     Packer p{blob, packed, ctx->wdev, act_kind};
     ctx->act_kind = act_kind;
+    for (int co = 0; co < kFeat; ++co)      // inc.conv1.weight [8][6][3][3]: the sigma channels 4, 5 (hn_dca.hip: SigmaMap)
+        for (int c = 0; c < 2; ++c)
+            for (int t = 0; t < 9; ++t) ctx->inc_w_sigma[(co * 2 + c) * 9 + t] = blob[((size_t)co * kInCh + 4 + c) * 9 + t];
     ctx->inc = p.dc(kInCh, kFeat, kFeat);
     for (int d = 0; d < depth; ++d) {
         ctx->sig[d] = p.dc(kFeat + kState, kFeat, kFeat);
@@ -536,7 +584,7 @@ int hn_load_weights(hn_ctx* ctx, const float* blob, size_t n_floats, int feature
         ctx->state_len = 0;
         for (int d = 0; d < depth; ++d) { ctx->state_off[d] = ctx->state_len; ctx->state_len += (int64_t)(ctx->tab.n >> d) * (ctx->tab.n >> d); }
     }
-    return HN_OK;
+    return build_inc_sigma_map(ctx);
 }
 
 int hn_set_domain(hn_ctx* ctx, int n, int pml, float sigma_max, float k) {
@@ -552,7 +600,7 @@ int hn_set_domain(hn_ctx* ctx, int n, int pml, float sigma_max, float k) {
     const int depth = ctx->have_weights ? ctx->depth : 4;
     ctx->state_len = 0;
     for (int d = 0; d < depth; ++d) { ctx->state_off[d] = ctx->state_len; ctx->state_len += (int64_t)(n >> d) * (n >> d); }
-    return HN_OK;
+    return build_inc_sigma_map(ctx);
 }
 
 int hn_get_sigmas(hn_ctx* ctx, float* out, void* stream) {

@@ -92,10 +92,14 @@ __device__ __forceinline__ void conv2_all(f32x2 (&a)[4][4], unsigned mid_addr, c
 // through (sc1 stores), drains them and publishes flags[tile] = epoch; the consumer first waits for the flags of the (up to nine) producer tiles its input
 // window touches and stages with sc1 LDS-direct loads.
 struct PairSync { unsigned* flags; unsigned epoch; int tile, tx, ty, gx, gy; int* err; };   // err: the context's host-mapped sticky error word (nullable)
+// The input layer's sigma channels are constants of the domain (hybridnet.py:564-566), so their share of conv1 is a per-domain map: P[pair c][y][x] =
+// sum over the two sigma channels and the 3x3 taps (float64 on the host, hn_api.hip: build_inc_sigma_map), zero farther than `band` pixels from the border.
+// With it the input layer stages and convolves 4 channels instead of 6; tiles whose mid region touches the band start their even-parity accumulators from it.
+struct SigmaMap { const float2* p; int band; };
 
 template <int CA, int CB, int CC, int EPI, int ROLE>
 __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, Dst out, const DcW& w, const VcEpi& epi, const float* zero_page, int H, int W,
-                                            int b, int x0, int y0, int tr_id, PairSync ps) {
+                                            int b, int x0, int y0, int tr_id, PairSync ps, SigmaMap sm = SigmaMap{nullptr, 0}) {
     constexpr int CIN = CA + CB + CC, NG = CIN / 2;
     static_assert(CIN % 2 == 0 && CA % 2 == 0 && CB % 2 == 0, "a chunk is two channels of one source");
     const int tid = threadIdx.x, lane = tid & 63;
@@ -175,6 +179,27 @@ __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, 
     const unsigned edge0 = 4u * (unsigned)(s * kPlane + (9 * h + (el >> 1)) * kPI + 66 + (el & 1));
     issue(0, 0);
     if (NG > 1) issue(1, 1);
+    // (behind the first two chunks' loads: the map's values travel beside them, and the adds wait for what conv1 waits for anyway)
+    if (CC == 0 && CA == 2 && sm.p != nullptr && s == 0) {   // the sigma channels' share of conv1 (mid rows y0 - 1 .. y0 + 16, columns x0 - 1 .. x0 + 64), border tiles only
+        const bool near = y0 - 1 < sm.band || y0 + 16 >= H - sm.band || x0 - 1 < sm.band || x0 + 64 >= W - sm.band;   // (wave-uniform)
+        if (near) {
+            const long plane2 = (long)H * W;
+            const int xc = min(max(x0 - 1 + lane, 0), W - 1);                 // (positions outside the image are masked when the halves meet: any value will do)
+            const int xe = min(max(x0 + 63 + (el & 1), 0), W - 1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                for (int r = 0; r < 9; ++r) {
+                    const int yc = min(max(y0 - 1 + 9 * h + r, 0), H - 1);
+                    const float2 pv = sm.p[c * plane2 + (long)yc * W + xc];
+                    acc[r][c] += (f32x2){pv.x, pv.y};
+                }
+                const int ye = min(max(y0 - 1 + 9 * h + (el >> 1), 0), H - 1);
+                const float2 pe = sm.p[c * plane2 + (long)ye * W + xe];
+                acce[c] += (f32x2){pe.x, pe.y};
+            }
+        }
+    }
     HN_TR(1);
     {
         int buf = 0;
@@ -354,11 +379,11 @@ __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, 
 }
 
 template <int CA, int CB, int CC, int EPI>
-__global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, const float* zero_page, int H, int W) {
+__global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst out, DcW w, VcEpi epi, const float* zero_page, int H, int W, SigmaMap sm) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const TileId tl = xcd_tile();
     const int tr_id = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191;
-    dc_asm_body<CA, CB, CC, EPI, 0>(lds, sa, sb, sc, out, w, epi, zero_page, H, W, tl.z, tl.x * 64, tl.y * 16, tr_id, PairSync{nullptr, 0u, 0, 0, 0, 0, 0, nullptr});
+    dc_asm_body<CA, CB, CC, EPI, 0>(lds, sa, sb, sc, out, w, epi, zero_page, H, W, tl.z, tl.x * 64, tl.y * 16, tr_id, PairSync{nullptr, 0u, 0, 0, 0, 0, 0, nullptr}, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -376,7 +401,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
 //     kernels as before.  Same arithmetic in the same order as the separate launches: results are bit-identical.
 // ------------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, Dst x0_out, DcW w_inc, Src b0, Src b1, Dst out0, DcW w_sig, const float* zero_page,
-                                                         int H, int W, int gx, int gy, int T, unsigned* flags, unsigned epoch, int* err) {
+                                                         int H, int W, int gx, int gy, int T, unsigned* flags, unsigned epoch, int* err, SigmaMap sm) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const bool second = __builtin_amdgcn_readfirstlane((int)blockIdx.x) >= T;   // wave-uniform
     int tile = second ? (int)blockIdx.x - T : (int)blockIdx.x;
@@ -388,14 +413,16 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, 
     const VcEpi noepi{nullptr, nullptr, nullptr, nullptr};
     const Src none{nullptr, 0, 0, 1.f};
     if (second) dc_asm_body<kFeat, kState, 0, 0, 2>(lds, b0, b1, none, out0, w_sig, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps);
+    else if (sm.p != nullptr) dc_asm_body<2, 2, 0, 0, 1>(lds, a0, a1, none, x0_out, w_inc, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps, sm);   // (sigma channels: the map)
     else dc_asm_body<2, 2, 2, 0, 1>(lds, a0, a1, a2, x0_out, w_inc, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps);
 }
 
 
 // lds_pad: bytes of (unused) dynamic LDS on top of the static 38 KB -- 7 KB make it 3 blocks per CU instead of 4 (launch_dc_asm)
 template <int CA, int CB, int CC, int EPI>
-void launch(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, const float* zero_page, int H, int W, int batch, hipStream_t s, int lds_pad = 0) {
-    hipLaunchKernelGGL((k_dc_asm<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), lds_pad, s, a, b, c, out, w, e, zero_page, H, W);
+void launch(Src a, Src b, Src c, Dst out, const DcW& w, const VcEpi& e, const float* zero_page, int H, int W, int batch, hipStream_t s, int lds_pad = 0,
+            SigmaMap sm = SigmaMap{nullptr, 0}) {
+    hipLaunchKernelGGL((k_dc_asm<CA, CB, CC, EPI>), dim3(cdiv_(W, 64), cdiv_(H, 16), batch), dim3(256), lds_pad, s, a, b, c, out, w, e, zero_page, H, W, sm);
 }
 
 }  // namespace
@@ -409,6 +436,11 @@ void pack_dca(const float* w, int cin, const float* scale, float* dst) {
                 for (int co = 0; co < kFeat; ++co)
                     dst[(((size_t)ci * 3 + kx) * 3 + ky) * kFeat + co] =
                         (float)((double)w[((size_t)co * cin + ci) * 9 + ky * 3 + kx] * (scale ? (double)scale[ci] : 1.0));
+}
+
+// the input layer's third channel group IS the domain's sigma maps (hn_step, hn_unet as the solver calls them: hybridnet.py:564-566) and their conv1 share is at hand
+static bool sigma_map_applies(const hn_ctx* ctx, Src c, int H, int W) {
+    return ctx->opt_inc_sigma_map && ctx->inc_sigma_map != nullptr && c.p == ctx->tab.sigmas && c.sb == 0 && c.sc == (long)H * W && H == ctx->tab.n && W == ctx->tab.n;
 }
 
 bool dc_asm_applies(const hn_ctx* ctx, int act, Src a, Src b, Src c, int kind, int H, int W) {
@@ -431,7 +463,10 @@ void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const Dc
                    int batch, hipStream_t s) {
     const VcEpi e{d_out, wf, ctx->v_dec0c, ctx->dec0c_b, ctx->step_wf_in != nullptr ? ctx->step_wf_in : wf};
     switch (kind) {
-        case 0: launch<2, 2, 2, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;              // inc
+        case 0:                                                                                           // inc
+            if (sigma_map_applies(ctx, c, H, W)) launch<2, 2, 0, 0>(a, b, Src{nullptr, 0, 0, 1.f}, out, w, e, ctx->zero_page, H, W, batch, s, 0, SigmaMap{ctx->inc_sigma_map, ctx->inc_sigma_band});
+            else launch<2, 2, 2, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s);
+            break;
         case 1: launch<kFeat, kState, 0, 0>(a, b, c, out, w, e, ctx->zero_page, H, W, batch, s); break;      // conv_signal
         default:
             // decoder (+ out-conv, wavefield update).  With the side stream's gate wave resident (flag sync, hn_internal.h) the kernel runs at 3 blocks per CU:
@@ -453,8 +488,9 @@ bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Sr
 void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, hipStream_t s) {
     const int gx = cdiv_(W, 64), gy = cdiv_(H, 16), T = gx * gy * batch;
     const unsigned epoch = ++ctx->pair_epoch;
+    const SigmaMap sm = sigma_map_applies(ctx, sig, H, W) ? SigmaMap{ctx->inc_sigma_map, ctx->inc_sigma_band} : SigmaMap{nullptr, 0};
     hipLaunchKernelGGL(k_dc_asm_pair, dim3(2 * T), dim3(256), 0, s, wf, res, sig, x0_out, ctx->inc, x0, st, out0, ctx->sig[0], ctx->zero_page, H, W, gx, gy, T,
-                       ctx->pair_flags, epoch, ctx->sync_err_dev);
+                       ctx->pair_flags, epoch, ctx->sync_err_dev, sm);
 }
 
 }  // namespace hn

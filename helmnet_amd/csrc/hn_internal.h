@@ -208,6 +208,11 @@ struct hn_ctx {
     int dca_dec_pad = 0;       // dynamic LDS of the next decode_0 launch on hn_dca.hip: 7168 (3 blocks per CU) while the gate kernel is resident, else 0
     int* sync_err = nullptr;          // host-mapped: a bounded device-side wait that gave up stores its code here (sticky; checked by hn_step)
     int* sync_err_dev = nullptr;
+    // the sigma channels' share of the input layer's conv1 as a per-domain map (hn_dca.hip: SigmaMap; built by hn_load_weights / hn_set_domain, whichever comes second)
+    float2* inc_sigma_map = nullptr;   // [4 channel pairs][n][n]
+    int inc_sigma_band = 0;            // the map is zero farther than this many pixels from the border
+    float inc_w_sigma[144]{};          // inc.conv1.weight[:, 4:6] ([8][2][3][3], host copy)
+    int opt_inc_sigma_map = 1;         // HN_OPT_INC_SIGMA_MAP: 0 = the input layer convolves its six channels as in r5
     const float* zero_page = nullptr;   // 256 zero bytes (out-of-image float4s of the LDS-direct staging loads, hn_dca.hip)
     const float* outc_w = nullptr;  // [8][2]
     const float* outc_b = nullptr;  // [2]
@@ -495,6 +500,7 @@ int side_join(hn_ctx* ctx, hn_ctx::SideLane* side_lane, hipStream_t s);
 bool side_flags_apply(hn_ctx* ctx, hipStream_t s);
 // flag sync, the side stream's halves (hn_unet.hip): a one-wave kernel that holds stream s until *flag has reached epoch / a one-thread kernel that stores it
 int ensure_sync_words(hn_ctx* ctx);
+int build_inc_sigma_map(hn_ctx* ctx);   // (hn_api.hip; needs weights and domain, synchronises)
 int check_async(hn_ctx* ctx, const char* who);   // HN_ERR_STATE once a bounded device-side wait has given up (sticky word: 1 side-stream flag, 2 merged level-0 launch, 3 deep kernel)
 int zero_async(hn_ctx* ctx, void* p, size_t bytes, hipStream_t s);   // (hn_api.hip: a kernel of this library, never hipMemsetAsync, on a caller's stream)
 void launch_sync_gate(hn_ctx* ctx, const unsigned* flag, unsigned epoch, hipStream_t s);

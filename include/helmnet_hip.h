@@ -116,6 +116,10 @@ enum hn_option {
                               * Bit-identical                                                                                          */
     HN_OPT_HIST_COPY = 15,   /* 0 (default): hn_step's residual / wavefield histories are written in place of the copies (see hn_step); 1: every
                               * iteration works in the caller's wf / res and copies them into the history slots (A/B; bit-identical)       */
+    HN_OPT_INC_SIGMA_MAP = 16, /* 0/1 (default 1): the sigma maps are constants of the domain and two of the six input channels of every UNet evaluation the solver
+                              * makes (hybridnet.py:564-566), so their share of the input layer's first convolution is precomputed per domain (float64 on the
+                              * host, at hn_load_weights / hn_set_domain) and the hand-scheduled input layer (HN_OPT_DC_VALU 3 / 4) convolves four
+                              * channels, adding the map in the tiles near the border (it is zero elsewhere).  Agrees with 0 to fp32 rounding  */
     HN_OPT_SPECTRAL_COLS = 7, /* 256-point column pass: 0 the r2 kernel (16-byte global accesses), 1 (default) / 2: coalesced float4 row
                               * segments transposed through LDS, 16 / 32 columns per workgroup                      */
     HN_OPT_TRAIN_FUSED = 10, /* hn_train_grad: sum of 1 (forward pass: an 8-channel DoubleConv is ONE launch of the fused matrix-core kernels of

@@ -764,3 +764,36 @@ def test_deep_level_kernel_under_lanes_replay_and_batch_changes():
         finally:
             eng.set_option(opt, 1 if opt == "lanes" else 0)
     eng.check_async_errors()
+
+
+@pytest.mark.parametrize("n,b", [(256, 3), (512, 1), (272, 2)])
+def test_input_layer_with_the_sigma_channels_as_a_precomputed_map(weights, n, b):
+    """HN_OPT_INC_SIGMA_MAP: the two sigma channels of the UNet input (hybridnet.py:564-566) are constants of the domain; their share of inc's first convolution
+    is evaluated once per domain in float64 and added in the tiles near the border, the kernel convolving the other four channels.  One teacher-forced step
+    with and without: equal to fp32 rounding (4e-6 of max, the bar between kernel sets), both within 1e-5 of the oracle; a free run of 60 iterations stays
+    within 1e-4.  272 is not a multiple of the 64-pixel tile width (ragged tiles at the right border, where the map is not zero)."""
+    from helmnet_amd import IterativeSolver
+    ti = {k: torch.from_numpy(v) for k, v in teacher_inputs(n, b, seed=77).items()}
+    loc = SRC.get(n, [n // 8, n // 2])
+    outs, runs = {}, {}
+    for m in (1, 0):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+        s.set_domain_size(n, source_location=loc)
+        s.engine().set_option("inc_sigma_map", m)
+        g = {k: v.to(DEV) for k, v in ti.items()}
+        k_sq, _ = s.get_initials(g["sos"])
+        s.f.set_states(g["states"], flatten=True)
+        wf2, res2 = s.single_step(g["wf"], k_sq, g["res"])
+        outs[m] = (wf2.cpu(), res2.cpu(), s.f.get_states(flatten=True).cpu())
+        sos = torch.from_numpy(ring_sos_batch(n, b, seed=78)).to(DEV)
+        runs[m] = s.forward(sos, num_iterations=60, residuals="norms")["wavefields"][0].cpu()
+        s.engine().set_option("inc_sigma_map", 1)
+    t = O.SpectralTables(n, 8, 2, 1.0)
+    k_sq_o, _ = O.get_initials(ti["sos"], 1.0)
+    want = O.single_step(ti["wf"], k_sq_o, ti["res"], O.unflatten_states(ti["states"], n, 4), weights, O.point_source_map(n, loc, 10.0), t)
+    want = (want[0], want[1], O.flatten_states(want[2]))
+    for a, c, w in zip(outs[1], outs[0], want):
+        scale = w.abs().max().item()
+        assert (a - c).abs().max().item() <= 4e-6 * scale
+        assert (a - w).abs().max().item() <= 1e-5 * scale and (c - w).abs().max().item() <= 1e-5 * scale
+    assert (runs[1] - runs[0]).abs().max().item() <= 1e-4
