@@ -89,15 +89,20 @@ ROCPROF_NAME = {"decode0": ("k_dc_asm<8, 8, 0, 1>", "k_dc_valu<8, 8, 0, 1, false
                 "inc": ("k_dc_asm<2, 2, 2, 0>", "k_dc_valu<2, 2, 2, 0, false, false>", "k_dc_valu<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0, false>", "k_dc_mfma_s<2, 2, 2, 0>"),
                 "inc_conv_signal0": ("k_dc_asm_pair",),
                 "conv_signal0": ("k_dc_asm<8, 2, 0, 0>", "k_dc_valu<8, 2, 0, 0, false, false>", "k_dc_mfma_s<8, 2, 0, 0, false>"),
-                "spectral_rows": ("k_spec8_rows", "k_spec_rows<256>"), "spectral_cols": ("k_spec16_cols_t<16>", "k_spec16_cols_t<32>", "k_spec16_cols", "k_spec_cols<256, 16>")}
+                "spectral_rows": ("k_spec8_rows", "k_spec512_rows", "k_spec_rows<256>"),
+                "spectral_cols": ("k_spec16_cols_t<16>", "k_spec512_cols_t", "k_spec16_cols_t<32>", "k_spec16_cols", "k_spec_cols<256, 16>"),
+                "deep": ("k_deepx<64, 2, false>", "k_deepx<64, 1, false>", "k_deep32<false>")}
 
 
 def measured_traffic(kernel: str, n: int, batch: int, precision: str):
-    """HBM bytes per launch from the committed PMC summary (valid for the default fp32 256^2 x 32 workload only)."""
-    if n != 256 or batch != 32 or precision != "fp32" or kernel not in ROCPROF_NAME:
+    """HBM bytes per launch from the committed PMC summary of THIS workload: profiles/r*_traffic.json for the default fp32 256^2 x 32, profiles/r*_512_traffic.json
+    for BASELINE configs[3] (512^2 x 16); None for anything else."""
+    if (n, batch) not in ((256, 32), (512, 16)) or precision != "fp32" or kernel not in ROCPROF_NAME:
         return None, None
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+    import re
+    pat = re.compile(r"r\d+_traffic\.json$" if n == 256 else r"r\d+_512_traffic\.json$")
+    for path in sorted((p for p in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if pat.search(os.path.basename(p))), reverse=True):
         with open(path) as f:
             t = json.load(f)
         for name in ROCPROF_NAME[kernel]:   # the newest summary that knows one of the kernel's names (newest name first)
