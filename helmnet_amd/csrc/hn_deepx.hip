@@ -43,6 +43,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
+// Scheduling: left alone, hipcc sinks every LDS read next to its first use (it minimises registers), which exposes one LDS round trip per group of matrix
+// instructions.  The loops below request the operands of step k + 1 before the instructions of step k; this pins that order: N times (one matrix
+// instruction, one LDS read), then a scheduling barrier (hn_deep.hip does the same).
+template <int N_DS>
+__device__ __forceinline__ void pin_pipeline() {
+#pragma unroll
+    for (int i = 0; i < N_DS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 constexpr int kG = 8;        // bands (workgroups) per sample
 #ifndef HN_DX_NT
 #define HN_DX_NT 512         // (A/B: 1024 = 16 wavefronts)
@@ -114,6 +127,8 @@ struct DxArgs {
     const float *bot1, *bot1_b, *bot_slope, *bot2, *bot2_b;   // bottleneck
     const float* x_in;       // input of the outermost level, [B][8][W][W]
     float* y_out;            // its decoder's output
+    const float* wblob;      // the context's packed weight blob (biases, slopes, conv_state's scalar-load weights live in it), for the L2 warm-up
+    int wblob_floats;
     long st_sb, st_sc;       // strides of the flat hidden state: sample, channel
     unsigned* flags;         // [slot][band][8 hand-offs]
     unsigned* done;          // [slot]: bands of this slot that have ended, ever
@@ -241,23 +256,27 @@ struct Conv3 {
     static constexpr int NTASK = (NR + RPT - 1) / RPT;                     // row groups that have work
     static constexpr int C = CA + CB;
     float af[C][3];
+    float bias[2], slope;   // requested with the fragments: a load at the point of use is a trip to L2 at best, on the stage's critical path
     int r0, col0;
     bool active;
-    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int row0, int wave, int lane) {
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, const float* __restrict__ bias_p, const float* __restrict__ slope_p, int row0, int wave, int lane) {
         const int grp = W == 64 ? wave >> 1 : wave;
         active = grp < NTASK;
         r0 = row0 + grp * RPT;
         if (r0 + RPT > row0 + NR) r0 = row0 + NR - RPT;
         col0 = W == 64 ? 32 * (wave & 1) : 0;
+        slope = 0.f;
         if (active) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy) af[c][dy] = afr[(c * 3 + dy) * 64 + lane];
+            bias[0] = bias_p[2 * (lane >> 4)]; bias[1] = bias_p[2 * (lane >> 4) + 1];
+            if (slope_p != nullptr) slope = slope_p[0];
         }
     }
     template <class Emit>
-    __device__ __forceinline__ void run(Pl a, Pl b, const float (&bias)[2], int lane, Emit emit) {
+    __device__ __forceinline__ void run(Pl a, Pl b, int lane, Emit emit) {
         if (!active) return;
         const int n = lane & 15, q = lane >> 4;
         // lane's B element of row r: column 2n + q - 1 (+ col0); at W = 16 lane n holds (row r + (n >> 3), pair n & 7)
@@ -274,6 +293,7 @@ struct Conv3 {
             for (int j = 0; j < T + 2; ++j) dst[j] = p[j * pitch];
         };
         rows(0, br[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             if (c + 1 < C) rows(c + 1, br[(c + 1) & 1]);
@@ -281,6 +301,7 @@ struct Conv3 {
             for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
                 for (int j = 0; j < T; ++j) acc[j] = mfma4(af[c][dy], br[c & 1][j + dy], acc[j]);
+            if (c + 1 < C) pin_pipeline<(T + 2 < 3 * T ? T + 2 : 3 * T)>();
         }
 #pragma unroll
         for (int j = 0; j < T; ++j) {
@@ -335,6 +356,7 @@ struct Down2 {
         for (int j = 0; j < NROW; ++j)
 #pragma unroll
             for (int k = 0; k < 10; ++k) bv[0][j][k] = b0[c0 * in.plane + 2 * j * in.pitch + k];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int cc = 0; cc < CPT; ++cc) {
             if (cc + 1 < CPT) {
@@ -347,6 +369,7 @@ struct Down2 {
             for (int k = 0; k < 10; ++k)
 #pragma unroll
                 for (int j = 0; j < NROW; ++j) acc[j] = mfma4(af[cc][k], bv[cc & 1][j][k], acc[j]);
+            if (cc + 1 < CPT) pin_pipeline<10 * NROW>();
         }
         // D rows of lane (n, q): (co = 2q, X = 2n), (2q, 2n + 1), (2q + 1, 2n), (2q + 1, 2n + 1)
 #pragma unroll
@@ -358,13 +381,21 @@ struct Down2 {
         }
     }
     // (behind a barrier) outputs spread over the threads, added up in a fixed order: LDS plane of the inner block + exchange tensor
-    __device__ __forceinline__ static void reduce(const float* part, const float* __restrict__ bias, Pl xi, float* g_x, int band_row0, int tid) {
-        for (int o = tid; o < OUTS; o += kNT) {
+    static constexpr int OPT = (OUTS + kNT - 1) / kNT;   // outputs per thread
+    __device__ __forceinline__ static void load_bias(float (&rb)[OPT], const float* __restrict__ bias, int tid) {
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) { const int o = tid + k * kNT; rb[k] = o < OUTS ? bias[o / (ROWS * W2)] : 0.f; }
+    }
+    __device__ __forceinline__ static void reduce(const float* part, const float (&rb)[OPT], Pl xi, float* g_x, int band_row0, int tid) {
+#pragma unroll
+        for (int k = 0; k < OPT; ++k) {
+            const int o = tid + k * kNT;
+            if (o >= OUTS) break;
             const int ch = o / (ROWS * W2), rem = o - ch * (ROWS * W2), row = rem / W2, x = rem - row * W2;
             float sum = part[o];
 #pragma unroll
             for (int p = 1; p < PARTS; ++p) sum += part[p * OUTS + o];
-            sum += bias[ch];
+            sum += rb[k];
             xi.p[ch * xi.plane + row * xi.pitch + x] = sum;
             st_coh(g_x + (long)ch * W2 * W2 + (long)(band_row0 + row) * W2 + x, sum);
         }
@@ -380,12 +411,14 @@ template <int W>
 struct Up2 {
     static constexpr int UNITS = W / 32, NWG = kNW / (2 * UNITS), R2 = W / kG / 2;   // window rows -1 .. R2 - 1 dealt over NWG groups of wavefronts
     float af[8][4];   // all fragments of (px): every task of this wavefront uses them
+    float b0, b1;
     int unit, px, wg;
     bool active;
-    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, int wave, int lane) {
+    __device__ __forceinline__ void prefetch(const float* __restrict__ afr, const float* __restrict__ bias, int wave, int lane) {
         unit = wave % UNITS; px = (wave / UNITS) & 1; wg = wave / (2 * UNITS);
         active = -1 + wg < R2;
         if (active) {
+            b0 = bias[2 * (lane >> 4)]; b1 = bias[2 * (lane >> 4) + 1];
 #pragma unroll
             for (int ci = 0; ci < 8; ++ci)
 #pragma unroll
@@ -393,13 +426,14 @@ struct Up2 {
         }
     }
     template <class Emit>
-    __device__ __forceinline__ void task(Pl in, const float* __restrict__ bias, int Yw, int lane, Emit emit) {
+    __device__ __forceinline__ void task(Pl in, int Yw, int lane, Emit emit) {
         const int n = lane & 15, q = lane >> 4;
         const float* bb0 = in.p + (Yw - 1 + q) * in.pitch + 16 * unit + n - 2 + px;
         f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
         float bv[2][4];
 #pragma unroll
         for (int bb = 0; bb < 4; ++bb) bv[0][bb] = bb0[bb];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ci = 0; ci < 8; ++ci) {
             if (ci + 1 < 8) {
@@ -408,16 +442,16 @@ struct Up2 {
             }
 #pragma unroll
             for (int bb = 0; bb < 4; ++bb) acc[ci & 1] = mfma4(af[ci][bb], bv[ci & 1][bb], acc[ci & 1]);
+            if (ci + 1 < 8) pin_pipeline<4>();
         }
         const f32x4 sum = acc[0] + acc[1];
-        const float b0 = bias[2 * q], b1 = bias[2 * q + 1];
         const float v[4] = {sum[0] + b0, sum[1] + b0, sum[2] + b1, sum[3] + b1};
         emit(2 * Yw + 1, 2 * (16 * unit + n) + px, q, v);
     }
     template <class Emit>
-    __device__ __forceinline__ void run(Pl in, const float* __restrict__ bias, int lane, Emit emit) {
+    __device__ __forceinline__ void run(Pl in, int lane, Emit emit) {
         if (!active) return;
-        for (int Yw = -1 + wg; Yw < R2; Yw += NWG) task(in, bias, Yw, lane, emit);
+        for (int Yw = -1 + wg; Yw < R2; Yw += NWG) task(in, Yw, lane, emit);
     }
 };
 
@@ -506,31 +540,27 @@ template <int W, bool GEN>
 __device__ void bottleneck(float* base, const DxArgs& a, int act, Ctl& c, const float* g_x, float* g_y, int hx, int hy, int tid) {
     using L = LayB<W>;
     constexpr int R = L::R;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Pl X = plane_at<W>(base, L::X, 2, R + 4), MID = plane_at<W>(base, L::MID, 1, R + 2), Y = plane_at<W>(base, L::Y, 3, R + 6);
     const int row0 = c.g * R;
     const float inf = __builtin_inff();
     Conv3<W, R + 2, 8, 0> c1;
     Conv3<W, R, 8, 0> c2;
     DX_T(32);
-    c1.prefetch(a.bot1, -1, wave, lane);
+    c1.prefetch(a.bot1, a.bot1_b, a.bot_slope, -1, wave, lane);
     wait_neighbours(c, hx);
     DX_T(33);
     load_halo<W, 2>(X, g_x, row0, tid);
-    c2.prefetch(a.bot2, 0, wave, lane);
+    c2.prefetch(a.bot2, a.bot2_b, nullptr, 0, wave, lane);
     lds_barrier();
     DX_T(34);
     {
-        const float slope = a.bot_slope[0], sel = slope <= 1.f ? inf : -inf;
-        const float bias[2] = {a.bot1_b[2 * q], a.bot1_b[2 * q + 1]};
-        c1.run(X, X, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
+        const float slope = c1.slope, sel = slope <= 1.f ? inf : -inf;
+        c1.run(X, X, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
     }
     lds_barrier();
     DX_T(35);
-    {
-        const float bias[2] = {a.bot2_b[2 * q], a.bot2_b[2 * q + 1]};
-        c2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(Y, g_y, row0, r, x, qq, v); });
-    }
+    c2.run(MID, MID, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(Y, g_y, row0, r, x, qq, v); });
     DX_T(36);
     signal(c, hy);
     DX_T(37);
@@ -544,7 +574,7 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     using L = Lay<W>;
     constexpr int R = L::R, W2 = W / 2, R2 = R / 2;
     const DxLevel& w = a.lv[li];
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), q = lane >> 4;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const Pl OUT = plane_at<W>(base, L::OUT, 3, R + 6), ST = plane_at<W>(base, L::ST, 2, R + 4), CSM = plane_at<W>(base, L::CSM, 1, R + 2),
              U = plane_at<W>(base, L::XU, 2, R + 4), X = U, MID = plane_at<W>(base, L::MID, 1, R + 2);
     float* const inner = base + L::INNER;
@@ -569,36 +599,34 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
         if (OUTER) {
             RowLoad<W, 8, -2, R + 4> lx;
             lx.issue(a.x_in + bo, (long)W * W, row0, tid);
-            s1.prefetch(w.sig1, -1, wave, lane);
+            s1.prefetch(w.sig1, w.sig1_b, w.sig_slope, -1, wave, lane);
             zero_fill(base, L::END, tid);
             lds_barrier();
             lx.commit(X, row0, tid);
         } else {
-            s1.prefetch(w.sig1, -1, wave, lane);
+            s1.prefetch(w.sig1, w.sig1_b, w.sig_slope, -1, wave, lane);
             wait_neighbours(c, hx_in);
             DX_T(TB + 1);
             load_halo<W, 2>(X, g_x_in, row0, tid);
         }
         lst.commit(ST, row0, tid);
     }
-    s2.prefetch(w.sig2, 0, wave, lane);
+    s2.prefetch(w.sig2, w.sig2_b, nullptr, 0, wave, lane);
     lds_barrier();
     DX_T(TB + 2);
 
     // ---- out = conv_signal(cat[x, state]) ----
     {
-        const float slope = w.sig_slope[0], sel = slope <= 1.f ? inf : -inf;
-        const float bias[2] = {w.sig1_b[2 * q], w.sig1_b[2 * q + 1]};
-        s1.run(X, ST, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
+        const float slope = s1.slope, sel = slope <= 1.f ? inf : -inf;
+        s1.run(X, ST, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
     }
     lds_barrier();
     DX_T(TB + 3);
     Down2<W> dn;
-    {
-        const float bias[2] = {w.sig2_b[2 * q], w.sig2_b[2 * q + 1]};
-        s2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(OUT, g_out, row0, r, x, qq, v); });
-    }
+    s2.run(MID, MID, lane, [&](int r, int x, int qq, const f32x4& v) { put_pair<W>(OUT, g_out, row0, r, x, qq, v); });
     dn.prefetch(w.down, wave, lane);
+    float dn_bias[Down2<W>::OPT];
+    Down2<W>::load_bias(dn_bias, w.down_b, tid);
     DX_T(TB + 4);
     lds_barrier();                          // x and the mid tensor are dead
     zero_fill(inner, L::INNER_SZ, tid);     // the inner block's planes and conv_state's mid tensor: fresh zero borders (while the write-through stores drain)
@@ -618,7 +646,7 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
         dn.run(OUT, part, lane);
         lds_barrier();
         const Pl XI = plane_at<W2>(inner, XIN, 2, R2 + 4);
-        Down2<W>::reduce(part, w.down_b, XI, g_x, row0_2, tid);
+        Down2<W>::reduce(part, dn_bias, XI, g_x, row0_2, tid);
         lds_barrier();
         zero_fill(part, Down2<W>::PART_SZ, tid);   // (planes of the inner block again)
     }
@@ -636,7 +664,7 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
     {
         const Pl YI = plane_at<W2>(inner, 0, 3, R2 + 6);
         Up2<W> up;
-        up.prefetch(w.up, wave, lane);
+        up.prefetch(w.up, w.up_b, wave, lane);
         DX_T(TB + 11);
         zero_fill(base + L::XU, L::XU_SZ, tid);     // the upsampled tensor's planes: fresh zero borders (the inner block is dead but for its result, which lies below XU)
         wait_neighbours(c, h_y);
@@ -644,7 +672,7 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
         load_halo<W2, 2>(YI, g_y, row0_2, tid);
         lds_barrier();
         DX_T(TB + 13);
-        up.run(YI, w.up_b, lane, [&](int yo, int xo, int qq, const float (&v)[4]) {
+        up.run(YI, lane, [&](int yo, int xo, int qq, const float (&v)[4]) {
 #pragma unroll
             for (int py = 0; py < 2; ++py) {
                 const int y = yo + py;
@@ -658,29 +686,27 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
         });
     }
     DX_T(TB + 14);
-    d1.prefetch(w.dec1, -1, wave, lane);
+    d1.prefetch(w.dec1, w.dec1_b, w.dec_slope, -1, wave, lane);
     signal(c, h_u);
     zero_fill(base + L::MID, L::MID_SZ, tid);       // the decoder's mid tensor returns to where the inner block's result was: fresh zero borders
     wait_neighbours(c, h_u);
     DX_T(TB + 15);
     load_halo<W, 2>(U, g_u, row0, tid);
     Conv3<W, R, 8, 0> d2;
-    d2.prefetch(w.dec2, 0, wave, lane);
+    d2.prefetch(w.dec2, w.dec2_b, nullptr, 0, wave, lane);
     lds_barrier();
     DX_T(OUTER ? 40 : 43);
     // ---- y = decode(cat[u, out]) ----
     {
-        const float slope = w.dec_slope[0], sel = slope <= 1.f ? inf : -inf;
-        const float bias[2] = {w.dec1_b[2 * q], w.dec1_b[2 * q + 1]};
-        d1.run(U, OUT, bias, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
+        const float slope = d1.slope, sel = slope <= 1.f ? inf : -inf;
+        d1.run(U, OUT, lane, [&](int r, int x, int qq, const f32x4& v) { put_mid<GEN>(MID, row0 + r, W, r, x, qq, v, slope, sel, act); });
     }
     lds_barrier();   // (out is dead from here on)
     DX_T(OUTER ? 41 : 44);
     {
-        const float bias[2] = {w.dec2_b[2 * q], w.dec2_b[2 * q + 1]};
         if (OUTER) {
             float* const yo = a.y_out + bo;
-            d2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) {
+            d2.run(MID, MID, lane, [&](int r, int x, int qq, const f32x4& v) {
                 float* o = yo + (long)(2 * qq) * W * W + (long)(row0 + r) * W + x;
                 *reinterpret_cast<float2*>(o) = make_float2(v[0], v[1]);
                 *reinterpret_cast<float2*>(o + (long)W * W) = make_float2(v[2], v[3]);
@@ -692,7 +718,7 @@ __device__ void level(float* base, const DxArgs& a, int act, int li, Ctl& c, con
             f32x4 keep[T];
             int kr[T], kx[T], kq = 0, nk = 0;
             zero_fill(base + L::OUT, L::OUT_SZ, tid);
-            d2.run(MID, MID, bias, lane, [&](int r, int x, int qq, const f32x4& v) { keep[nk] = v; kr[nk] = r; kx[nk] = x; kq = qq; ++nk; });
+            d2.run(MID, MID, lane, [&](int r, int x, int qq, const f32x4& v) { keep[nk] = v; kr[nk] = r; kx[nk] = x; kq = qq; ++nk; });
             lds_barrier();
             for (int k = 0; k < nk; ++k) put_pair<W>(OUT, g_y_out, row0, kr[k], kx[k], kq, keep[k]);
             DX_T(45);
@@ -739,6 +765,7 @@ __global__ __launch_bounds__(kNT) void k_deepx(DxArgs a, int act, SyncHook hook)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 32 * l), (__attribute__((address_space(3))) void*)junk, 4, 0, 0);
                 }
         };
+        warm(a.wblob, a.wblob_floats);   // 193 KB: biases, slopes, the vector-ALU weights of conv_state
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const DxLevel& w = a.lv[k];
@@ -807,6 +834,7 @@ int launch_deepx(hn_ctx* ctx, int K, const float* states_in, float* states_out, 
     a.bot1 = ctx->f_dec[depth][0]; a.bot1_b = ctx->dec[depth].b1; a.bot_slope = ctx->dec[depth].slope; a.bot2 = ctx->f_dec[depth][1]; a.bot2_b = ctx->dec[depth].b2;
     a.x_in = ctx->buf_a[d0] + (long)ws_off * kFeat * plane(d0);
     a.y_out = ctx->buf_y[d0] + (long)ws_off * kFeat * plane(d0);
+    a.wblob = ctx->wdev; a.wblob_floats = (int)hn_weight_count(kFeat, depth, kState);
     a.st_sb = 2 * L; a.st_sc = L;
     a.flags = ctx->dx_flags + (long)ws_off * (kG * 8);
     a.done = ctx->dx_done + ws_off;
