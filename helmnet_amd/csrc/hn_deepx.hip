@@ -800,9 +800,9 @@ void pack_frag_down2(const float* w, float* dst) {
 
 // which form: 2 = two levels (the last two encoder levels are 64 and 32 wide), 1 = one level (the last encoder level is 64 wide), 0 = not applicable
 int deepx_levels(const hn_ctx* ctx, int batch) {
-    // one workgroup per CU (88 KB of LDS): up to ~1.25 rounds of workgroups the launch beats the layers it replaces; beyond that (batch 64: two full rounds)
+    // one workgroup per CU (88 KB of LDS): one round of workgroups (32 maps = 256 workgroups) beats the layers it replaces; beyond that (batch 40: 1596 vs 1629 it/s; batch 64: two full rounds)
     // the per-sample kernel + the layer-by-layer level are ahead [measured, r6: 256^2 x 64 1145 vs 1173 it/s]
-    if (batch > 40) return 0;
+    if (batch > 32) return 0;
     if (ctx->opt_deep < 2 || ctx->precision != HN_PREC_FP32 || ctx->act_kind > HN_ACT_LEAKYRELU || ctx->dx_flags == nullptr) return 0;
     const int n = ctx->tab.n, depth = ctx->depth;
     // (at least one level above the fused ones: the decoder's output buffer of level 0 does not exist -- decode_0 ends in the wavefield update)
