@@ -475,6 +475,37 @@ __device__ __forceinline__ void put_mid(Pl mid, int gy, int W, int r, int x, int
     m[mid.plane] = in ? activ<GEN>(v[2], slope, sel, act) : 0.f; m[mid.plane + 1] = in ? activ<GEN>(v[3], slope, sel, act) : 0.f;
 }
 
+// The weights do not survive an iteration in the L2 (the level-0 kernels stream > 100 MB through every XCD's 4 MB), so every fragment load of the stages
+// would pay the way to HBM -- 2 - 3 us where an L2 hit is a fraction of that [measured: a stage's time followed its count of dependent fragment fetches].
+// Touch every fragment line -- and the packed weight blob with the biases, slopes and conv_state's scalar-load weights -- once, one 128-byte line per lane,
+// with LDS-direct loads (no destination register to keep alive): by the time a stage asks, its lines are in this XCD's L2.
+template <int W, int K>
+__device__ __forceinline__ void warm_l2(const DxArgs& a, float* junk, int wave, int lane) {
+    // (junk: 256 bytes of LDS of their own that every wavefront's loads land in)
+    int ins = 0;
+    auto warm = [&](const float* p, int nfloats) {
+        const int lines = nfloats / 32;
+        for (int l0 = 0; l0 < lines; l0 += 64, ++ins)
+            if ((ins & (kNW - 1)) == wave) {
+                const int l = l0 + lane < lines ? l0 + lane : lines - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 32 * l), (__attribute__((address_space(3))) void*)junk, 4, 0, 0);
+            }
+    };
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const DxLevel& w = a.lv[k];
+        if (k > 0) warm(w.sig1, 10 * 3 * 64);
+        warm(w.sig2, 8 * 3 * 64); warm(w.down, 8 * 2 * 10 * 64);
+    }
+    warm(a.wblob, a.wblob_floats);   // 193 KB: biases, slopes, the vector-ALU weights of conv_state
+    warm(a.bot1, 8 * 3 * 64); warm(a.bot2, 8 * 3 * 64);
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) {
+        const DxLevel& w = a.lv[k];
+        warm(w.up, 8 * 2 * 4 * 64); warm(w.dec1, 16 * 3 * 64); warm(w.dec2, 8 * 3 * 64);
+    }
+}
+
 // ---- conv_state (DoubleConv 10 -> 2 -> 2) of a band on the vector ALU.  On the matrix core its two output channels fill 4 of the 16 rows of M: 720 + 96
 // instructions per workgroup at W = 64, 4 us; as plain FMAs it is 180 + 36 MACs per pixel at full lane use: [measured, r6] ~1 us.  conv1 -> CSM rows [-1, R + 1)
 // (pairs of pixels per thread; zero outside the image), barrier, conv2 -> the new state in global memory.  Weights through scalar loads (wave-uniform).
@@ -744,41 +775,12 @@ __global__ __launch_bounds__(kNT) void k_deepx(DxArgs a, int act, SyncHook hook)
     if (c.b >= a.batch) return;
     c.flags = a.flags + (long)c.b * (kG * 8);
     c.err = a.err;
-    // the launch's epoch: bands of this sample that have ever ended / 8 + 1 -- the same for all eight (a band ends only after its last
-    // hand-off, i.e. after every other band of the sample has read the word at least... read it or will read a value < 8 more)
+    // the launch's epoch: bands of this sample that have ever ended / 8 + 1 -- the same for all eight whenever they read it: a band that starts late may
+    // see the count already raised by bands of this launch that have ended, but never by all eight (it is one of them), and the division drops the rest
     c.epoch = __hip_atomic_load(a.done + c.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kG + 1u;
-    {
-        // The weights do not survive an iteration in the L2 (the level-0 kernels stream > 100 MB through every XCD's 4 MB), so every fragment load of the stages
-        // below would pay the way to HBM -- 2 - 3 us where an L2 hit is a fraction of that [measured: a stage's time followed its count of dependent fragment
-        // fetches].  Touch every fragment line now, one 128-byte line per lane, with LDS-direct loads (no destination register to keep alive):
-        // by the time a stage asks, its lines are in this XCD's L2.
-        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-        // (the junk row: a band row of conv_signal's output plane, written long after these loads have landed -- they precede the first stage's own loads in
-        // the in-order memory counter)
-        float* const junk = lds + Lay<W>::OUT + ((wave >> 3) * (Lay<W>::R + 6) + 3 + (wave & 7)) * Lay<W>::P + kC0;
-        int ins = 0;
-        auto warm = [&](const float* p, int nfloats) {
-            const int lines = nfloats / 32;
-            for (int l0 = 0; l0 < lines; l0 += 64, ++ins)
-                if ((ins & (kNW - 1)) == wave) {
-                    const int l = l0 + lane < lines ? l0 + lane : lines - 1;
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p + 32 * l), (__attribute__((address_space(3))) void*)junk, 4, 0, 0);
-                }
-        };
-        warm(a.wblob, a.wblob_floats);   // 193 KB: biases, slopes, the vector-ALU weights of conv_state
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const DxLevel& w = a.lv[k];
-            if (k > 0) warm(w.sig1, 10 * 3 * 64);
-            warm(w.sig2, 8 * 3 * 64); warm(w.down, 8 * 2 * 10 * 64);
-        }
-        warm(a.bot1, 8 * 3 * 64); warm(a.bot2, 8 * 3 * 64);
-#pragma unroll
-        for (int k = K - 1; k >= 0; --k) {
-            const DxLevel& w = a.lv[k];
-            warm(w.up, 8 * 2 * 4 * 64); warm(w.dec1, 16 * 3 * 64); warm(w.dec2, 8 * 3 * 64);
-        }
-    }
+    __shared__ float junk_row[64];
+    // ([measured] first thing: requested behind the first stage's own loads, the warm-up costs that stage 2 us)
+    warm_l2<W, K>(a, junk_row, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
     level<W, K, true, GEN>(lds, a, act, 0, c, nullptr, 0, nullptr, 0, tid);
     DX_T(47);
     if (tid == 0) __hip_atomic_fetch_add(a.done + c.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
