@@ -805,7 +805,7 @@ int deepx_levels(const hn_ctx* ctx, int batch) {
     // one workgroup per CU (88 KB of LDS): one round of workgroups (32 maps = 256 workgroups) beats the layers it replaces; beyond that (batch 40: 1596 vs 1629 it/s; batch 64: two full rounds)
     // the per-sample kernel + the layer-by-layer level are ahead [measured, r6: 256^2 x 64 1145 vs 1173 it/s]
     if (batch > 32) return 0;
-    if (ctx->opt_deep < 2 || ctx->precision != HN_PREC_FP32 || ctx->act_kind > HN_ACT_LEAKYRELU || ctx->dx_flags == nullptr) return 0;
+    if (ctx->opt_deep < 2 || ctx->precision != HN_PREC_FP32 || ctx->dx_flags == nullptr) return 0;
     const int n = ctx->tab.n, depth = ctx->depth;
     // (at least one level above the fused ones: the decoder's output buffer of level 0 does not exist -- decode_0 ends in the wavefield update)
     if (depth >= 3 && (n >> (depth - 2)) == 64 && (n >> (depth - 1)) == 32) return 2;
@@ -847,9 +847,14 @@ int launch_deepx(hn_ctx* ctx, int K, const float* states_in, float* states_out, 
     if (!ctx->deepx_attr_set) {
         HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_deepx<64, 2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_deepx<64, 1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_deepx<64, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HN_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(k_deepx<64, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         ctx->deepx_attr_set = true;
     }
-    if (K == 2) hipLaunchKernelGGL((k_deepx<64, 2, false>), dim3(grid), dim3(kNT), lds, s, a, ctx->act_kind, hook);
+    const bool gen = ctx->act_kind > HN_ACT_LEAKYRELU;   // the smooth activations (architectures.py:22-39): a template instance of their own, as in the other kernels
+    if (K == 2 && gen) hipLaunchKernelGGL((k_deepx<64, 2, true>), dim3(grid), dim3(kNT), lds, s, a, ctx->act_kind, hook);
+    else if (K == 2) hipLaunchKernelGGL((k_deepx<64, 2, false>), dim3(grid), dim3(kNT), lds, s, a, ctx->act_kind, hook);
+    else if (gen) hipLaunchKernelGGL((k_deepx<64, 1, true>), dim3(grid), dim3(kNT), lds, s, a, ctx->act_kind, hook);
     else hipLaunchKernelGGL((k_deepx<64, 1, false>), dim3(grid), dim3(kNT), lds, s, a, ctx->act_kind, hook);
     return HN_OK;
 }
