@@ -115,6 +115,7 @@ void free_workspace(hn_ctx* c) {
     }
     (void)hipFree(c->st_tmp); c->st_tmp = nullptr;
     (void)hipFree(c->pair_flags); c->pair_flags = nullptr; c->pair_flags_cap = 0;
+    (void)hipFree(c->pair_done); c->pair_done = nullptr;
     (void)hipFree(c->dx_flags); c->dx_flags = nullptr;
     (void)hipFree(c->dx_done); c->dx_done = nullptr;
     c->cap_batch = 0;
@@ -632,11 +633,13 @@ int hn_reserve(hn_ctx* ctx, int max_batch) {
     ctx->pair_flags_cap = (long)((n + 63) / 64) * ((n + 15) / 16) * max_batch;   // one flag word per level-0 tile (k_dc_asm_pair); epochs start at 1
     HN_HIP(ctx, hipMalloc((void**)&ctx->pair_flags, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
     HN_HIP(ctx, hipMemset(ctx->pair_flags, 0, sizeof(unsigned) * (size_t)ctx->pair_flags_cap));
+    HN_HIP(ctx, hipMalloc((void**)&ctx->pair_done, sizeof(unsigned) * kCounterStride * (size_t)max_batch));          // (zero: the first launch's epoch is 1)
+    HN_HIP(ctx, hipMemset(ctx->pair_done, 0, sizeof(unsigned) * kCounterStride * (size_t)max_batch));
     // hn_deepx.hip: 64 epoch words and one counter per sample slot (zero: the first launch's epoch is 1)
     HN_HIP(ctx, hipMalloc((void**)&ctx->dx_flags, sizeof(unsigned) * 64 * (size_t)max_batch));
     HN_HIP(ctx, hipMemset(ctx->dx_flags, 0, sizeof(unsigned) * 64 * (size_t)max_batch));
-    HN_HIP(ctx, hipMalloc((void**)&ctx->dx_done, sizeof(unsigned) * (size_t)max_batch));
-    HN_HIP(ctx, hipMemset(ctx->dx_done, 0, sizeof(unsigned) * (size_t)max_batch));
+    HN_HIP(ctx, hipMalloc((void**)&ctx->dx_done, sizeof(unsigned) * kCounterStride * (size_t)max_batch));
+    HN_HIP(ctx, hipMemset(ctx->dx_done, 0, sizeof(unsigned) * kCounterStride * (size_t)max_batch));
     if (int rc_sync = ensure_sync_words(ctx); rc_sync != HN_OK) return rc_sync;
     ctx->cap_batch = max_batch;
     return HN_OK;

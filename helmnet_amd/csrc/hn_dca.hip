@@ -90,8 +90,16 @@ __device__ __forceinline__ void conv2_all(f32x2 (&a)[4][4], unsigned mid_addr, c
 
 // ROLE 0: a launch of its own.  ROLE 1 / 2: the producer / consumer half of a two-phase launch (k_dc_asm_pair below): the producer writes its output tile
 // through (sc1 stores), drains them and publishes flags[tile] = epoch; the consumer first waits for the flags of the (up to nine) producer tiles its input
-// window touches and stages with sc1 LDS-direct loads.
-struct PairSync { unsigned* flags; unsigned epoch; int tile, tx, ty, gx, gy; int* err; };   // err: the context's host-mapped sticky error word (nullable)
+// window touches and stages with sc1 LDS-direct loads.  The epoch comes from one of two sources:
+//   host != 0   the launch's number on this context with the top bit set, in the kernel arguments (r5) -- a launch that is not being captured;
+//   host == 0   derived on the device (r6), for a launch under stream capture, whose arguments every replay repeats: every CONSUMER block adds 1 to its
+//               sample's word of `done` when it ends, so whenever a block of launch L reads the word it holds L * per + (consumers of THIS launch that have
+//               ended) < (L + 1) * per, per = the gx gy tiles of a sample (a producer reads it before it publishes, and its own tile's consumer cannot end
+//               before that): epoch = done / per + 1, top bit clear -- the two numberings never meet.  One 128-byte line per sample: atomics on one line are
+//               served one after the other at the memory side (all 4096 blocks of a launch on ONE line doubled the kernel's duration [measured, r6]).
+// [measured, profiles/r6_epoch_ab.txt] the device form everywhere costs the eager loop 0.5-0.7 % (merged launch +1.4 us: the counter's round trip and the
+// division sit between a producer's last store and its flag), which is why the eager path keeps the argument.
+struct PairSync { unsigned* flags; unsigned* done; unsigned host; int tile, tx, ty, gx, gy; int* err; };   // err: the context's host-mapped sticky error word (nullable)
 // The input layer's sigma channels are constants of the domain (hybridnet.py:564-566), so their share of conv1 is a per-domain map: P[pair c][y][x] =
 // sum over the two sigma channels and the 3x3 taps (float64 on the host, hn_api.hip: build_inc_sigma_map), zero farther than `band` pixels from the border.
 // With it the input layer stages and convolves 4 channels instead of 6; tiles whose mid region touches the band start their even-parity accumulators from it.
@@ -115,11 +123,15 @@ __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, 
             const int dy = lane / 3 - 1, dx = lane % 3 - 1;
             const bool need = lane < 9 && ps.ty + dy >= 0 && ps.ty + dy < ps.gy && ps.tx + dx >= 0 && ps.tx + dx < ps.gx;
             const unsigned* f = ps.flags + (need ? ps.tile + dy * ps.gx + dx : ps.tile);
-            bool got = !need;
+            // (the counter and the first poll travel together: one round trip)
+            const unsigned dn = ps.host ? 0u : __hip_atomic_load(ps.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned f0 = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned epoch = ps.host ? ps.host : dn / (unsigned)(ps.gx * ps.gy) + 1u;
+            bool got = !need || f0 == epoch;
             for (int spin = 0; spin < 2000000; ++spin) {   // bounded: a block that gives up poisons its output instead of hanging the GPU
-                if (!got) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ps.epoch;
                 if (__builtin_amdgcn_ballot_w64(!got) == 0) break;
                 __builtin_amdgcn_s_sleep(2);
+                if (!got) got = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == epoch;
             }
             if (lane == 0) {
                 s_ok = __builtin_amdgcn_ballot_w64(!got) == 0 ? 1 : 0;
@@ -370,10 +382,12 @@ __device__ __forceinline__ void dc_asm_body(float* lds, Src sa, Src sb, Src sc, 
                 }
             }
         }
-        if (ROLE == 1) {   // publish: every store of the block has left (vmcnt), then the flag
+        if (ROLE == 1) {   // publish: every store of the block has left (vmcnt), then the flag.  The counter's load rides under the drain of the stores
+            unsigned dn = 0;
+            if (tid == 0 && !ps.host) dn = __hip_atomic_load(ps.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(ps.flags + ps.tile, ps.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0) __hip_atomic_store(ps.flags + ps.tile, ps.host ? ps.host : dn / (unsigned)(ps.gx * ps.gy) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const TileId tl = xcd_tile();
     const int tr_id = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & 8191;
-    dc_asm_body<CA, CB, CC, EPI, 0>(lds, sa, sb, sc, out, w, epi, zero_page, H, W, tl.z, tl.x * 64, tl.y * 16, tr_id, PairSync{nullptr, 0u, 0, 0, 0, 0, 0, nullptr}, sm);
+    dc_asm_body<CA, CB, CC, EPI, 0>(lds, sa, sb, sc, out, w, epi, zero_page, H, W, tl.z, tl.x * 64, tl.y * 16, tr_id, PairSync{nullptr, nullptr, 0u, 0, 0, 0, 1, 1, nullptr}, sm);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -397,11 +411,12 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm(Src sa, Src sb, Src sc, Dst o
 //   * visibility without fences (a device-scope release / acquire pair is a whole-L2 write-back here: +60 us in the micro-benchmark): inc's output
 //     stores are write-through (sc1), drained (s_waitcnt vmcnt(0)) before the flag is published with an agent-scope store; conv_signal polls with
 //     agent-scope loads and stages that tensor with sc1 LDS-direct loads (what an agent-scope relaxed atomic access compiles to on gfx950);
-//   * used by hn_step's single-lane eager path only (the epoch travels in the kernel arguments: not under capture); anything else launches the two
-//     kernels as before.  Same arithmetic in the same order as the separate launches: results are bit-identical.
+//   * every caller of the two layers takes this launch (r5: hn_step's single-lane eager path only): under stream capture the epoch is derived on the device
+//     from a per-sample counter (PairSync above), and pipeline lanes use disjoint sample slots of the flag / counter arrays.  Same arithmetic in the same
+//     order as the separate launches: results are bit-identical.
 // ------------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, Dst x0_out, DcW w_inc, Src b0, Src b1, Dst out0, DcW w_sig, const float* zero_page,
-                                                         int H, int W, int gx, int gy, int T, unsigned* flags, unsigned epoch, int* err, SigmaMap sm) {
+                                                         int H, int W, int gx, int gy, int T, unsigned* flags, unsigned* done, unsigned host_epoch, int* err, SigmaMap sm) {
     __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
     const bool second = __builtin_amdgcn_readfirstlane((int)blockIdx.x) >= T;   // wave-uniform
     int tile = second ? (int)blockIdx.x - T : (int)blockIdx.x;
@@ -409,12 +424,13 @@ __global__ __launch_bounds__(256, 4) void k_dc_asm_pair(Src a0, Src a1, Src a2, 
     if ((T & 7) == 0) tile = (tile & 7) * (T >> 3) + (tile >> 3);   // xcd_tile(): block i and block T + i share an XCD, and so do a tile's neighbours
 #endif
     const int tq = tile / gx, tx = tile - tq * gx, b = tq / gy, ty = tq - b * gy;
-    const PairSync ps{flags, epoch, tile, tx, ty, gx, gy, err};
+    const PairSync ps{flags, done + (long)b * kCounterStride, host_epoch, tile, tx, ty, gx, gy, err};
     const VcEpi noepi{nullptr, nullptr, nullptr, nullptr};
     const Src none{nullptr, 0, 0, 1.f};
     if (second) dc_asm_body<kFeat, kState, 0, 0, 2>(lds, b0, b1, none, out0, w_sig, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps);
     else if (sm.p != nullptr) dc_asm_body<2, 2, 0, 0, 1>(lds, a0, a1, none, x0_out, w_inc, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps, sm);   // (sigma channels: the map)
     else dc_asm_body<2, 2, 2, 0, 1>(lds, a0, a1, a2, x0_out, w_inc, noepi, zero_page, H, W, b, tx * 64, ty * 16, 0, ps);
+    if (second && host_epoch == 0u && threadIdx.x == 0) __hip_atomic_fetch_add(ps.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (no return value: nothing waits for it)
 }
 
 
@@ -478,19 +494,20 @@ void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const Dc
 }
 
 // inc + conv_signal_0 as one launch (k_dc_asm_pair): both must be what launch_dc_asm would run with tile order and sizes in common
-bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch) {
-    if (!ctx->opt_dc_pair || ctx->pair_flags == nullptr) return false;
+bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch, int ws_off) {
+    if (!ctx->opt_dc_pair || ctx->pair_flags == nullptr || ctx->pair_done == nullptr) return false;
     const Src none{nullptr, 0, 0, 1.f};
     if (!dc_asm_applies(ctx, ctx->inc.act, wf, res, sig, 0, H, W) || !dc_asm_applies(ctx, ctx->sig[0].act, x0, st, none, 1, H, W)) return false;
-    return (long)cdiv_(W, 64) * cdiv_(H, 16) * batch <= ctx->pair_flags_cap;
+    return H == ctx->tab.n && W == ctx->tab.n && (long)cdiv_(W, 64) * cdiv_(H, 16) * (ws_off + batch) <= ctx->pair_flags_cap;   // (the counters assume ONE tile grid per context)
 }
 
-void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, hipStream_t s) {
+// ws_off: first sample slot of the call (pipeline lanes work on disjoint slots: flags and counters are per slot)
+void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, int ws_off, bool capturing, hipStream_t s) {
     const int gx = cdiv_(W, 64), gy = cdiv_(H, 16), T = gx * gy * batch;
-    const unsigned epoch = ++ctx->pair_epoch;
     const SigmaMap sm = sigma_map_applies(ctx, sig, H, W) ? SigmaMap{ctx->inc_sigma_map, ctx->inc_sigma_band} : SigmaMap{nullptr, 0};
+    const unsigned host_epoch = capturing ? 0u : 0x80000000u | ++ctx->pair_epoch;   // (0: derive it on the device)
     hipLaunchKernelGGL(k_dc_asm_pair, dim3(2 * T), dim3(256), 0, s, wf, res, sig, x0_out, ctx->inc, x0, st, out0, ctx->sig[0], ctx->zero_page, H, W, gx, gy, T,
-                       ctx->pair_flags, epoch, ctx->sync_err_dev, sm);
+                       ctx->pair_flags + (long)ws_off * gx * gy, ctx->pair_done + (long)ws_off * kCounterStride, host_epoch, ctx->sync_err_dev, sm);
 }
 
 }  // namespace hn

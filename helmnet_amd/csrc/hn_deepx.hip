@@ -131,7 +131,7 @@ struct DxArgs {
     int wblob_floats;
     long st_sb, st_sc;       // strides of the flat hidden state: sample, channel
     unsigned* flags;         // [slot][band][8 hand-offs]
-    unsigned* done;          // [slot]: bands of this slot that have ended, ever
+    unsigned* done;          // [slot][kCounterStride]: bands of this slot that have ended, ever (a cache line per slot)
     int* err;                // the context's sticky error word (host-mapped; nullable)
     int batch;
 };
@@ -777,13 +777,13 @@ __global__ __launch_bounds__(kNT) void k_deepx(DxArgs a, int act, SyncHook hook)
     c.err = a.err;
     // the launch's epoch: bands of this sample that have ever ended / 8 + 1 -- the same for all eight whenever they read it: a band that starts late may
     // see the count already raised by bands of this launch that have ended, but never by all eight (it is one of them), and the division drops the rest
-    c.epoch = __hip_atomic_load(a.done + c.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kG + 1u;
+    c.epoch = __hip_atomic_load(a.done + (long)c.b * kCounterStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) / kG + 1u;
     __shared__ float junk_row[64];
     // ([measured] first thing: requested behind the first stage's own loads, the warm-up costs that stage 2 us)
     warm_l2<W, K>(a, junk_row, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
     level<W, K, true, GEN>(lds, a, act, 0, c, nullptr, 0, nullptr, 0, tid);
     DX_T(47);
-    if (tid == 0) __hip_atomic_fetch_add(a.done + c.b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_fetch_add(a.done + (long)c.b * kCounterStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace
@@ -839,7 +839,7 @@ int launch_deepx(hn_ctx* ctx, int K, const float* states_in, float* states_out, 
     a.wblob = ctx->wdev; a.wblob_floats = (int)hn_weight_count(kFeat, depth, kState);
     a.st_sb = 2 * L; a.st_sc = L;
     a.flags = ctx->dx_flags + (long)ws_off * (kG * 8);
-    a.done = ctx->dx_done + ws_off;
+    a.done = ctx->dx_done + (long)ws_off * kCounterStride;
     a.err = ctx->sync_err_dev;
     a.batch = batch;
     const int grid = 64 * ((batch + 7) / 8);

@@ -13,6 +13,9 @@
 namespace hn {
 
 constexpr int kFeat = 8;    // feature channels of the shipped net (hparams.features)
+// device-side launch counters (hn_dca.hip: pair_done, hn_deepx.hip: dx_done): one 128-byte line per sample slot -- atomics on ONE line are served one after
+// the other at the memory side, ~26 ns each [measured, r6: 4096 of them doubled a 106 us kernel]
+constexpr int kCounterStride = 32;
 constexpr int kState = 2;   // hidden-state channels per level (hparams.state_channels)
 constexpr int kInCh = 6;    // [wf_re, wf_im, 1e3*res_re, 1e3*res_im, sigma_x, sigma_y]
 constexpr int kMaxDepth = 6;
@@ -178,14 +181,15 @@ struct hn_ctx {
                                // 2 (default) the last one or two levels + bottleneck as ONE launch with eight workgroups per sample where it applies (hn_deepx.hip:
                                // a 64-wide level, with a 32-wide one below it or not), else as 1; 0 layer by layer
     unsigned* dx_flags = nullptr;   // hn_deepx.hip: [sample slot][8 bands][8 hand-offs] epoch words
-    unsigned* dx_done = nullptr;    // [sample slot]: bands that have ended, ever (the launch's epoch is derived from it on the device)
+    unsigned* dx_done = nullptr;    // [sample slot][kCounterStride]: bands that have ended, ever (the launch's epoch is derived from it on the device)
     bool deepx_attr_set = false;
     int opt_dc_valu = 4;       // fp32 DoubleConvs of the big levels on the packed vector FMA: 0 none, 1 inc + decoder (hn_dcv.hip), 2 all three;
                                // 3 / 4 (default): the same two / three on the hand-scheduled kernel (hn_dca.hip)
     int opt_dc_pair = 1;       // HN_OPT_DC_PAIR: inc and conv_signal_0 as one launch with per-tile flags (hn_dca.hip, k_dc_asm_pair); hn_step's single-lane eager path
     unsigned* pair_flags = nullptr;   // one word per level-0 tile of the reserved batch: the epoch of the launch whose inc block wrote that tile
     long pair_flags_cap = 0;
-    unsigned pair_epoch = 0;
+    unsigned pair_epoch = 0;          // launches of the merged kernel outside stream capture (their epoch travels in the arguments, top bit set)
+    unsigned* pair_done = nullptr;    // [sample slot][kCounterStride]: conv_signal blocks of the merged launch that have ended, ever (the launch's epoch is derived from it on the device)
     // Side stream <-> main stream without event packets ("flag sync", hn_unet.hip).  An event record holds the recording stream for ~7 us, a stream-wait for ~6,
     // and so does ANY extra kernel, however small [measured, r5: profiles/r5_side_sync.txt].  So between the iterations of one hn_step call the hand-overs
     // ride on kernels the main chain launches anyway (SyncHook):
@@ -474,8 +478,8 @@ void launch_dc_asm(hn_ctx* ctx, int kind, Src a, Src b, Src c, Dst out, const Dc
 bool conv_state_applies(const hn_ctx* ctx, const DcW& w, Src a, Src b, Dst out, int H, int W);
 void launch_conv_state(hn_ctx* ctx, int n, const Src* a, const Src* b, const Dst* out, const DcW* w, const int* H, const int* W, int batch, hipStream_t s);   // n levels, one launch
 // inc and conv_signal_0 as ONE launch with a flag per tile (k_dc_asm_pair): x0_out / x0 are the same tensor as inc's output and conv_signal's input
-bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch);
-void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, hipStream_t s);
+bool dc_asm_pair_applies(const hn_ctx* ctx, Src wf, Src res, Src sig, Src x0, Src st, int H, int W, int batch, int ws_off);
+void launch_dc_asm_pair(hn_ctx* ctx, Src wf, Src res, Src sig, Dst x0_out, Src x0, Src st, Dst out0, int H, int W, int batch, int ws_off, bool capturing, hipStream_t s);
 
 // ---- deep levels in one per-sample kernel (hn_deep.hip) ----
 void pack_frag_3x3_c2(const float* w_oihw, int cin, float* dst);  // 2 output channels -> [cin][3][64], rows 4..15 of M zero

@@ -452,22 +452,21 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     auto feat = [&](float* p, int d) { return Dst{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d)}; };
     auto featsrc = [&](const float* p, int d) { return Src{p + (long)ws_off * kFeat * plane(d), kFeat * plane(d), plane(d), 1.f}; };
 
-    // inc and conv_signal_0 as ONE launch with a flag per tile (hn_dca.hip, k_dc_asm_pair) where both run on the hand-scheduled kernel: hn_step's
-    // single-lane path, not under stream capture (the launch's epoch travels in the kernel arguments)
-    bool pair = false, eager = false;
-    if (ws_off == 0 && ctx->opt_lanes == 1 && side_lane != nullptr) {   // hn_step's single lane, launched kernel by kernel
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        eager = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
-        (void)hipGetLastError();
-        const Src st0{states_in + ctx->state_off[0], 2 * L, L, 1.f};
-        pair = eager && mfma && dc_asm_pair_applies(ctx, in_wf, in_res, in_sig, featsrc(ctx->buf_a[0], 0), st0, n, n, batch);
-    }
+    // inc and conv_signal_0 as ONE launch with a flag per tile (hn_dca.hip, k_dc_asm_pair) where both run on the hand-scheduled kernel -- eagerly, under
+    // stream capture (where it derives its epoch on the device) and in every pipeline lane (flags and counters per sample slot)
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool not_capturing = hipStreamIsCapturing(s, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone;
+    (void)hipGetLastError();
+    const bool eager = not_capturing && ws_off == 0 && ctx->opt_lanes == 1 && side_lane != nullptr;   // hn_step's single lane, launched kernel by kernel (flag sync below)
+    const bool pair = mfma && dc_asm_pair_applies(ctx, in_wf, in_res, in_sig, featsrc(ctx->buf_a[0], 0), Src{states_in + ctx->state_off[0], 2 * L, L, 1.f}, n, n, batch, ws_off);
     if (pair) {
-        int rc = side_join(ctx, side_lane, s);   // (deferred join: conv_signal_0 reads the new states)
-        if (rc != HN_OK) return rc;
+        if (side_lane != nullptr) {   // (deferred join: conv_signal_0 reads the new states)
+            int rc = side_join(ctx, side_lane, s);
+            if (rc != HN_OK) return rc;
+        }
         const Src st0{states_in + ctx->state_off[0], 2 * L, L, 1.f};
         ProfScope ps(ctx, KID_INC_SIG0, s);
-        HN_REP(KID_INC_SIG0) launch_dc_asm_pair(ctx, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), featsrc(ctx->buf_a[0], 0), st0, feat(ctx->buf_o[0], 0), n, n, batch, s);
+        HN_REP(KID_INC_SIG0) launch_dc_asm_pair(ctx, in_wf, in_res, in_sig, feat(ctx->buf_a[0], 0), featsrc(ctx->buf_a[0], 0), st0, feat(ctx->buf_o[0], 0), n, n, batch, ws_off, !not_capturing, s);
     } else {
     // inc: DoubleConv(6 -> 8 -> 8) on [wf, 1e3*res, sigmas]  (architectures.py:442, hybridnet.py:566)
     ProfScope ps(ctx, KID_INC, s);

@@ -93,8 +93,9 @@ enum hn_option {
                               * (hn_dca.hip: all 8 mid channels per wavefront, LDS-direct staging; [measured, r5] +1 .. 3 % it/s over 1).  Smooth
                               * activations and unaligned tensors always take hn_dcv.hip                                          */
     HN_OPT_DC_PAIR = 12,     /* 0/1 (default 1): where inc and conv_signal_0 both run on hn_dca.hip they are ONE launch -- conv_signal's blocks wait, tile by
-                              * tile, on a flag the inc blocks of the tiles they read publish (write-through stores, agent-scope flag).  hn_step's
-                              * single-lane eager path only (not under capture, not with HN_OPT_LANES > 1).  Bit-identical to the two launches.
+                              * tile, on a flag the inc blocks of the tiles they read publish (write-through stores, agent-scope flag).  The same launch
+                              * eagerly, under stream capture (HN_OPT_GRAPH: the launch's epoch is derived on the device there) and in every pipeline
+                              * lane.  Bit-identical to the two launches.
                               * ASSUMES that the workgroups of a launch are dispatched in index order (true of the hardware dispatcher; a tool that
                               * re-orders or caps dispatch must run with 0): a conv_signal block whose inputs have not arrived after ~2 M polls
                               * writes NaN into its tile AND raises the context's sticky device error (HN_ERR_STATE from this or the next hn_step) */

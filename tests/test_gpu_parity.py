@@ -583,6 +583,33 @@ def test_inc_and_conv_signal_as_one_launch_is_bit_identical_to_two(n, b):
         assert torch.equal(a, c)
 
 
+@pytest.mark.parametrize("opt,val", [("graph", 1), ("lanes", 2)])
+def test_merged_level0_launch_under_capture_and_in_pipeline_lanes(opt, val):
+    """r6: k_dc_asm_pair derives its epoch on the device (a per-sample counter of ended blocks), so a captured iteration that is replayed with the same kernel
+    arguments and two pipeline lanes on disjoint sample slots run the SAME merged launch as the plain loop (r5: they fell back to two launches).  Bits equal
+    to the two-launch eager path over 25 iterations, a second call on the same context (counters continue) and a smaller batch in between."""
+    from helmnet_amd import IterativeSolver
+    from helmnet_amd.phantoms import ring_sos_batch
+    n, b = 256, 6
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=17)).to(DEV)
+    s0 = IterativeSolver.from_exported_weights(); s0.freeze(); s0.to(DEV)
+    s0.set_domain_size(n, source_location=SRC[n])
+    s0.engine().set_option("dc_pair", 0)
+    o = s0.forward(sos, num_iterations=25, residuals="norms")
+    want = (o["wavefields"][0].clone(), o["last_residual"].clone(), s0.f.get_states(flatten=True).clone())
+    want3 = s0.forward(sos[:3], num_iterations=25, residuals="norms")["wavefields"][0].clone()
+    s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV)
+    s.set_domain_size(n, source_location=SRC[n])
+    s.engine().set_option(opt, val)
+    for call in range(2):
+        o = s.forward(sos, num_iterations=25, residuals="norms")
+        got = (o["wavefields"][0], o["last_residual"], s.f.get_states(flatten=True))
+        for a, c in zip(got, want):
+            assert torch.equal(a, c), (opt, call)
+        assert torch.equal(s.forward(sos[:3], num_iterations=25, residuals="norms")["wavefields"][0], want3), (opt, call)
+    s.engine().check_async_errors()
+
+
 @pytest.mark.parametrize("n,b", [(256, 8), (128, 4), (96, 5), (512, 2)])
 def test_side_stream_synchronised_by_device_flags_is_bit_identical_to_events(n, b):
     """HN_OPT_SIDE_SYNC (hn_unet.hip): between the iterations of one hn_step call the hidden-state kernels on the side stream are released by a word the
