@@ -547,7 +547,9 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     if (rel_flag) { rel_hook.store = ctx->sync_flags; rel_hook.store_epoch = sync_epoch; }
     // (the deep kernel carries the release: its start = everything before it is complete.  [measured, r6: profiles/r6_release_point_ab.txt] the last
     // layer-by-layer `down` carrying it instead -- the hidden-state kernels one kernel earlier -- loses 2 % at 256^2 x 32 and 512^2 x 16; conv_state_0 alone
-    // released by down_0 (a matrix-core kernel with registers, LDS and bandwidth to spare) loses 2.5 %: it runs on into conv_signal_1, profiles/r6_cs_split_ab.txt)
+    // released by down_0 (a matrix-core kernel with registers, LDS and bandwidth to spare) loses 2.5 %: it runs on into conv_signal_1, profiles/r6_cs_split_ab.txt;
+    // the first decoder `up` BEHIND the deep kernel carrying it -- k_deepx alone, conv_state beside level 1's decoder -- loses 2.5 % (1.5 % at 512^2), also with the
+    // 16-wavefront k_deepx that is 9 us faster alone: profiles/r6_release_late_ab.txt)
     if (flags) { join_hook.wait = ctx->sync_flags + 32; join_hook.wait_epoch = sync_epoch; join_hook.err = ctx->sync_err_dev; }
     for (int d = 0; d < n_enc; ++d) {
         const int m = n >> d;
