@@ -805,7 +805,9 @@ int deepx_levels(const hn_ctx* ctx, int batch) {
     // one workgroup per CU (88 KB of LDS): one round of workgroups (32 maps = 256 workgroups) beats the layers it replaces; beyond that (batch 40: 1596 vs 1629 it/s; batch 64: two full rounds)
     // the per-sample kernel + the layer-by-layer level are ahead [measured, r6: 256^2 x 64 1145 vs 1173 it/s]
     if (batch > 32) return 0;
-    if (ctx->opt_deep < 2 || ctx->precision != HN_PREC_FP32 || ctx->dx_flags == nullptr) return 0;
+    // (the 16-bit modes keep levels >= 2 in fp32 -- their DoubleConvs are narrower than 128, their 8x8 convolutions than 64 outputs: hn_mfma.hip -- so the
+    // kernel serves them too; the vector-ALU-only mode does not reach this function)
+    if (ctx->opt_deep < 2 || ctx->precision == HN_PREC_FP32_VALU || ctx->dx_flags == nullptr) return 0;
     const int n = ctx->tab.n, depth = ctx->depth;
     // (at least one level above the fused ones: the decoder's output buffer of level 0 does not exist -- decode_0 ends in the wavefield update)
     if (depth >= 3 && (n >> (depth - 2)) == 64 && (n >> (depth - 1)) == 32) return 2;

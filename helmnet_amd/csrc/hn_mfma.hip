@@ -2269,8 +2269,9 @@ struct UpX {
 
 template <typename M>
 __global__ __launch_bounds__(256, 2) void k_up_x16(Src in, Dst out, const void* __restrict__ afr /*[2 px][4 bb][NPF][64] x 8*/,
-                                                    const float* __restrict__ bias, int Hin, int Win) {
+                                                    const float* __restrict__ bias, int Hin, int Win, SyncHook hook) {
     using C = UpX<M>;
+    sync_hook_begin(hook);   // (flag sync in the 16-bit modes, r6: the side stream's join rides on up_0 as in k_up_mfma)
     typedef typename M::V8 V8;
     typedef typename M::T T;
     __shared__ __attribute__((aligned(16))) unsigned char lds[C::LDS_BYTES];
@@ -2358,6 +2359,7 @@ __global__ __launch_bounds__(256, 2) void k_up_x16(Src in, Dst out, const void* 
             }
         }
     }
+    sync_hook_end(hook);
 }
 
 template <int CA, int CB, int CC, int EPI>
@@ -2694,9 +2696,9 @@ void launch_up(const hn_ctx* ctx, Src in, Dst out, const float* frag, const floa
         const dim3 g(cdiv_(Win, 16), cdiv_(Hin + 1, 20), batch);
         const float* split = frag + (size_t)kFeat * kFeat * 64;
         const float* half = split + k8_split_floats();
-        if (mode == 1) hipLaunchKernelGGL((k_up_x16<SplitBf16>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
-        else if (mode == 3) hipLaunchKernelGGL((k_up_x16<SplitBf16x2>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win);
-        else hipLaunchKernelGGL((k_up_x16<HalfF16>), g, dim3(256), 0, s, in, out, half, bias, Hin, Win);
+        if (mode == 1) hipLaunchKernelGGL((k_up_x16<SplitBf16>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win, hook);
+        else if (mode == 3) hipLaunchKernelGGL((k_up_x16<SplitBf16x2>), g, dim3(256), 0, s, in, out, split, bias, Hin, Win, hook);
+        else hipLaunchKernelGGL((k_up_x16<HalfF16>), g, dim3(256), 0, s, in, out, half, bias, Hin, Win, hook);
         return;
     }
     constexpr int up_small = 64;  // at and below: the all-channels-at-once kernel (few tiles, latency-bound)

@@ -495,8 +495,7 @@ int unet_forward(hn_ctx* ctx, Src in_wf, Src in_res, Src in_sig, const float* st
     const int policy = side != nullptr ? ctx->opt_side_stream : 0;
     // flag sync (hn_internal.h: sync_flags): in an iteration whose join may be deferred (all but the last of an hn_step call) the join is one thread of
     // up_0 polling a word, and, where the deep kernel exists to carry the store, the release is a word too: no event packet touches the main stream
-    const bool flags = eager && defer_join && policy == 1 && ctx->opt_side_sync == 1 && ctx->sync_flags != nullptr && ctx->precision == HN_PREC_FP32 &&
-                       n_enc >= 1;
+    const bool flags = eager && defer_join && policy == 1 && ctx->opt_side_sync == 1 && ctx->sync_flags != nullptr && mfma && n_enc >= 1;   // (r6: the 16-bit modes too)
     const bool rel_flag = flags && (deep || deepx);   // otherwise the release stays an event record (no other kernel sits where the store belongs)
     const unsigned sync_epoch = flags ? ++ctx->sync_epoch : 0u;
     auto release_states = [&](int d0, int d1, hipEvent_t ev) -> int {

@@ -82,7 +82,8 @@ enum hn_option {
     HN_OPT_DEEP = 3,         /* the deep levels as one launch.  1: deepest level (32^2) + bottleneck in one per-sample LDS kernel (hn_deep.hip; 256^2 at
                               * depth 4).  2 (default): where the last encoder level is 64^2 (512^2) or the last two are 64^2 and 32^2 (256^2), those
                               * levels + the bottleneck as ONE launch with EIGHT workgroups per sample that exchange halo rows through flag-guarded
-                              * global memory (hn_deepx.hip; batches up to 32 maps per call, fp32 arithmetic, every activation), else as 1.  0: layer
+                              * global memory (hn_deepx.hip; batches up to 32 maps per call, every activation; fp32 arithmetic, which is what the 16-bit
+                              * modes use below level 1 anyway -- they take this launch too), else as 1.  0: layer
                               * by layer.  Its waits are bounded like HN_OPT_SIDE_SYNC's and report through hn_check_async_errors                   */
     HN_OPT_SPECTRAL_PFA = 4, /* 0/1: prime-factor FFT for n = 3 * 2^k, 5 * 2^k, 7 * 2^k instead of the dense n x n operator (default 1;
                               * read by the next hn_set_domain)                                                     */

@@ -824,3 +824,32 @@ def test_input_layer_with_the_sigma_channels_as_a_precomputed_map(weights, n, b)
         assert (a - c).abs().max().item() <= 4e-6 * scale
         assert (a - w).abs().max().item() <= 1e-5 * scale and (c - w).abs().max().item() <= 1e-5 * scale
     assert (runs[1] - runs[0]).abs().max().item() <= 1e-4
+
+
+@pytest.mark.parametrize("mode,n,b", [("fp16", 256, 3), ("bf16x3", 256, 2), ("fp16", 512, 1)])
+def test_deep_levels_as_one_launch_in_the_16_bit_modes(mode, n, b):
+    """r6: the 16-bit modes keep every layer below level 1 in fp32 (hn_mfma.hip: DoubleConvs narrower than 128, 8x8 convolutions with fewer than 64 outputs), so
+    k_deepx serves them too, and the side stream's flag sync rides on k_up_x16.  One teacher-forced step with HN_OPT_DEEP 2 against 1 in the SAME mode: levels 0 / 1
+    run the same 16-bit kernels on the same inputs, the deep levels differ in fp32 summation order only (4e-6 of max, the bar between fp32 kernel sets); a free
+    run of 40 iterations stays within 1e-4."""
+    from helmnet_amd import IterativeSolver
+    ti = {k: torch.from_numpy(v).to(DEV) for k, v in teacher_inputs(n, b, seed=123).items()}
+    sos = torch.from_numpy(ring_sos_batch(n, b, seed=124)).to(DEV)
+    outs, runs = {}, {}
+    for deep in (2, 1):
+        s = IterativeSolver.from_exported_weights(); s.freeze(); s.to(DEV); s.set_unet_precision(mode)
+        s.set_domain_size(n, source_location=SRC.get(n, [n // 8, n // 2]))
+        s.engine().set_option("deep", deep)
+        k_sq, _ = s.get_initials(ti["sos"])
+        s.f.set_states(ti["states"], flatten=True)
+        wf2, res2 = s.single_step(ti["wf"], k_sq, ti["res"])
+        outs[deep] = (wf2.clone(), res2.clone(), s.f.get_states(flatten=True).clone())
+        runs[deep] = s.forward(sos, num_iterations=40, residuals="norms")["wavefields"][0].clone()
+        s.engine().check_async_errors()
+    for a, c in zip(outs[2], outs[1]):
+        assert (a - c).abs().max().item() <= 4e-6 * c.abs().max().item()
+    # fp16: operands are rounded to 11 bits at levels 0 / 1, so a last-bit difference below is a 5e-4 difference above every now and then and the free runs part
+    # at the mode's own noise (its bar against the reference is 1e-3 of the wavefield after 100 iterations); the split-bf16 mode keeps the fp32 bar
+    d, scale = (runs[2] - runs[1]).abs().max().item(), runs[1].abs().max().item()
+    print(f"[{mode} {n}] free run deep 2 vs 1: Linf {d:.3e}, max |wf| {scale:.3e}")
+    assert torch.isfinite(runs[2]).all() and d <= (1e-4 if mode == "bf16x3" else 2e-2 * scale)
